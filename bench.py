@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GAE forward+backward samples/s at T=1024, B=65536 fp32 per GPU (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W            # N=1 direct; N>1 under torch.distributed.run
+
+A "step" is one pass of the hot path over one batch of synthetic input: ``adv = GAE(value, reward)``
+followed by ``adv.backward(grad_adv)`` through the drop-in ``hpc_rll.rl_utils.gae.GAE`` module (HIP
+kernels behind the C ABI).  Inputs are resident in HBM before the timed region.  The batch axis shards
+across ranks with NO data-path collective (every trajectory is independent), so per-GPU
+work is fixed as N grows: weak scaling; ``value`` = (N * T * B) * K / max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     -- dominant kernel's algorithmic bytes per launch / its average launch duration measured
+                  live with HIP events on the launch stream, vs the 8 TB/s HBM3E peak.
+  cpu_baseline -- oracle/gae_ref.c (a port of the reference algorithm, OpenMP) timed on this host, on a
+                  bounded sample of the same workload.  A reported baseline, not the target.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+
+import torch  # noqa: E402
+
+T_DEFAULT, B_DEFAULT = 1024, 65536
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(T, B, gamma, lam, budget_s=12.0):
+    """Time the C port of the reference GAE (fwd + adjoint bwd) on the host cores.  oracle/ is used here only
+    as the reported CPU baseline."""
+    so = os.path.join(ROOT, "oracle", "_build", "libgae_ref.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.gae_ref_forward.argtypes = [fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
+    lib.gae_ref_backward.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
+    lib.gae_ref_num_threads.restype = ctypes.c_int
+    Bs = min(B, 16384)  # bounded sample: a quarter of the batch axis (columns are independent)
+    g = torch.Generator().manual_seed(0)
+    v, r, ga = torch.randn(T + 1, Bs, generator=g), torch.randn(T, Bs, generator=g), torch.randn(T, Bs, generator=g)
+    adv, gv, gr, tab = torch.empty(T, Bs), torch.empty(T + 1, Bs), torch.empty(T, Bs), torch.empty(T)
+    P = lambda t: ctypes.cast(t.data_ptr(), fp)  # noqa: E731
+
+    def one():
+        lib.gae_ref_forward(P(v), P(r), P(adv), T, Bs, gamma, lam)
+        lib.gae_ref_backward(P(ga), P(gv), P(gr), P(tab), T, Bs, gamma, lam)
+
+    one()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or reps >= 200:
+            break
+    return {"value": T * Bs * reps / dt, "unit": "samples/s", "cores": int(lib.gae_ref_num_threads()),
+            "kind": "port", "sample": f"T={T} B={Bs} (1/{B // Bs} of the batch axis) x {reps} fwd+bwd passes, "
+                                      f"oracle/gae_ref.c OpenMP, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--T", type=int, default=T_DEFAULT)
+    ap.add_argument("--B", type=int, default=B_DEFAULT, help="batch per GPU")
+    ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hpc_rll product path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.gae import GAE
+
+    T, B, gamma, lam = args.T, args.B, 0.99, 0.97
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    value = torch.randn(T + 1, B, device=dev, generator=g).requires_grad_(True)
+    reward = torch.randn(T, B, device=dev, generator=g).requires_grad_(True)
+    grad_adv = torch.randn(T, B, device=dev, generator=g)
+    gae = GAE(T, B).to(dev)
+
+    def step():
+        value.grad = None
+        reward.grad = None
+        adv = gae(value, reward, gamma, lam)
+        adv.backward(grad_adv)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # ---- per-kernel durations with HIP events on the launch stream (torch's current stream)
+    v_d, r_d = value.detach(), reward.detach()
+    adv = torch.empty_like(r_d)
+    gv, gr = torch.empty_like(v_d), torch.empty_like(r_d)
+
+    def timed(fn, n=20):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    t_fwd = timed(lambda: U.GaeForward([v_d, r_d], [adv], gamma, lam))
+    t_bwd = timed(lambda: U.GaeBackward([grad_adv], [gv, gr], gamma, lam))
+    bytes_launch = 12 * T * B + 4 * B  # either direction: SURVEY.md 8(d)
+    dom, t_dom = ("gae_bwd_kernel", t_bwd) if t_bwd >= t_fwd else ("gae_fwd_kernel", t_fwd)
+
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "gae_traffic.json")
+    if os.path.exists(tj):
+        try:
+            rec = json.load(open(tj))
+            if rec.get("T") == T and rec.get("B") == B:
+                traffic = rec.get(dom)
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        samples = T * B * world
+        out = {
+            "metric": "gae_fwd_bwd_samples_per_sec",
+            "value": samples * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"GAE fwd+bwd, T={T}, B={B} per GPU, fp32 (BASELINE.json configs[1])",
+                       "T": T, "B_per_gpu": B, "global_B": B * world,
+                       "parallelism": f"batch-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_launch / t_dom / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": bytes_launch / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "fwd_us": t_fwd * 1e6, "bwd_us": t_bwd * 1e6,
+                         "fwd_bwd_frac": (2 * bytes_launch) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS},
+            "cpu_baseline": None if args.skip_cpu_baseline else cpu_baseline(T, B, gamma, lam),
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

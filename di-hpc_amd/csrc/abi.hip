@@ -1,0 +1,18 @@
+// abi.hip -- version + status strings of the C ABI (include/hpc_rll_hip.h).
+#include <hip/hip_runtime.h>
+
+#include "hpc_rll_hip.h"
+
+extern "C" int hpc_rll_abi_version(void) { return 1; }
+
+extern "C" const char* hpc_rll_status_string(int status) {
+    switch (status) {
+        case HPC_RLL_OK: return "ok";
+        case HPC_RLL_EINVAL: return "hpc_rll: invalid argument (negative size or null pointer)";
+        case HPC_RLL_EALIGN: return "hpc_rll: pointer is not 4-byte aligned";
+        case HPC_RLL_EUNSUPPORTED: return "hpc_rll: shape/configuration not supported by the gfx950 kernels";
+        default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "hpc_rll: unknown status";
+}

@@ -1,0 +1,460 @@
+// gae.hip -- GAE forward + analytic backward for gfx950 (MI355X).
+//
+// Replaces the reference's GaeForward (src/rl_utils/gae.cu:8-28, gae_kernel.h:10-29: one thread
+// per column walking T serially, 32-thread blocks, `value` fetched twice) and adds the backward the
+// reference lacks (hpc_rll/rl_utils/gae.py:17-18 returns None).
+//
+// Maths.  With D_t = 1 + lambda*D_{t+1}, D_T = 0 and c_t = gamma*lambda*D_{t+1}/D_t:
+//     forward : adv_t = delta_t + c_t * adv_{t+1},   delta_t = r_t + gamma*V_{t+1} - V_t
+//     backward: d_t   = g_t + c_{t-1} * d_{t-1};  dL/dr_t = d_t;  dL/dV_t = -d_t + gamma*d_{t-1}
+// Both are first-order affine recurrences with a LANE-UNIFORM coefficient, so a chunk [t0,t1) can be
+// scanned locally from a zero carry and repaired afterwards:  adv_t = L_t + P_t * adv_{t1},
+// P_t = prod_{s=t}^{t1-1} c_s.  That is what buys time-parallelism without a second HBM sweep.
+//
+// Mapping (HBM-bound, 12 B/sample each way; no data reuse -> no LDS staging of the payload):
+//   * lane <-> V consecutive columns (V*4-byte coalesced loads along B, 64*V columns per wave row);
+//   * wave <-> LC consecutive time steps, held entirely in VGPRs (all 2*LC+1 row loads of a chunk are
+//     independent and issued back to back -> deep memory-level parallelism per wave);
+//   * workgroup = NW waves covering NW*LC consecutive steps of one column tile; the NW chunk carries
+//     (one L and one lane-uniform P per wave) are exchanged through a double-buffered LDS slot with
+//     one barrier per NW*LC steps; the workgroup then walks the rest of T carrying V floats per lane.
+//   * grid = ceil(B / (64*V)) workgroups, no inter-workgroup communication.
+// HBM traffic = algorithmic + the one `value` row per chunk boundary that two waves both read
+// (an L2 hit: same workgroup, same instant).
+#include <hip/hip_runtime.h>
+
+#include <initializer_list>
+#include <type_traits>
+
+#include "hpc_rll_hip.h"
+#include "wave.hpp"
+
+namespace hpc_rll {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// coefficient table: c_t = gamma*lambda*S(k-1)/S(k), k = T-t, S(k) = sum_{j<k} lambda^j (= D_t).
+// Closed form in fp64 (expm1/log keep full relative precision as lambda -> 1).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double geom_sum(double lam, int k) {
+    if (k <= 0) return 0.0;
+    if (lam == 1.0) return (double)k;
+    if (lam > 0.0) return -expm1((double)k * log(lam)) / (1.0 - lam);
+    return (1.0 - pow(lam, (double)k)) / (1.0 - lam);
+}
+
+__global__ void gae_coef_kernel(float* __restrict__ coef, int T, float gamma, float lambda) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int k = T - t;
+    const double lam = (double)lambda;
+    coef[t] = (float)((double)gamma * lam * geom_sum(lam, k - 1) / geom_sum(lam, k));
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int V, int LC, int NW>
+__global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restrict__ value,
+                                                          const float* __restrict__ reward,
+                                                          float* __restrict__ adv,
+                                                          const float* __restrict__ coef, int T, int B,
+                                                          float gamma) {
+    constexpr int TILE = 64 * V;
+    // one LDS object: [buf][wave][TILE] chunk-head values, then [buf][wave] chunk products
+    __shared__ float lds[2 * NW * TILE + 2 * NW];
+    float* const s_l0 = lds;
+    float* const s_p0 = lds + 2 * NW * TILE;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    const bool col_ok = col < (long)B;  // dispatcher guarantees B % V == 0: packs never straddle B
+
+    float carry[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) carry[k] = 0.f;
+
+    constexpr int SPAN = NW * LC;
+    const int n_iter = (T + SPAN - 1) / SPAN;
+
+    for (int it = 0; it < n_iter; ++it) {
+        // chunks are aligned to the END of the trajectory; wave NW-1 owns the latest chunk
+        const int t1 = T - (it * NW + (NW - 1 - w)) * LC;  // exclusive end, <= T, may be <= 0
+        const int t0 = t1 - LC;
+        const int buf = it & 1;
+
+        float L[LC][V];
+        float P[LC];
+
+        if (t0 >= 0) {
+            // ---- fast path: the whole chunk is inside [0,T) ----
+            Pack<V> vr[LC + 1], rr[LC];
+            if (col_ok) {
+                const float* vp = value + (size_t)t0 * B + col;
+                const float* rp = reward + (size_t)t0 * B + col;
+#pragma unroll
+                for (int j = LC; j >= 0; --j) vr[j] = load_pack<V>(vp + (size_t)j * B);
+#pragma unroll
+                for (int j = LC - 1; j >= 0; --j) rr[j] = load_pack<V>(rp + (size_t)j * B);
+            } else {
+#pragma unroll
+                for (int j = 0; j <= LC; ++j)
+#pragma unroll
+                    for (int k = 0; k < V; ++k) vr[j].v[k] = 0.f;
+#pragma unroll
+                for (int j = 0; j < LC; ++j)
+#pragma unroll
+                    for (int k = 0; k < V; ++k) rr[j].v[k] = 0.f;
+            }
+            float a[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) a[k] = 0.f;
+            float p = 1.f;
+#pragma unroll
+            for (int j = LC - 1; j >= 0; --j) {
+                const float c = coef[t0 + j];  // wave-uniform address -> scalar load
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float delta = fmaf(gamma, vr[j + 1].v[k], rr[j].v[k]) - vr[j].v[k];
+                    a[k] = fmaf(c, a[k], delta);
+                    L[j][k] = a[k];
+                }
+                p *= c;
+                P[j] = p;
+            }
+        } else {
+            // ---- ragged head of the trajectory (only in the last iteration) ----
+            float a[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) a[k] = 0.f;
+            float p = 1.f;
+#pragma unroll
+            for (int j = LC - 1; j >= 0; --j) {
+                const int t = t0 + j;
+                if (t >= 0) {
+                    const float c = coef[t];
+                    Pack<V> v0, v1, r;
+                    if (col_ok) {
+                        v0 = load_pack<V>(value + (size_t)t * B + col);
+                        v1 = load_pack<V>(value + (size_t)(t + 1) * B + col);
+                        r = load_pack<V>(reward + (size_t)t * B + col);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < V; ++k) v0.v[k] = v1.v[k] = r.v[k] = 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const float delta = fmaf(gamma, v1.v[k], r.v[k]) - v0.v[k];
+                        a[k] = fmaf(c, a[k], delta);
+                    }
+                    p *= c;
+                }
+#pragma unroll
+                for (int k = 0; k < V; ++k) L[j][k] = a[k];
+                P[j] = p;
+            }
+        }
+
+        // ---- publish this chunk's head (value at t0 with zero carry-in, and the product over the chunk)
+#pragma unroll
+        for (int k = 0; k < V; ++k) s_l0[(buf * NW + w) * TILE + lane * V + k] = L[0][k];
+        if (lane == 0) s_p0[buf * NW + w] = P[0];
+        __syncthreads();
+
+        // ---- resolve carries: walk the NW chunks from the latest to the earliest
+        float A[V], Aw[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { A[k] = carry[k]; Aw[k] = 0.f; }
+#pragma unroll
+        for (int u = NW - 1; u >= 0; --u) {
+            if (u == w) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) Aw[k] = A[k];
+            }
+            const float p0 = s_p0[buf * NW + u];
+#pragma unroll
+            for (int k = 0; k < V; ++k) A[k] = fmaf(p0, A[k], s_l0[(buf * NW + u) * TILE + lane * V + k]);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) carry[k] = A[k];
+
+        // ---- repair and store
+        if (col_ok) {
+#pragma unroll
+            for (int j = LC - 1; j >= 0; --j) {
+                const int t = t0 + j;
+                if (t >= 0) {
+                    Pack<V> o;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) o.v[k] = fmaf(P[j], Aw[k], L[j][k]);
+                    store_pack<V>(adv + (size_t)t * B + col, o);
+                }
+            }
+        }
+        // no second barrier: the next iteration writes the other LDS buffer, and nobody can be two
+        // iterations ahead because every wave must pass the next iteration's barrier first.
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: d_t = g_t + c_{t-1} d_{t-1} (forward in time), chunks aligned to t = 0, wave 0 earliest.
+// ------------------------------------------------------------------------------------------------
+template <int V, int LC, int NW>
+__global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restrict__ grad_adv,
+                                                          float* __restrict__ grad_value,
+                                                          float* __restrict__ grad_reward,
+                                                          const float* __restrict__ coef, int T, int B,
+                                                          float gamma) {
+    constexpr int TILE = 64 * V;
+    __shared__ float lds[2 * NW * TILE + 2 * NW];
+    float* const s_l0 = lds;
+    float* const s_p0 = lds + 2 * NW * TILE;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    const bool col_ok = col < (long)B;
+
+    float carry[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) carry[k] = 0.f;
+
+    constexpr int SPAN = NW * LC;
+    const int n_iter = (T + SPAN - 1) / SPAN;
+
+    for (int it = 0; it < n_iter; ++it) {
+        const int t0 = (it * NW + w) * LC;
+        const int buf = it & 1;
+
+        float L[LC][V];
+        float Q[LC];
+        {
+            float a[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) a[k] = 0.f;
+            float q = 1.f;
+            if (t0 + LC <= T) {
+                Pack<V> g[LC];
+                if (col_ok) {
+                    const float* gp = grad_adv + (size_t)t0 * B + col;
+#pragma unroll
+                    for (int j = 0; j < LC; ++j) g[j] = load_pack<V>(gp + (size_t)j * B);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < LC; ++j)
+#pragma unroll
+                        for (int k = 0; k < V; ++k) g[j].v[k] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < LC; ++j) {
+                    const int t = t0 + j;
+                    const float c = (t > 0) ? coef[t - 1] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        a[k] = fmaf(c, a[k], g[j].v[k]);
+                        L[j][k] = a[k];
+                    }
+                    q *= c;
+                    Q[j] = q;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < LC; ++j) {
+                    const int t = t0 + j;
+                    if (t < T) {
+                        const float c = (t > 0) ? coef[t - 1] : 0.f;
+                        Pack<V> g;
+                        if (col_ok) {
+                            g = load_pack<V>(grad_adv + (size_t)t * B + col);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < V; ++k) g.v[k] = 0.f;
+                        }
+#pragma unroll
+                        for (int k = 0; k < V; ++k) a[k] = fmaf(c, a[k], g.v[k]);
+                        q *= c;
+                    }
+#pragma unroll
+                    for (int k = 0; k < V; ++k) L[j][k] = a[k];
+                    Q[j] = q;
+                }
+            }
+        }
+
+#pragma unroll
+        for (int k = 0; k < V; ++k) s_l0[(buf * NW + w) * TILE + lane * V + k] = L[LC - 1][k];
+        if (lane == 0) s_p0[buf * NW + w] = Q[LC - 1];
+        __syncthreads();
+
+        float A[V], Aw[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { A[k] = carry[k]; Aw[k] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            if (u == w) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) Aw[k] = A[k];
+            }
+            const float q0 = s_p0[buf * NW + u];
+#pragma unroll
+            for (int k = 0; k < V; ++k) A[k] = fmaf(q0, A[k], s_l0[(buf * NW + u) * TILE + lane * V + k]);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) carry[k] = A[k];
+
+        if (col_ok) {
+            float prev[V];  // d_{t-1}
+#pragma unroll
+            for (int k = 0; k < V; ++k) prev[k] = Aw[k];
+#pragma unroll
+            for (int j = 0; j < LC; ++j) {
+                const int t = t0 + j;
+                if (t < T) {
+                    Pack<V> d, gv;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        d.v[k] = fmaf(Q[j], Aw[k], L[j][k]);
+                        gv.v[k] = fmaf(gamma, prev[k], -d.v[k]);
+                        prev[k] = d.v[k];
+                    }
+                    if (grad_reward) store_pack<V>(grad_reward + (size_t)t * B + col, d);
+                    if (grad_value) {
+                        store_pack<V>(grad_value + (size_t)t * B + col, gv);
+                        if (t == T - 1) {  // bootstrap row: dL/dV_T = gamma * d_{T-1}
+                            Pack<V> last;
+#pragma unroll
+                            for (int k = 0; k < V; ++k) last.v[k] = gamma * d.v[k];
+                            store_pack<V>(grad_value + (size_t)T * B + col, last);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: configuration choice + dispatch
+// ------------------------------------------------------------------------------------------------
+struct Cfg { int v, lc, nw; };
+
+inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Widest pack the shape and pointers allow.
+inline int max_vec(int B, std::initializer_list<const void*> ptrs) {
+    for (int v : {4, 2}) {
+        bool ok = (B % v) == 0;
+        for (const void* p : ptrs) ok = ok && aligned(p, 4 * v);
+        if (ok) return v;
+    }
+    return 1;
+}
+
+inline Cfg choose_cfg(int T, int B, int vmax, int v, int lc, int nw) {
+    // Heuristic (tuned on MI355X): keep >= ~2 workgroups per CU before widening
+    // the per-lane pack; 16-step chunks; as many waves as there are chunks, up to 8.
+    if (v == 0) {
+        v = vmax;
+        while (v > 1 && (B + 64 * v - 1) / (64 * v) < 512) v >>= 1;
+    }
+    if (v > vmax) v = vmax;
+    if (lc == 0) lc = (v == 4) ? 8 : 16;
+    if (nw == 0) {
+        const int chunks = (T + lc - 1) / lc;
+        nw = 1;
+        while (nw < 8 && nw < chunks) nw <<= 1;
+    }
+    return Cfg{v, lc, nw};
+}
+
+#define HPC_RLL_GAE_DISPATCH(KERNEL, ...)                                                  \
+    do {                                                                                   \
+        bool hit = false;                                                                  \
+        auto go = [&](auto V_, auto LC_, auto NW_) {                                       \
+            constexpr int V = decltype(V_)::value, LC = decltype(LC_)::value,              \
+                          NW = decltype(NW_)::value;                                       \
+            if (cfg.v == V && cfg.lc == LC && cfg.nw == NW) {                              \
+                const unsigned grid = (unsigned)((B + 64 * V - 1) / (64 * V));             \
+                hipLaunchKernelGGL((KERNEL<V, LC, NW>), dim3(grid), dim3(NW * 64), 0, st,  \
+                                   __VA_ARGS__);                                           \
+                hit = true;                                                                \
+            }                                                                              \
+        };                                                                                 \
+        for_each_cfg(go);                                                                  \
+        if (!hit) return HPC_RLL_EUNSUPPORTED;                                             \
+    } while (0)
+
+template <int N> using I = std::integral_constant<int, N>;
+
+template <class F>
+inline void for_each_cfg(F&& f) {
+    // V x LC x NW grid; (V=4, LC=16) is left out (VGPR budget)
+#define HPC_RLL_NW_ROW(V, LC) \
+    f(I<V>{}, I<LC>{}, I<1>{}); f(I<V>{}, I<LC>{}, I<2>{}); f(I<V>{}, I<LC>{}, I<4>{}); \
+    f(I<V>{}, I<LC>{}, I<8>{}); f(I<V>{}, I<LC>{}, I<16>{});
+    HPC_RLL_NW_ROW(1, 4) HPC_RLL_NW_ROW(1, 8) HPC_RLL_NW_ROW(1, 16)
+    HPC_RLL_NW_ROW(2, 4) HPC_RLL_NW_ROW(2, 8) HPC_RLL_NW_ROW(2, 16)
+    HPC_RLL_NW_ROW(4, 4) HPC_RLL_NW_ROW(4, 8)
+#undef HPC_RLL_NW_ROW
+}
+
+inline int check_launch() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HPC_RLL_OK : (int)e;
+}
+
+}  // namespace
+}  // namespace hpc_rll
+
+using namespace hpc_rll;
+
+extern "C" int hpc_rll_gae_coef(float* coef, int T, float gamma, float lambda, void* stream) {
+    if (T < 0) return HPC_RLL_EINVAL;
+    if (T == 0) return HPC_RLL_OK;
+    if (!coef) return HPC_RLL_EINVAL;
+    hipLaunchKernelGGL(gae_coef_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, coef, T, gamma,
+                       lambda);
+    return check_launch();
+}
+
+extern "C" int hpc_rll_gae_forward_ex(const float* value, const float* reward, float* adv, const float* coef,
+                                      int T, int B, float gamma, int vec, int lc, int nw, void* stream) {
+    if (T < 0 || B < 0) return HPC_RLL_EINVAL;
+    if (T == 0 || B == 0) return HPC_RLL_OK;
+    if (!value || !reward || !adv || !coef) return HPC_RLL_EINVAL;
+    if (!aligned(value, 4) || !aligned(reward, 4) || !aligned(adv, 4) || !aligned(coef, 4)) return HPC_RLL_EALIGN;
+    const Cfg cfg = choose_cfg(T, B, max_vec(B, {value, reward, adv}), vec, lc, nw);
+    hipStream_t st = (hipStream_t)stream;
+    HPC_RLL_GAE_DISPATCH(gae_fwd_kernel, value, reward, adv, coef, T, B, gamma);
+    return check_launch();
+}
+
+extern "C" int hpc_rll_gae_forward(const float* value, const float* reward, float* adv, const float* coef, int T,
+                                   int B, float gamma, void* stream) {
+    return hpc_rll_gae_forward_ex(value, reward, adv, coef, T, B, gamma, 0, 0, 0, stream);
+}
+
+extern "C" int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value, float* grad_reward,
+                                       const float* coef, int T, int B, float gamma, int vec, int lc, int nw,
+                                       void* stream) {
+    if (T < 0 || B < 0) return HPC_RLL_EINVAL;
+    if (B == 0) return HPC_RLL_OK;
+    if (T == 0) {  // grad_value has one row (the bootstrap value), which adv does not depend on
+        if (grad_value) return (int)hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)B, (hipStream_t)stream);
+        return HPC_RLL_OK;
+    }
+    if (!grad_adv || !coef) return HPC_RLL_EINVAL;
+    if (!grad_value && !grad_reward) return HPC_RLL_OK;
+    if (!aligned(grad_adv, 4) || !aligned(grad_value, 4) || !aligned(grad_reward, 4) || !aligned(coef, 4))
+        return HPC_RLL_EALIGN;
+    const Cfg cfg = choose_cfg(T, B, max_vec(B, {grad_adv, grad_value, grad_reward}), vec, lc, nw);
+    hipStream_t st = (hipStream_t)stream;
+    HPC_RLL_GAE_DISPATCH(gae_bwd_kernel, grad_adv, grad_value, grad_reward, coef, T, B, gamma);
+    return check_launch();
+}
+
+extern "C" int hpc_rll_gae_backward(const float* grad_adv, float* grad_value, float* grad_reward, const float* coef,
+                                    int T, int B, float gamma, void* stream) {
+    return hpc_rll_gae_backward_ex(grad_adv, grad_value, grad_reward, coef, T, B, gamma, 0, 0, 0, stream);
+}

@@ -1,0 +1,86 @@
+// wave.hpp -- wave64 device primitives for gfx950 (CDNA4).
+//
+// Re-design (not a translation) of the reference's include/hpc/rll/cuda/reduce.h:13-99 and
+// basic_math.h:15-29: those assume 32-lane warps and a 32-slot static shared array that is reused
+// without a barrier.  Here: 64-lane butterflies in registers, one LDS slot per
+// wave, explicit barriers, and deterministic two-stage scalar reductions (no float atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hpc_rll {
+
+constexpr int kWave = 64;
+
+// ---- vector packs (V consecutive fp32 columns owned by one lane) ----------------------------
+template <int V> struct Pack { float v[V]; };
+
+template <int V> __device__ __forceinline__ Pack<V> load_pack(const float* p);
+template <> __device__ __forceinline__ Pack<1> load_pack<1>(const float* p) { return Pack<1>{{*p}}; }
+template <> __device__ __forceinline__ Pack<2> load_pack<2>(const float* p) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    return Pack<2>{{t.x, t.y}};
+}
+template <> __device__ __forceinline__ Pack<4> load_pack<4>(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    return Pack<4>{{t.x, t.y, t.z, t.w}};
+}
+template <int V> __device__ __forceinline__ void store_pack(float* p, const Pack<V>& x);
+template <> __device__ __forceinline__ void store_pack<1>(float* p, const Pack<1>& x) { *p = x.v[0]; }
+template <> __device__ __forceinline__ void store_pack<2>(float* p, const Pack<2>& x) {
+    *reinterpret_cast<float2*>(p) = make_float2(x.v[0], x.v[1]);
+}
+template <> __device__ __forceinline__ void store_pack<4>(float* p, const Pack<4>& x) {
+    *reinterpret_cast<float4*>(p) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+}
+
+// ---- wave-level reductions (all 64 lanes end with the result) --------------------------------
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+// reductions restricted to aligned groups of G lanes (G a power of two <= 64)
+template <int G> __device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+template <int G> __device__ __forceinline__ float group_max(float x) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+
+// ---- workgroup reduction of K running sums -> K per-workgroup partials ------------------------
+// Every thread passes its K partial sums; thread 0 returns with the K workgroup totals in out[].
+// `lds` must hold K * (blockDim.x/64) floats.  Contains __syncthreads(): call from all threads.
+template <int K>
+__device__ __forceinline__ void block_sum(const float (&in)[K], float (&out)[K], float* lds) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s = wave_sum(in[k]);
+        if (lane == 0) lds[k * nw + w] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float s = 0.f;
+            for (int i = 0; i < nw; ++i) s += lds[k * nw + i];  // fixed order: deterministic
+            out[k] = s;
+        }
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+}  // namespace hpc_rll

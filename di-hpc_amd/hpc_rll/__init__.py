@@ -1,0 +1,7 @@
+"""hpc_rll for MI355X: the reference's ``hpc_rll.rl_utils`` / ``hpc_rll.torch_utils`` Python API on top of
+hand-written gfx950 HIP kernels (``libhpc_rll_hip.so``, C ABI in ``include/hpc_rll_hip.h``).
+
+Like the reference (all of whose ``__init__.py`` files are empty) nothing is re-exported here: import
+the leaf modules, e.g. ``from hpc_rll.rl_utils.gae import GAE``.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,84 @@
+"""ctypes loader for the C-ABI HIP library (include/hpc_rll_hip.h).
+
+There is deliberately NO fallback: if ``libhpc_rll_hip.so`` is missing or does not export a symbol,
+importing this module raises -- the product path never silently degrades to eager PyTorch.
+
+torch is imported first on purpose: torch's bundled ``libamdhip64.so`` has the same soname
+(``libamdhip64.so.7``) as the ROCm one the library was linked against, so once torch is loaded the
+dynamic linker binds our library to the SAME HIP runtime instance torch uses, and torch's streams /
+device pointers are valid inside our launches.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below, see docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libhpc_rll_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python di-hpc_amd/build.py` (hipcc --offload-arch=gfx950). "
+        "hpc_rll has no CPU/eager fallback.")
+
+lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_p = ctypes.c_void_p
+c_l = ctypes.c_int64
+
+# name -> argtypes; restype is always int (status) unless noted.  Mirrors include/hpc_rll_hip.h.
+SIGNATURES = {
+    "hpc_rll_gae_coef": [c_p, c_i, c_f, c_f, c_p],
+    "hpc_rll_gae_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    "hpc_rll_gae_backward": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    "hpc_rll_gae_forward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
+    "hpc_rll_gae_backward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
+}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError if the .so is stale: loud by design
+    _fn.argtypes = _args
+    _fn.restype = c_i
+lib.hpc_rll_abi_version.restype = c_i
+lib.hpc_rll_abi_version.argtypes = []
+lib.hpc_rll_status_string.restype = ctypes.c_char_p
+lib.hpc_rll_status_string.argtypes = [c_i]
+
+ABI_VERSION = 1
+if lib.hpc_rll_abi_version() != ABI_VERSION:
+    raise ImportError(f"libhpc_rll_hip.so ABI {lib.hpc_rll_abi_version()} != expected {ABI_VERSION}; rebuild")
+
+
+def check(status: int, what: str = "") -> None:
+    """Convert a C-ABI status into the reference's error behaviour (RuntimeError, cf. status.h:19-28)."""
+    if status != 0:
+        msg = lib.hpc_rll_status_string(status).decode()
+        raise RuntimeError(f"{what}: {msg} (status {status})")
+
+
+def stream_ptr(device=None) -> int:
+    """The current torch HIP stream for ``device`` as an integer hipStream_t."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def require(t, name, dtype=torch.float32, shape=None, device=None):
+    """Input validation the reference omits (status.h:15-17 defines CHECK_* but never uses them)."""
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: must live on a GPU (hpc_rll has no CPU path)")
+    if device is not None and t.device != device:
+        raise RuntimeError(f"{name}: on {t.device}, expected {device}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t

@@ -1,0 +1,62 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/hpc_rll_hip.h declares (no compute calls: there is no GPU on the CPU test tier)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "hpc_rll_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hpc_rll_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert "hpc_rll_gae_forward" in syms and "hpc_rll_gae_backward" in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from hpc_rll import _native
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"libhpc_rll_hip.so lacks {missing}"
+
+
+def test_python_signature_table_matches_header():
+    from hpc_rll import _native
+    declared = set(declared_symbols()) - {"hpc_rll_abi_version", "hpc_rll_status_string"}
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+
+
+def test_abi_version_and_status_strings():
+    from hpc_rll import _native
+    assert _native.lib.hpc_rll_abi_version() == _native.ABI_VERSION
+    assert _native.lib.hpc_rll_status_string(0) == b"ok"
+    assert b"invalid" in _native.lib.hpc_rll_status_string(-1)
+
+
+def test_no_oracle_import_in_product():
+    """The product package must never import the oracle (parity claims are void otherwise)."""
+    pkg = os.path.join(ROOT, "di-hpc_amd")
+    bad = []
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "ref_torch" in txt or "gae_ref" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    import pytest
+    import torch
+    import hpc_rl_utils
+    v, r, a = torch.zeros(3, 2), torch.zeros(2, 2), torch.zeros(2, 2)
+    with pytest.raises(RuntimeError):
+        hpc_rl_utils.GaeForward([v, r], [a], 0.99, 0.97)
