@@ -124,23 +124,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # ---- per-kernel durations with HIP events on the launch stream (torch's current stream)
+    # ---- per-kernel durations: HIP events on the launch stream (torch's current stream) around EVERY launch of
+    # a second, instrumented pass over the same K steps in the same alternating fwd/bwd order as the timed
+    # region (a kernel repeated back to back would find its inputs in the 256 MiB Infinity Cache and look
+    # faster than it is in the real sequence; rocprofv3 --kernel-trace of this command sees the same pattern).
     v_d, r_d = value.detach(), reward.detach()
     adv = torch.empty_like(r_d)
     gv, gr = torch.empty_like(v_d), torch.empty_like(r_d)
-
-    def timed(fn, n=20):
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / n * 1e-3
-
-    t_fwd = timed(lambda: U.GaeForward([v_d, r_d], [adv], gamma, lam))
-    t_bwd = timed(lambda: U.GaeBackward([grad_adv], [gv, gr], gamma, lam))
+    n_ev = max(args.steps, 10)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_ev + 1)]
+    U.GaeForward([v_d, r_d], [adv], gamma, lam)
+    U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
+    ev[0].record()
+    for i in range(n_ev):
+        U.GaeForward([v_d, r_d], [adv], gamma, lam)
+        ev[2 * i + 1].record()
+        U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
+        ev[2 * i + 2].record()
+    ev[-1].synchronize()
+    t_fwd = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(n_ev)) / n_ev * 1e-3
+    t_bwd = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(n_ev)) / n_ev * 1e-3
     bytes_launch = 12 * T * B + 4 * B  # either direction: SURVEY.md 8(d)
     dom, t_dom = ("gae_bwd_kernel", t_bwd) if t_bwd >= t_fwd else ("gae_fwd_kernel", t_fwd)
 

@@ -1,0 +1,318 @@
+// categorical.hip -- fused categorical-head row kernels shared by V-trace, UPGO and PPO (gfx950).
+//
+// Replaces the reference's categoricalTarget / categoricalBehaviour (vtrace_kernel.h:11-151),
+// crossEntropyKernel (upgo_kernel.h:40-81), categoricalProbEntropy / categoricalProb (ppo_kernel.h:12-150)
+// and the three backward kernels that consume their saved (rows,N) buffers (vtrace_kernel.h:235-273,
+// upgo_kernel.h:96-108, ppo_kernel.h:252-283).
+//
+// Reference design: one 256-thread block per row, 5-6 passes over the N logits through 5 block reductions,
+// and three N-wide gradient buffers written in forward and re-read in backward.  Here:
+//   * a row is owned by a GROUP of G lanes (G = 1..64, a power of two) that keeps the whole row in VGPRs:
+//     logits are read from HBM exactly once per kernel, 16 B per lane when N % 4 == 0;
+//   * max / sum-exp / sum p*log p are G-lane butterflies (no LDS, no barrier);
+//   * forward emits only per-row scalars (log pi(a), entropy); backward RECOMPUTES the softmax from the
+//     logits instead of loading saved buffers:  forward writes 8 B/row instead of 12*N B/row.
+//
+// Algorithmic HBM bytes: forward 4*N + 8 (+8 for the int64 action) per row; backward 4*N read + 4*N write.
+#include <hip/hip_runtime.h>
+
+#include "hpc_rll_hip.h"
+#include "wave.hpp"
+
+namespace hpc_rll {
+namespace {
+
+constexpr float kNegInf = -3.0e38f;
+
+// Per-lane slice of one row: E pieces of VEC consecutive floats, piece e at column (e*G + gl)*VEC.
+template <int G, int VEC, int E>
+struct RowSlice {
+    float x[E * VEC];
+    __device__ __forceinline__ void load(const float* __restrict__ row, int N, int gl) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = (e * G + gl) * VEC;
+            if (VEC == 4) {
+                if (c < N) {
+                    const float4 t = *reinterpret_cast<const float4*>(row + c);
+                    x[e * 4 + 0] = t.x; x[e * 4 + 1] = t.y; x[e * 4 + 2] = t.z; x[e * 4 + 3] = t.w;
+                } else {
+                    x[e * 4 + 0] = x[e * 4 + 1] = x[e * 4 + 2] = x[e * 4 + 3] = kNegInf;
+                }
+            } else {
+                x[e] = (c < N) ? row[c] : kNegInf;
+            }
+        }
+    }
+};
+
+// Softmax statistics of the row held by a G-lane group.  On return ex[i] = exp(x_i - max) (0 for padding).
+template <int G, int VEC, int E>
+__device__ __forceinline__ void row_stats(const RowSlice<G, VEC, E>& r, int N, int gl, long action,
+                                          float (&ex)[E * VEC], float& lse, float& sum, float& logp_a, float& ent) {
+    float m = kNegInf;
+#pragma unroll
+    for (int i = 0; i < E * VEC; ++i) m = fmaxf(m, r.x[i]);
+    m = group_max<G>(m);
+    float s = 0.f, xa = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int i = e * VEC + k;
+            const int c = (e * G + gl) * VEC + k;
+            ex[i] = (c < N) ? expf(r.x[i] - m) : 0.f;
+            s += ex[i];
+            xa += ((long)c == action) ? r.x[i] : 0.f;
+        }
+    s = group_sum<G>(s);
+    xa = group_sum<G>(xa);
+    const float ls = logf(s);
+    lse = m + ls;
+    sum = s;
+    logp_a = xa - lse;
+    // entropy = -sum p_i log p_i,  p_i = ex_i / s,  log p_i = x_i - lse
+    float h = 0.f;
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int i = e * VEC + k;
+            const int c = (e * G + gl) * VEC + k;
+            if (c < N) h -= (ex[i] * inv) * (r.x[i] - lse);
+        }
+    ent = group_sum<G>(h);
+}
+
+template <int G, int VEC, int E>
+__global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* __restrict__ logits,
+                                                              const int64_t* __restrict__ action,
+                                                              float* __restrict__ logp_out,
+                                                              float* __restrict__ ent_out, long rows, int N) {
+    constexpr int RPB = 256 / G;  // rows per block per sweep
+    const int gl = threadIdx.x % G;
+    const int gi = threadIdx.x / G;
+    for (long row = (long)blockIdx.x * RPB + gi; row < rows; row += (long)gridDim.x * RPB) {
+        RowSlice<G, VEC, E> r;
+        r.load(logits + row * (long)N, N, gl);
+        const long a = action[row];
+        float ex[E * VEC], lse, sum, lp, h;
+        row_stats<G, VEC, E>(r, N, gl, a, ex, lse, sum, lp, h);
+        if (gl == 0) {
+            logp_out[row] = lp;
+            if (ent_out) ent_out[row] = h;
+        }
+    }
+}
+
+// grad[row,i] = g1*c1[row]*(1[i==a] - p_i) + g2*c2[row]*(-p_i*(log p_i + H))
+template <int G, int VEC, int E>
+__global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __restrict__ logits,
+                                                              const int64_t* __restrict__ action,
+                                                              const float* __restrict__ c1,
+                                                              const float* __restrict__ g1,
+                                                              const float* __restrict__ c2,
+                                                              const float* __restrict__ g2,
+                                                              float* __restrict__ grad, long rows, int N) {
+    constexpr int RPB = 256 / G;
+    const int gl = threadIdx.x % G;
+    const int gi = threadIdx.x / G;
+    const float u1 = g1 ? g1[0] : 1.f;
+    const float u2 = (c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
+    for (long row = (long)blockIdx.x * RPB + gi; row < rows; row += (long)gridDim.x * RPB) {
+        RowSlice<G, VEC, E> r;
+        r.load(logits + row * (long)N, N, gl);
+        const long a = action[row];
+        const float k1 = u1 * c1[row];
+        const float k2 = (c2 != nullptr) ? u2 * c2[row] : 0.f;
+        float ex[E * VEC], lse, sum, lp, h;
+        row_stats<G, VEC, E>(r, N, gl, a, ex, lse, sum, lp, h);
+        const float inv = 1.f / sum;
+        float* __restrict__ out = grad + row * (long)N;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c0 = (e * G + gl) * VEC;
+            float o[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int i = e * VEC + k;
+                const float p = ex[i] * inv;
+                const float onehot = ((long)(c0 + k) == a) ? 1.f : 0.f;
+                o[k] = k1 * (onehot - p) - k2 * p * ((r.x[i] - lse) + h);
+            }
+            if (c0 < N) {
+                if (VEC == 4) {
+                    *reinterpret_cast<float4*>(out + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    out[c0] = o[0];
+                }
+            }
+        }
+    }
+}
+
+// ---- generic fallback for rows too long for registers (N > 64*VEC*8): three L2-friendly passes, one wave per row
+__global__ __launch_bounds__(256) void categorical_fwd_long_kernel(const float* __restrict__ logits,
+                                                                   const int64_t* __restrict__ action,
+                                                                   float* __restrict__ logp_out,
+                                                                   float* __restrict__ ent_out, long rows, int N) {
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+        const float* __restrict__ x = logits + row * (long)N;
+        float m = kNegInf;
+        for (int c = lane; c < N; c += 64) m = fmaxf(m, x[c]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < N; c += 64) s += expf(x[c] - m);
+        s = wave_sum(s);
+        const float lse = m + logf(s);
+        float h = 0.f;
+        for (int c = lane; c < N; c += 64) {
+            const float lp = x[c] - lse;
+            h -= expf(lp) * lp;
+        }
+        h = wave_sum(h);
+        if (lane == 0) {
+            const long a = action[row];
+            logp_out[row] = ((a >= 0 && a < N) ? x[a] : 0.f) - lse;
+            if (ent_out) ent_out[row] = h;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void categorical_bwd_long_kernel(const float* __restrict__ logits,
+                                                                   const int64_t* __restrict__ action,
+                                                                   const float* __restrict__ c1,
+                                                                   const float* __restrict__ g1,
+                                                                   const float* __restrict__ c2,
+                                                                   const float* __restrict__ g2,
+                                                                   float* __restrict__ grad, long rows, int N) {
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const float u1 = g1 ? g1[0] : 1.f;
+    const float u2 = (c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
+    for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+        const float* __restrict__ x = logits + row * (long)N;
+        float m = kNegInf;
+        for (int c = lane; c < N; c += 64) m = fmaxf(m, x[c]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < N; c += 64) s += expf(x[c] - m);
+        s = wave_sum(s);
+        const float lse = m + logf(s);
+        float h = 0.f;
+        for (int c = lane; c < N; c += 64) {
+            const float lp = x[c] - lse;
+            h -= expf(lp) * lp;
+        }
+        h = wave_sum(h);
+        const long a = action[row];
+        const float k1 = u1 * c1[row];
+        const float k2 = (c2 != nullptr) ? u2 * c2[row] : 0.f;
+        float* __restrict__ out = grad + row * (long)N;
+        for (int c = lane; c < N; c += 64) {
+            const float lp = x[c] - lse;
+            const float p = expf(lp);
+            out[c] = k1 * (((long)c == a ? 1.f : 0.f) - p) - k2 * p * (lp + h);
+        }
+    }
+}
+
+inline unsigned grid_for(long rows, int rows_per_block) {
+    long g = (rows + rows_per_block - 1) / rows_per_block;
+    const long cap = 256L * 8;  // 256 CUs x 8 blocks of 256 threads
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+struct RowCfg { int g, vec, e; };
+
+inline RowCfg row_cfg(int N, bool can_vec4) {
+    RowCfg c;
+    c.vec = (can_vec4 && (N % 4) == 0) ? 4 : 1;
+    const int pieces = (N + c.vec - 1) / c.vec;
+    c.g = 1;
+    while (c.g < 64 && c.g < pieces) c.g <<= 1;
+    const int e = (pieces + c.g - 1) / c.g;
+    c.e = 1;
+    while (c.e < e) c.e <<= 1;
+    return c;  // e > 8 means "use the long-row fallback"
+}
+
+#define HPC_RLL_ROW_CASE(G_, V_, E_, KERNEL, ...)                                                         \
+    if (cfg.g == G_ && cfg.vec == V_ && cfg.e == E_) {                                                    \
+        hipLaunchKernelGGL((KERNEL<G_, V_, E_>), dim3(grid_for(rows, 256 / G_)), dim3(256), 0, st,        \
+                           __VA_ARGS__);                                                                  \
+        return true;                                                                                      \
+    }
+#define HPC_RLL_ROW_DISPATCH(KERNEL, ...)                                                                  \
+    HPC_RLL_ROW_CASE(1, 1, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(2, 1, 1, KERNEL, __VA_ARGS__)          \
+    HPC_RLL_ROW_CASE(4, 1, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(8, 1, 1, KERNEL, __VA_ARGS__)          \
+    HPC_RLL_ROW_CASE(16, 1, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(32, 1, 1, KERNEL, __VA_ARGS__)        \
+    HPC_RLL_ROW_CASE(64, 1, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(64, 1, 2, KERNEL, __VA_ARGS__)        \
+    HPC_RLL_ROW_CASE(64, 1, 4, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(64, 1, 8, KERNEL, __VA_ARGS__)        \
+    HPC_RLL_ROW_CASE(1, 4, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(2, 4, 1, KERNEL, __VA_ARGS__)          \
+    HPC_RLL_ROW_CASE(4, 4, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(8, 4, 1, KERNEL, __VA_ARGS__)          \
+    HPC_RLL_ROW_CASE(16, 4, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(32, 4, 1, KERNEL, __VA_ARGS__)        \
+    HPC_RLL_ROW_CASE(64, 4, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(64, 4, 2, KERNEL, __VA_ARGS__)        \
+    HPC_RLL_ROW_CASE(64, 4, 4, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(64, 4, 8, KERNEL, __VA_ARGS__)        \
+    return false;
+
+bool launch_fwd(const RowCfg& cfg, hipStream_t st, const float* logits, const int64_t* action, float* logp,
+                float* ent, long rows, int N) {
+    HPC_RLL_ROW_DISPATCH(categorical_fwd_kernel, logits, action, logp, ent, rows, N)
+}
+bool launch_bwd(const RowCfg& cfg, hipStream_t st, const float* logits, const int64_t* action, const float* c1,
+                const float* g1, const float* c2, const float* g2, float* grad, long rows, int N) {
+    HPC_RLL_ROW_DISPATCH(categorical_bwd_kernel, logits, action, c1, g1, c2, g2, grad, rows, N)
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// Internal C++ entry points used by vtrace.hip / upgo.hip / ppo.hip (same library).
+int categorical_forward(const float* logits, const int64_t* action, float* logp, float* ent, long rows, int N,
+                        hipStream_t st) {
+    if (rows < 0 || N <= 0) return HPC_RLL_EINVAL;
+    if (rows == 0) return HPC_RLL_OK;
+    if (!logits || !action || !logp) return HPC_RLL_EINVAL;
+    const RowCfg cfg = row_cfg(N, al16(logits));
+    if (cfg.e > 8 || !launch_fwd(cfg, st, logits, action, logp, ent, rows, N)) {
+        hipLaunchKernelGGL(categorical_fwd_long_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, st, logits, action,
+                           logp, ent, rows, N);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HPC_RLL_OK : (int)e;
+}
+
+int categorical_backward(const float* logits, const int64_t* action, const float* c1, const float* g1,
+                         const float* c2, const float* g2, float* grad, long rows, int N, hipStream_t st) {
+    if (rows < 0 || N <= 0) return HPC_RLL_EINVAL;
+    if (rows == 0) return HPC_RLL_OK;
+    if (!logits || !action || !c1 || !grad) return HPC_RLL_EINVAL;
+    const RowCfg cfg = row_cfg(N, al16(logits) && al16(grad));
+    if (cfg.e > 8 || !launch_bwd(cfg, st, logits, action, c1, g1, c2, g2, grad, rows, N)) {
+        hipLaunchKernelGGL(categorical_bwd_long_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, st, logits, action,
+                           c1, g1, c2, g2, grad, rows, N);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HPC_RLL_OK : (int)e;
+}
+
+}  // namespace hpc_rll
+
+extern "C" int hpc_rll_categorical_forward(const float* logits, const int64_t* action, float* logp, float* entropy,
+                                           int64_t rows, int N, void* stream) {
+    return hpc_rll::categorical_forward(logits, action, logp, entropy, (long)rows, N, (hipStream_t)stream);
+}
+
+extern "C" int hpc_rll_categorical_backward(const float* logits, const int64_t* action, const float* coef_logp,
+                                            const float* g_logp, const float* coef_ent, const float* g_ent,
+                                            float* grad_logits, int64_t rows, int N, void* stream) {
+    return hpc_rll::categorical_backward(logits, action, coef_logp, g_logp, coef_ent, g_ent, grad_logits, (long)rows,
+                                         N, (hipStream_t)stream);
+}

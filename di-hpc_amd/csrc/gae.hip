@@ -54,7 +54,7 @@ __global__ void gae_coef_kernel(float* __restrict__ coef, int T, float gamma, fl
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int V, int LC, int NW>
+template <int V, int LC, int NW, bool NTL, bool NTS>
 __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restrict__ value,
                                                           const float* __restrict__ reward,
                                                           float* __restrict__ adv,
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restric
                 const float* vp = value + (size_t)t0 * B + col;
                 const float* rp = reward + (size_t)t0 * B + col;
 #pragma unroll
-                for (int j = LC; j >= 0; --j) vr[j] = load_pack<V>(vp + (size_t)j * B);
+                for (int j = LC; j >= 0; --j) vr[j] = load_pack<V, NTL>(vp + (size_t)j * B);
 #pragma unroll
-                for (int j = LC - 1; j >= 0; --j) rr[j] = load_pack<V>(rp + (size_t)j * B);
+                for (int j = LC - 1; j >= 0; --j) rr[j] = load_pack<V, NTL>(rp + (size_t)j * B);
             } else {
 #pragma unroll
                 for (int j = 0; j <= LC; ++j)
@@ -136,9 +136,9 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restric
                     const float c = coef[t];
                     Pack<V> v0, v1, r;
                     if (col_ok) {
-                        v0 = load_pack<V>(value + (size_t)t * B + col);
-                        v1 = load_pack<V>(value + (size_t)(t + 1) * B + col);
-                        r = load_pack<V>(reward + (size_t)t * B + col);
+                        v0 = load_pack<V, NTL>(value + (size_t)t * B + col);
+                        v1 = load_pack<V, NTL>(value + (size_t)(t + 1) * B + col);
+                        r = load_pack<V, NTL>(reward + (size_t)t * B + col);
                     } else {
 #pragma unroll
                         for (int k = 0; k < V; ++k) v0.v[k] = v1.v[k] = r.v[k] = 0.f;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restric
                     Pack<V> o;
 #pragma unroll
                     for (int k = 0; k < V; ++k) o.v[k] = fmaf(P[j], Aw[k], L[j][k]);
-                    store_pack<V>(adv + (size_t)t * B + col, o);
+                    store_pack<V, NTS>(adv + (size_t)t * B + col, o);
                 }
             }
         }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // backward: d_t = g_t + c_{t-1} d_{t-1} (forward in time), chunks aligned to t = 0, wave 0 earliest.
 // ------------------------------------------------------------------------------------------------
-template <int V, int LC, int NW>
+template <int V, int LC, int NW, bool NTL, bool NTS>
 __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restrict__ grad_adv,
                                                           float* __restrict__ grad_value,
                                                           float* __restrict__ grad_reward,
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restric
                 if (col_ok) {
                     const float* gp = grad_adv + (size_t)t0 * B + col;
 #pragma unroll
-                    for (int j = 0; j < LC; ++j) g[j] = load_pack<V>(gp + (size_t)j * B);
+                    for (int j = 0; j < LC; ++j) g[j] = load_pack<V, NTL>(gp + (size_t)j * B);
                 } else {
 #pragma unroll
                     for (int j = 0; j < LC; ++j)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restric
                         const float c = (t > 0) ? coef[t - 1] : 0.f;
                         Pack<V> g;
                         if (col_ok) {
-                            g = load_pack<V>(grad_adv + (size_t)t * B + col);
+                            g = load_pack<V, NTL>(grad_adv + (size_t)t * B + col);
                         } else {
 #pragma unroll
                             for (int k = 0; k < V; ++k) g.v[k] = 0.f;
@@ -318,14 +318,14 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restric
                         gv.v[k] = fmaf(gamma, prev[k], -d.v[k]);
                         prev[k] = d.v[k];
                     }
-                    if (grad_reward) store_pack<V>(grad_reward + (size_t)t * B + col, d);
+                    if (grad_reward) store_pack<V, NTS>(grad_reward + (size_t)t * B + col, d);
                     if (grad_value) {
-                        store_pack<V>(grad_value + (size_t)t * B + col, gv);
+                        store_pack<V, NTS>(grad_value + (size_t)t * B + col, gv);
                         if (t == T - 1) {  // bootstrap row: dL/dV_T = gamma * d_{T-1}
                             Pack<V> last;
 #pragma unroll
                             for (int k = 0; k < V; ++k) last.v[k] = gamma * d.v[k];
-                            store_pack<V>(grad_value + (size_t)T * B + col, last);
+                            store_pack<V, NTS>(grad_value + (size_t)T * B + col, last);
                         }
                     }
                 }
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // host side: configuration choice + dispatch
 // ------------------------------------------------------------------------------------------------
-struct Cfg { int v, lc, nw; };
+struct Cfg { int v, lc, nw, flags; };
 
 inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
@@ -351,53 +351,74 @@ inline int max_vec(int B, std::initializer_list<const void*> ptrs) {
     return 1;
 }
 
-inline Cfg choose_cfg(int T, int B, int vmax, int v, int lc, int nw) {
-    // Heuristic (tuned on MI355X): keep >= ~2 workgroups per CU before widening
-    // the per-lane pack; 16-step chunks; as many waves as there are chunks, up to 8.
+// Launch-configuration heuristic, tuned on MI355X with forward and backward launches ALTERNATING (the real
+// access pattern; a kernel repeated back to back finds part of its input in the 256 MiB Infinity Cache and
+// looks faster than it is).  Sweeps of every instantiation: profiles/r01_gae_tuning_*.txt, DESIGN.md.
+//   * streaming regime (>= 512 workgroups): ~32 KiB of loads in flight per CU is enough, more resident
+//     waves do not help.  Forward: 2 columns/lane, 2 waves x 8 steps.  Backward: 4 columns/lane, 4 x 4.
+//     Stores are always NONTEMPORAL: a regular store leaves dirty lines in L2/MALL whose write-back lands in
+//     the NEXT kernel (measured: +35-45 us on the following launch); nontemporal loads help the forward.
+//   * small-B regime: 1 column per lane and up to 16 waves x 16 steps so that ~2048 waves cover the chip
+//     even when there are few column tiles (B=64 -> one workgroup walking T in 256-step strides).
+inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, int flags) {
+    auto wgs_for = [&](int vv) { return (B + 64 * vv - 1) / (64 * vv); };
     if (v == 0) {
-        v = vmax;
-        while (v > 1 && (B + 64 * v - 1) / (64 * v) < 512) v >>= 1;
+        v = vmax > 2 ? 2 : vmax;
+        while (v > 1 && wgs_for(v) < 512) v >>= 1;
+        if (!fwd && vmax == 4 && wgs_for(4) >= 256 && wgs_for(2) >= 512) v = 4;
     }
     if (v > vmax) v = vmax;
-    if (lc == 0) lc = (v == 4) ? 8 : 16;
+    const int wgs = wgs_for(v);
+    const bool streaming = wgs_for(v > 2 ? 2 : v) >= 512;
+    if (lc == 0) {
+        lc = streaming ? (fwd ? 8 : 4) : 16;
+        if (lc == 16 && v == 4) lc = 8;  // (4,16) is not instantiated (VGPR budget)
+    }
     if (nw == 0) {
         const int chunks = (T + lc - 1) / lc;
-        nw = 1;
-        while (nw < 8 && nw < chunks) nw <<= 1;
+        nw = streaming ? (fwd ? 2 : 4) : 4;
+        if (!streaming)
+            while (nw < 16 && wgs * nw < 2048) nw <<= 1;
+        while (nw > 1 && nw > chunks) nw >>= 1;
     }
-    return Cfg{v, lc, nw};
+    if (flags < 0) flags = (streaming && fwd) ? 3 : 2;
+    return Cfg{v, lc, nw, flags & 3};
 }
-
-#define HPC_RLL_GAE_DISPATCH(KERNEL, ...)                                                  \
-    do {                                                                                   \
-        bool hit = false;                                                                  \
-        auto go = [&](auto V_, auto LC_, auto NW_) {                                       \
-            constexpr int V = decltype(V_)::value, LC = decltype(LC_)::value,              \
-                          NW = decltype(NW_)::value;                                       \
-            if (cfg.v == V && cfg.lc == LC && cfg.nw == NW) {                              \
-                const unsigned grid = (unsigned)((B + 64 * V - 1) / (64 * V));             \
-                hipLaunchKernelGGL((KERNEL<V, LC, NW>), dim3(grid), dim3(NW * 64), 0, st,  \
-                                   __VA_ARGS__);                                           \
-                hit = true;                                                                \
-            }                                                                              \
-        };                                                                                 \
-        for_each_cfg(go);                                                                  \
-        if (!hit) return HPC_RLL_EUNSUPPORTED;                                             \
-    } while (0)
 
 template <int N> using I = std::integral_constant<int, N>;
 
+// (V, LC, NW) triples that are instantiated (each in 4 nontemporal flavours).
 template <class F>
 inline void for_each_cfg(F&& f) {
-    // V x LC x NW grid; (V=4, LC=16) is left out (VGPR budget)
 #define HPC_RLL_NW_ROW(V, LC) \
     f(I<V>{}, I<LC>{}, I<1>{}); f(I<V>{}, I<LC>{}, I<2>{}); f(I<V>{}, I<LC>{}, I<4>{}); \
     f(I<V>{}, I<LC>{}, I<8>{}); f(I<V>{}, I<LC>{}, I<16>{});
     HPC_RLL_NW_ROW(1, 4) HPC_RLL_NW_ROW(1, 8) HPC_RLL_NW_ROW(1, 16)
-    HPC_RLL_NW_ROW(2, 4) HPC_RLL_NW_ROW(2, 8) HPC_RLL_NW_ROW(2, 16)
-    HPC_RLL_NW_ROW(4, 4) HPC_RLL_NW_ROW(4, 8)
+    HPC_RLL_NW_ROW(2, 2) HPC_RLL_NW_ROW(2, 4) HPC_RLL_NW_ROW(2, 8) HPC_RLL_NW_ROW(2, 16)
+    HPC_RLL_NW_ROW(4, 2) HPC_RLL_NW_ROW(4, 4) HPC_RLL_NW_ROW(4, 8)
 #undef HPC_RLL_NW_ROW
 }
+
+#define HPC_RLL_GAE_DISPATCH(KERNEL, ...)                                                          \
+    do {                                                                                           \
+        bool hit = false;                                                                          \
+        auto go = [&](auto V_, auto LC_, auto NW_) {                                               \
+            constexpr int V = decltype(V_)::value, LC = decltype(LC_)::value,                      \
+                          NW = decltype(NW_)::value;                                               \
+            if (cfg.v == V && cfg.lc == LC && cfg.nw == NW) {                                      \
+                const dim3 grid((unsigned)((B + 64 * V - 1) / (64 * V))), block(NW * 64);          \
+                switch (cfg.flags) {                                                               \
+                    case 0: hipLaunchKernelGGL((KERNEL<V, LC, NW, false, false>), grid, block, 0, st, __VA_ARGS__); break; \
+                    case 1: hipLaunchKernelGGL((KERNEL<V, LC, NW, true, false>), grid, block, 0, st, __VA_ARGS__); break;  \
+                    case 2: hipLaunchKernelGGL((KERNEL<V, LC, NW, false, true>), grid, block, 0, st, __VA_ARGS__); break;  \
+                    default: hipLaunchKernelGGL((KERNEL<V, LC, NW, true, true>), grid, block, 0, st, __VA_ARGS__); break;  \
+                }                                                                                  \
+                hit = true;                                                                        \
+            }                                                                                      \
+        };                                                                                         \
+        for_each_cfg(go);                                                                          \
+        if (!hit) return HPC_RLL_EUNSUPPORTED;                                                     \
+    } while (0)
 
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
@@ -419,12 +440,12 @@ extern "C" int hpc_rll_gae_coef(float* coef, int T, float gamma, float lambda, v
 }
 
 extern "C" int hpc_rll_gae_forward_ex(const float* value, const float* reward, float* adv, const float* coef,
-                                      int T, int B, float gamma, int vec, int lc, int nw, void* stream) {
+                                      int T, int B, float gamma, int vec, int lc, int nw, int flags, void* stream) {
     if (T < 0 || B < 0) return HPC_RLL_EINVAL;
     if (T == 0 || B == 0) return HPC_RLL_OK;
     if (!value || !reward || !adv || !coef) return HPC_RLL_EINVAL;
     if (!aligned(value, 4) || !aligned(reward, 4) || !aligned(adv, 4) || !aligned(coef, 4)) return HPC_RLL_EALIGN;
-    const Cfg cfg = choose_cfg(T, B, max_vec(B, {value, reward, adv}), vec, lc, nw);
+    const Cfg cfg = choose_cfg(true, T, B, max_vec(B, {value, reward, adv}), vec, lc, nw, flags);
     hipStream_t st = (hipStream_t)stream;
     HPC_RLL_GAE_DISPATCH(gae_fwd_kernel, value, reward, adv, coef, T, B, gamma);
     return check_launch();
@@ -432,12 +453,12 @@ extern "C" int hpc_rll_gae_forward_ex(const float* value, const float* reward, f
 
 extern "C" int hpc_rll_gae_forward(const float* value, const float* reward, float* adv, const float* coef, int T,
                                    int B, float gamma, void* stream) {
-    return hpc_rll_gae_forward_ex(value, reward, adv, coef, T, B, gamma, 0, 0, 0, stream);
+    return hpc_rll_gae_forward_ex(value, reward, adv, coef, T, B, gamma, 0, 0, 0, -1, stream);
 }
 
 extern "C" int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value, float* grad_reward,
                                        const float* coef, int T, int B, float gamma, int vec, int lc, int nw,
-                                       void* stream) {
+                                       int flags, void* stream) {
     if (T < 0 || B < 0) return HPC_RLL_EINVAL;
     if (B == 0) return HPC_RLL_OK;
     if (T == 0) {  // grad_value has one row (the bootstrap value), which adv does not depend on
@@ -448,7 +469,7 @@ extern "C" int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value,
     if (!grad_value && !grad_reward) return HPC_RLL_OK;
     if (!aligned(grad_adv, 4) || !aligned(grad_value, 4) || !aligned(grad_reward, 4) || !aligned(coef, 4))
         return HPC_RLL_EALIGN;
-    const Cfg cfg = choose_cfg(T, B, max_vec(B, {grad_adv, grad_value, grad_reward}), vec, lc, nw);
+    const Cfg cfg = choose_cfg(false, T, B, max_vec(B, {grad_adv, grad_value, grad_reward}), vec, lc, nw, flags);
     hipStream_t st = (hipStream_t)stream;
     HPC_RLL_GAE_DISPATCH(gae_bwd_kernel, grad_adv, grad_value, grad_reward, coef, T, B, gamma);
     return check_launch();
@@ -456,5 +477,5 @@ extern "C" int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value,
 
 extern "C" int hpc_rll_gae_backward(const float* grad_adv, float* grad_value, float* grad_reward, const float* coef,
                                     int T, int B, float gamma, void* stream) {
-    return hpc_rll_gae_backward_ex(grad_adv, grad_value, grad_reward, coef, T, B, gamma, 0, 0, 0, stream);
+    return hpc_rll_gae_backward_ex(grad_adv, grad_value, grad_reward, coef, T, B, gamma, 0, 0, 0, -1, stream);
 }

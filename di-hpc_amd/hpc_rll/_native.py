@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libhpc_rll_hip.so")
+LIB_PATH = os.environ.get("HPC_RLL_LIB") or os.path.join(_HERE, "_lib", "libhpc_rll_hip.so")  # env: kernel experiments
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -33,8 +33,8 @@ SIGNATURES = {
     "hpc_rll_gae_coef": [c_p, c_i, c_f, c_f, c_p],
     "hpc_rll_gae_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "hpc_rll_gae_backward": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
-    "hpc_rll_gae_forward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
-    "hpc_rll_gae_backward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
+    "hpc_rll_gae_forward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
+    "hpc_rll_gae_backward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
 }
 
 for _name, _args in SIGNATURES.items():

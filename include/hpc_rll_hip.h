@@ -55,12 +55,14 @@ int hpc_rll_gae_forward(const float* value, const float* reward, float* adv, con
 int hpc_rll_gae_backward(const float* grad_adv, float* grad_value, float* grad_reward, const float* coef,
                          int T, int B, float gamma, void* stream);
 /* Expert entry points: pin the launch configuration instead of the built-in heuristic.
- * vec in {1,2,4} columns per lane, lc in {4,8,16} time steps per wave chunk, nw in {1,2,4,8,16}
- * waves per workgroup; 0 for any of them = choose automatically. */
+ * vec in {1,2,4} columns per lane, lc in {2,4,8,16} time steps per wave chunk, nw in {1,2,4,8,16}
+ * waves per workgroup; 0 for any of them = choose automatically.  flags: bit0 nontemporal loads,
+ * bit1 nontemporal stores; -1 = choose automatically.  HPC_RLL_EUNSUPPORTED if the combination is
+ * not instantiated. */
 int hpc_rll_gae_forward_ex(const float* value, const float* reward, float* adv, const float* coef,
-                           int T, int B, float gamma, int vec, int lc, int nw, void* stream);
+                           int T, int B, float gamma, int vec, int lc, int nw, int flags, void* stream);
 int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value, float* grad_reward, const float* coef,
-                            int T, int B, float gamma, int vec, int lc, int nw, void* stream);
+                            int T, int B, float gamma, int vec, int lc, int nw, int flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -113,7 +113,7 @@ def test_fp64_oracle_small(dev):
     assert rel_err(r64.grad.numpy(), gr) < TOL
 
 
-def _ex_call(dev, v, r, ga, gamma, lam, vec, lc, nw):
+def _ex_call(dev, v, r, ga, gamma, lam, vec, lc, nw, flags=-1):
     import hpc_rl_utils as U
     T, B = r.shape
     tv, tr, tg = (torch.from_numpy(x).to(dev) for x in (v, r, ga))
@@ -123,9 +123,9 @@ def _ex_call(dev, v, r, ga, gamma, lam, vec, lc, nw):
     coef = U.gae_coef(T, gamma, lam, dev)
     s = U.N.stream_ptr(dev)
     st1 = U.N.lib.hpc_rll_gae_forward_ex(tv.data_ptr(), tr.data_ptr(), adv.data_ptr(), coef.data_ptr(), T, B, gamma,
-                                         vec, lc, nw, s)
+                                         vec, lc, nw, flags, s)
     st2 = U.N.lib.hpc_rll_gae_backward_ex(tg.data_ptr(), gv.data_ptr(), gr.data_ptr(), coef.data_ptr(), T, B, gamma,
-                                          vec, lc, nw, s)
+                                          vec, lc, nw, flags, s)
     torch.cuda.synchronize()
     return st1, st2, adv.cpu().numpy(), gv.cpu().numpy(), gr.cpu().numpy()
 
@@ -140,22 +140,23 @@ def test_every_launch_configuration(dev, cref, T, B):
     o_adv, o_gv, o_gr = oracle_fwd_bwd(cref, v, r, ga, 0.99, 0.97)
     n = 0
     for vec in (1, 2, 4):
-        for lc in (4, 8, 16):
-            if vec == 4 and lc == 16:
-                continue
+        for lc in (2, 4, 8, 16):
             for nw in (1, 2, 4, 8, 16):
-                st1, st2, adv, gv, gr = _ex_call(dev, v, r, ga, 0.99, 0.97, vec, lc, nw)
-                assert st1 == 0 and st2 == 0, (vec, lc, nw, st1, st2)
-                assert rel_err(o_adv, adv) < TOL, (vec, lc, nw)
-                assert rel_err(o_gv, gv) < 2 * TOL, (vec, lc, nw)
-                assert rel_err(o_gr, gr) < 2 * TOL, (vec, lc, nw)
-                n += 1
-    assert n == 40
+                for flags in (0, 1, 2, 3):
+                    st1, st2, adv, gv, gr = _ex_call(dev, v, r, ga, 0.99, 0.97, vec, lc, nw, flags)
+                    if st1 == -3 and st2 == -3:   # combination not instantiated
+                        continue
+                    assert st1 == 0 and st2 == 0, (vec, lc, nw, flags, st1, st2)
+                    assert rel_err(o_adv, adv) < TOL, (vec, lc, nw, flags)
+                    assert rel_err(o_gv, gv) < 2 * TOL, (vec, lc, nw, flags)
+                    assert rel_err(o_gr, gr) < 2 * TOL, (vec, lc, nw, flags)
+                    n += 1
+    assert n >= 100
 
 
 def test_unsupported_configuration_is_reported(dev):
     v = np.zeros((3, 4), np.float32)
-    st1, st2, *_ = _ex_call(dev, v, v[:2], v[:2], 0.99, 0.97, 4, 16, 4)
+    st1, st2, *_ = _ex_call(dev, v, v[:2], v[:2], 0.99, 0.97, 4, 16, 4, 0)
     assert st1 == -3 and st2 == -3
 
 

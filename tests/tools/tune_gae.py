@@ -38,17 +38,30 @@ rows = []
 src = torch.empty(BYTES // 8, device=dev); dst = torch.empty_like(src)
 t = timed(lambda: dst.copy_(src))
 rows.append(("copy_", 0, 0, 0, t, t))
-for vec in (1, 2, 4):
-    for lc in (4, 8, 16):
-        if vec == 4 and lc == 16:
-            continue
-        for nw in (1, 2, 4, 8, 16):
-            f = lambda: lib.hpc_rll_gae_forward_ex(v.data_ptr(), r.data_ptr(), adv.data_ptr(), coef.data_ptr(), T, B, 0.99, vec, lc, nw, s)
-            b = lambda: lib.hpc_rll_gae_backward_ex(ga.data_ptr(), gv.data_ptr(), gr.data_ptr(), coef.data_ptr(), T, B, 0.99, vec, lc, nw, s)
-            assert f() == 0 and b() == 0
-            rows.append(("gae", vec, lc, nw, timed(f), timed(b)))
+import statistics
+acc = {}
+ROUNDS = int(os.environ.get("ROUNDS", 3))
+for rnd in range(ROUNDS):
+    for vec in (1, 2, 4):
+        for lc in (2, 4, 8, 16):
+            for nw in (1, 2, 4, 8, 16):
+                for fl in (0, 1, 2, 3):
+                    f = lambda: lib.hpc_rll_gae_forward_ex(v.data_ptr(), r.data_ptr(), adv.data_ptr(), coef.data_ptr(), T, B, 0.99, vec, lc, nw, fl, s)
+                    b = lambda: lib.hpc_rll_gae_backward_ex(ga.data_ptr(), gv.data_ptr(), gr.data_ptr(), coef.data_ptr(), T, B, 0.99, vec, lc, nw, fl, s)
+                    if f() != 0 or b() != 0:
+                        continue
+                    acc.setdefault((vec, lc, nw, fl), []).append((timed(f, 5), timed(b, 5)))
+for (vec, lc, nw, fl), ts in acc.items():
+    rows.append((f"nt{fl}", vec, lc, nw, statistics.median(t[0] for t in ts), statistics.median(t[1] for t in ts)))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 lines = [f"T={T} B={B} algorithmic bytes/launch={BYTES}", "kind vec lc nw   fwd_us  fwd_GB/s   bwd_us  bwd_GB/s"]
+lines.append("--- sorted by forward time")
+for k, vec, lc, nw, tf, tb in sorted(rows, key=lambda x: x[4])[:25]:
+    lines.append(f"{k:5s} {vec:3d} {lc:2d} {nw:2d} {tf*1e6:8.1f} {BYTES/tf/1e9:9.0f} {tb*1e6:8.1f} {BYTES/tb/1e9:9.0f}")
+lines.append("--- sorted by backward time")
+for k, vec, lc, nw, tf, tb in sorted(rows, key=lambda x: x[5])[:25]:
+    lines.append(f"{k:5s} {vec:3d} {lc:2d} {nw:2d} {tf*1e6:8.1f} {BYTES/tf/1e9:9.0f} {tb*1e6:8.1f} {BYTES/tb/1e9:9.0f}")
+lines.append("--- all, sorted by sum")
 for k, vec, lc, nw, tf, tb in sorted(rows, key=lambda x: x[4] + x[5]):
     lines.append(f"{k:5s} {vec:3d} {lc:2d} {nw:2d} {tf*1e6:8.1f} {BYTES/tf/1e9:9.0f} {tb*1e6:8.1f} {BYTES/tb/1e9:9.0f}")
 txt = "\n".join(lines)
