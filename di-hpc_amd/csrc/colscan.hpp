@@ -1,0 +1,185 @@
+// colscan.hpp -- generic reverse-time column scan for (T,B)-layout return ops on gfx950.
+//
+// All trajectory "return" recurrences on the hot path (TD-lambda, V-trace, UPGO; GAE has its own
+// specialised kernels in gae.hip) are first-order affine maps walked backwards in time,
+//       s_t = b_t + a_t * s_{t+1},          t = T-1 .. 0,   s_T = init(column)
+// with per-element (a_t, b_t) computed from the row's inputs.  Affine maps compose associatively, so a
+// chunk [t0,t1) can be scanned from a zero carry (L_t, and the running product P_t of the a's) and
+// repaired once the true s_{t1} is known:  s_t = L_t + P_t * s_{t1}.
+//
+// Mapping (same skeleton as gae.hip): lane <-> V consecutive columns (coalesced along B), wave <-> LC
+// consecutive steps held in VGPRs, workgroup = NW waves covering NW*LC steps; chunk heads (L,P per lane) go
+// through a double-buffered LDS slot, one barrier per NW*LC steps.  Each workgroup also reduces NACC scalar
+// sums (loss terms) deterministically: lane sums -> wave butterfly -> LDS -> one partial per workgroup;
+// a second tiny kernel (reduce.hip) adds the partials in a fixed order.  No float atomics anywhere
+// (the reference uses cross-block atomicAdd: td_lambda_kernel.h:38, vtrace_kernel.h:215-222).
+//
+// The reference walks each column with one thread (td_lambda_kernel.h:17-32, vtrace_kernel.h:161-180,
+// upgo_kernel.h:17-36) -- no time parallelism at all.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wave.hpp"
+
+namespace hpc_rll {
+
+// An Op provides:
+//   static constexpr int NACC;                         number of scalar sums
+//   template<int V> struct Row;                        per-row register payload
+//   template<int V> void init(long col, bool ok, float (&carry)[V]) const;          s_T
+//   template<int V> void load(Row<V>&, int t, long col, bool ok) const;             issue the row's loads
+//   template<int V> void coeffs(const Row<V>&, int t, float (&a)[V], float (&b)[V]) const;
+//   template<int V> void finish(const Row<V>&, int t, long col, bool ok, const float (&s)[V],
+//                               const float (&s_next)[V], float (&acc)[NACC]) const;   outputs + sums
+template <class Op, int V, int LC, int NW>
+__global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T, int B,
+                                                              float* __restrict__ partials) {
+    constexpr int TILE = 64 * V;
+    constexpr int NACC = Op::NACC;
+    __shared__ float lds[4 * NW * TILE + NW * (NACC > 0 ? NACC : 1)];
+    float* const s_l0 = lds;                      // [buf][wave][TILE]
+    float* const s_p0 = lds + 2 * NW * TILE;      // [buf][wave][TILE]
+    float* const s_red = lds + 4 * NW * TILE;     // [NACC][NW]
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    const bool ok = col < (long)B;
+
+    float carry[V];
+    op.template init<V>(col, ok, carry);
+    float acc[NACC > 0 ? NACC : 1];
+#pragma unroll
+    for (int k = 0; k < (NACC > 0 ? NACC : 1); ++k) acc[k] = 0.f;
+
+    constexpr int SPAN = NW * LC;
+    const int n_iter = (T + SPAN - 1) / SPAN;
+    for (int it = 0; it < n_iter; ++it) {
+        const int t1 = T - (it * NW + (NW - 1 - w)) * LC;
+        const int t0 = t1 - LC;
+        const int buf = it & 1;
+
+        typename Op::template Row<V> rows[LC];
+        float L[LC][V], P[LC][V];
+#pragma unroll
+        for (int j = LC - 1; j >= 0; --j)
+            if (t0 + j >= 0) op.template load<V>(rows[j], t0 + j, col, ok);
+        {
+            float a[V], p[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) { a[k] = 0.f; p[k] = 1.f; }
+#pragma unroll
+            for (int j = LC - 1; j >= 0; --j) {
+                if (t0 + j >= 0) {
+                    float ca[V], cb[V];
+                    op.template coeffs<V>(rows[j], t0 + j, ca, cb);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        a[k] = fmaf(ca[k], a[k], cb[k]);
+                        p[k] *= ca[k];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < V; ++k) { L[j][k] = a[k]; P[j][k] = p[k]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            s_l0[(buf * NW + w) * TILE + lane * V + k] = L[0][k];
+            s_p0[(buf * NW + w) * TILE + lane * V + k] = P[0][k];
+        }
+        __syncthreads();
+
+        float A[V], Aw[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { A[k] = carry[k]; Aw[k] = 0.f; }
+#pragma unroll
+        for (int u = NW - 1; u >= 0; --u) {
+            if (u == w) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) Aw[k] = A[k];
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                A[k] = fmaf(s_p0[(buf * NW + u) * TILE + lane * V + k], A[k],
+                            s_l0[(buf * NW + u) * TILE + lane * V + k]);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) carry[k] = A[k];
+
+        float s_next[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s_next[k] = Aw[k];
+#pragma unroll
+        for (int j = LC - 1; j >= 0; --j) {
+            if (t0 + j >= 0) {
+                float s[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) s[k] = fmaf(P[j][k], Aw[k], L[j][k]);
+                op.template finish<V>(rows[j], t0 + j, col, ok, s, s_next, acc);
+#pragma unroll
+                for (int k = 0; k < V; ++k) s_next[k] = s[k];
+            }
+        }
+    }
+
+    if (NACC > 0) {
+        // deterministic workgroup reduction of the NACC running sums
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            const float sum = wave_sum(acc[k]);
+            if (lane == 0) s_red[k * NW + w] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x < NACC) {
+            float sum = 0.f;
+            for (int i = 0; i < NW; ++i) sum += s_red[threadIdx.x * NW + i];
+            partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sum;
+        }
+    }
+}
+
+struct ScanCfg { int v, lc, nw; };
+
+// V=1 or 2 (the fat rows of V-trace/UPGO do not fit V=4), LC = 8, NW up to 16 for small B.
+inline ScanCfg scan_cfg(int T, int B, bool can_v2) {
+    ScanCfg c;
+    c.v = (can_v2 && (B + 127) / 128 >= 512) ? 2 : 1;
+    c.lc = 8;
+    const int wgs = (B + 64 * c.v - 1) / (64 * c.v);
+    const int chunks = (T + c.lc - 1) / c.lc;
+    c.nw = 4;
+    while (c.nw < 16 && wgs * c.nw < 2048) c.nw <<= 1;
+    while (c.nw > 1 && c.nw > chunks) c.nw >>= 1;
+    return c;
+}
+
+template <class Op, bool ALLOW_V2 = true>
+inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* partials, hipStream_t st) {
+    const unsigned grid = (unsigned)((B + 64 * c.v - 1) / (64 * c.v));
+#define HPC_RLL_SCAN_CASE(V_, NW_)                                                                          \
+    if (c.v == V_ && c.nw == NW_) {                                                                         \
+        hipLaunchKernelGGL((colscan_rev_kernel<Op, V_, 8, NW_>), dim3(grid), dim3(NW_ * 64), 0, st, op, T, B, \
+                           partials);                                                                       \
+        return;                                                                                             \
+    }
+    HPC_RLL_SCAN_CASE(1, 1) HPC_RLL_SCAN_CASE(1, 2) HPC_RLL_SCAN_CASE(1, 4) HPC_RLL_SCAN_CASE(1, 8)
+    HPC_RLL_SCAN_CASE(1, 16)
+    if constexpr (ALLOW_V2) {
+        HPC_RLL_SCAN_CASE(2, 1) HPC_RLL_SCAN_CASE(2, 2) HPC_RLL_SCAN_CASE(2, 4) HPC_RLL_SCAN_CASE(2, 8)
+        HPC_RLL_SCAN_CASE(2, 16)
+    }
+#undef HPC_RLL_SCAN_CASE
+}
+
+inline int scan_num_blocks(int T, int B, bool can_v2) {
+    const ScanCfg c = scan_cfg(T, B, can_v2);
+    return (B + 64 * c.v - 1) / (64 * c.v);
+}
+
+// reduce.hip
+int finalize_sums(const float* partials, int nblocks, int nacc, const float* scales /*host, nacc*/, float* out,
+                  hipStream_t st);
+int scale_rows(const float* g, const float* in, float* out, long n_in, long n_out, hipStream_t st);
+
+}  // namespace hpc_rll

@@ -1,0 +1,273 @@
+// dist_ops.hip -- distributional n-step TD errors for gfx950: C51 (dist), IQN and QR-DQN.
+//
+// Replaces (under /root/reference):
+//   DistNStepTdForward/Backward        src/rl_utils/dist_nstep_td.cu:8-98,  dist_nstep_td_kernel.h:11-107
+//   IQNNStepTDErrorForward/Backward    src/rl_utils/iqn_nstep_td_error.cu,  iqn_nstep_td_error_kernel.h:11-108
+//   QRDQNNStepTDErrorForward/Backward  src/rl_utils/qrdqn_nstep_td_error.cu, qrdqn_nstep_td_error_kernel.h:11-106
+// Semantics: hpc_rll/origin/td.py:56-143, 391-448, 480-517.
+//
+// One WAVE per sample b; the atoms / quantile pairs of that sample are spread over the 64 lanes, per-sample
+// sums are wave butterflies, the batch loss goes through the usual deterministic two-stage reduction.
+//   * C51: the reference scatters projected mass with float atomicAdd (dist_nstep_td_kernel.h:58-59, order
+//     dependent).  Here each lane OWNS target atoms and gathers the (few) source atoms that land on them, in
+//     source order: deterministic, no atomics, no scratch proj buffer round trip.
+//   * IQN / QR-DQN: the reference materialises three (B,tau',tau) scratch tensors over three launches; here the
+//     tau x tau' pair loop runs in registers, one launch, and only the (B,tau) unit gradient is written.
+#include <hip/hip_runtime.h>
+
+#include "colscan.hpp"
+#include "hpc_rll_hip.h"
+
+namespace hpc_rll {
+
+int onehot_scatter(const float* g, const float* buf, const int64_t* action, float* grad, long B, int N, int K,
+                   hipStream_t st);
+
+namespace {
+
+inline int last_error() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HPC_RLL_OK : (int)e;
+}
+
+// 4 waves (= 4 samples) per workgroup; workgroup partial = sum of its 4 per-sample weighted losses.
+template <class F>
+__device__ __forceinline__ void wave_per_sample(int B, float* __restrict__ partials, F&& body) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    float contrib = 0.f;
+    if (b < B) contrib = body(b, lane);
+    if (lane == 0) red[w] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ C51
+// buf[b, k] = -w_b * proj[b,k] / p[b,a,k] * scale    (unit gradient wrt dist[b, a_b, k])
+__global__ __launch_bounds__(256) void dist_nstep_fwd_kernel(
+    const float* __restrict__ dist, const float* __restrict__ next_dist, const int64_t* __restrict__ action,
+    const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
+    const float* __restrict__ weight, float* __restrict__ td_err, float* __restrict__ buf,
+    float* __restrict__ partials, int nstep, int B, int N, int n_atom, float gamma, float gamma_n, float v_min,
+    float v_max, float dz, float scale) {
+    wave_per_sample(B, partials, [&](int b, int lane) -> float {
+        float R = 0.f, f = 1.f;
+        for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
+        const float nd_scale = (1.f - done[b]) * gamma_n;
+        const float* __restrict__ p = dist + ((size_t)b * N + action[b]) * n_atom;
+        const float* __restrict__ pn = next_dist + ((size_t)b * N + next_action[b]) * n_atom;
+        const float w = weight ? weight[b] : 1.f;
+        float ce = 0.f;  // sum_k proj_k * log p_k over this lane's atoms
+        for (int k = lane; k < n_atom; k += 64) {
+            float proj = 0.f;
+            // gather: source atoms j whose floor / ceil position is k (source order => deterministic sum)
+            for (int j = 0; j < n_atom; ++j) {
+                // support_j: torch.linspace(v_min, v_max, n_atom) evaluates start + j*step below the midpoint
+                // and end - (n-1-j)*step above it
+                const float step = (v_max - v_min) / (float)(n_atom - 1);
+                const float sup = (j < n_atom / 2) ? (v_min + step * (float)j) : (v_max - step * (float)(n_atom - 1 - j));
+                // unfused mul/add/div, like the oracle's tensor ops (origin/td.py:95-98)
+                float tz = __fadd_rn(R, __fmul_rn(nd_scale, sup));
+                tz = fminf(fmaxf(tz, v_min), v_max);
+                const float bp = __fdiv_rn(__fsub_rn(tz, v_min), dz);
+                const float lo = floorf(bp), up = ceilf(bp);
+                if ((int)lo == k) proj = fmaf(pn[j], up - bp, proj);
+                if ((int)up == k) proj = fmaf(pn[j], bp - lo, proj);
+            }
+            const float pk = p[k];
+            ce = fmaf(proj, logf(pk), ce);
+            buf[(size_t)b * n_atom + k] = -w * proj / pk * scale;
+        }
+        ce = wave_sum(ce);
+        if (lane == 0) td_err[b] = -ce;
+        return -ce * w;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ IQN
+// q (tau,B,N), next_q (tau',B,N), replay_quantiles (tau,B).  buf[b,i] = unit gradient wrt q[i,b,a_b].
+__global__ __launch_bounds__(256) void iqn_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ next_q, const int64_t* __restrict__ action,
+    const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
+    const float* __restrict__ rq, const float* __restrict__ weight, const float* __restrict__ value_gamma,
+    float* __restrict__ td_err, float* __restrict__ buf, float* __restrict__ partials, int tau, int tau_p,
+    int nstep, int B, int N, float gamma, float gamma_n, float kappa, float scale) {
+    wave_per_sample(B, partials, [&](int b, int lane) -> float {
+        float R = 0.f, f = 1.f;
+        for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
+        const float vg = (value_gamma ? value_gamma[b] : gamma_n) * (1.f - done[b]);
+        const long a = action[b], na = next_action[b];
+        const float w = weight ? weight[b] : 1.f;
+        const float inv_tp = 1.f / (float)tau_p;
+        float loss = 0.f;
+        for (int i = lane; i < tau; i += 64) {
+            const float qi = q[((size_t)i * B + b) * N + a];
+            const float rho = rq[(size_t)i * B + b];
+            float li = 0.f, gi = 0.f;
+            for (int j = 0; j < tau_p; ++j) {
+                const float tgt = fmaf(vg, next_q[((size_t)j * B + b) * N + na], R);
+                const float e = tgt - qi;
+                const float ae = fabsf(e);
+                const float hub = (ae <= kappa) ? 0.5f * e * e : kappa * (ae - 0.5f * kappa);
+                const float dh = (ae <= kappa) ? e : ((e > 0.f) ? kappa : -kappa);
+                const float qw = fabsf(rho - ((e < 0.f) ? 1.f : 0.f)) / kappa;
+                li = fmaf(qw, hub, li);
+                gi = fmaf(qw, dh, gi);
+            }
+            loss += li;
+            buf[(size_t)b * tau + i] = -gi * inv_tp * w * scale;   // de/dq = -1
+        }
+        loss = wave_sum(loss) * inv_tp;
+        if (lane == 0) td_err[b] = loss;
+        return loss * w;
+    });
+}
+
+// grad_q[i,b,n] = (n == a_b) ? g * buf[b,i] : 0      for q laid out (tau,B,N)
+__global__ __launch_bounds__(256) void iqn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ buf,
+                                                      const int64_t* __restrict__ action, float* __restrict__ grad,
+                                                      int tau, int B, int N) {
+    const float u = g[0];
+    const long total = (long)tau * B * N;
+    for (long x = (long)blockIdx.x * 256 + threadIdx.x; x < total; x += (long)gridDim.x * 256) {
+        const int n = (int)(x % N);
+        const long ib = x / N;
+        const int b = (int)(ib % B);
+        const int i = (int)(ib / B);
+        __builtin_nontemporal_store(((long)n == action[b]) ? u * buf[(size_t)b * tau + i] : 0.f, grad + x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ QR-DQN
+// q (B,N,tau), next_q (B,N,tau).  buf[b,i] = unit gradient wrt q[b,a_b,i].
+__global__ __launch_bounds__(256) void qrdqn_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ next_q, const int64_t* __restrict__ action,
+    const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
+    const float* __restrict__ weight, const float* __restrict__ value_gamma, float* __restrict__ td_err,
+    float* __restrict__ buf, float* __restrict__ partials, int tau, int nstep, int B, int N, float gamma,
+    float gamma_n, float tau_value, float scale) {
+    wave_per_sample(B, partials, [&](int b, int lane) -> float {
+        float R = 0.f, f = 1.f;
+        for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
+        const float vg = (value_gamma ? value_gamma[b] : gamma_n) * (1.f - done[b]);
+        const float* __restrict__ qa = q + ((size_t)b * N + action[b]) * tau;
+        const float* __restrict__ qn = next_q + ((size_t)b * N + next_action[b]) * tau;
+        const float w = weight ? weight[b] : 1.f;
+        const float inv_tau = 1.f / (float)tau;
+        float loss = 0.f;
+        for (int i = lane; i < tau; i += 64) {
+            const float qi = qa[i];
+            float li = 0.f, gi = 0.f;
+            for (int j = 0; j < tau; ++j) {
+                const float e = fmaf(vg, qn[j], R) - qi;
+                const float ae = fabsf(e);
+                const float u = (ae < 1.f) ? 0.5f * e * e : ae - 0.5f;       // smooth_l1, beta = 1
+                const float du = (ae < 1.f) ? e : ((e > 0.f) ? 1.f : -1.f);
+                const float qw = fabsf(tau_value - ((e <= 0.f) ? 1.f : 0.f));
+                li = fmaf(qw, u, li);
+                gi = fmaf(qw, du, gi);
+            }
+            loss += li;
+            buf[(size_t)b * tau + i] = -gi * inv_tau * w * scale;
+        }
+        loss = wave_sum(loss) * inv_tau;
+        if (lane == 0) td_err[b] = loss;
+        return loss * w;
+    });
+}
+
+}  // namespace
+}  // namespace hpc_rll
+
+using namespace hpc_rll;
+
+extern "C" int hpc_rll_dist_nstep_td_forward(const float* dist, const float* next_n_dist, const int64_t* action,
+                                             const int64_t* next_n_action, const float* reward, const float* done,
+                                             const float* weight, float* loss, float* td_err, float* buf,
+                                             float* partials, int nstep, int B, int N, int n_atom, float gamma,
+                                             float v_min, float v_max, float scale, void* stream) {
+    if (nstep < 0 || B < 0 || N <= 0 || n_atom < 2 || !loss) return HPC_RLL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return (int)hipMemsetAsync(loss, 0, sizeof(float), st);
+    if (!dist || !next_n_dist || !action || !next_n_action || (nstep && !reward) || !done || !td_err || !buf ||
+        !partials)
+        return HPC_RLL_EINVAL;
+    const int blocks = (B + 3) / 4;
+    // delta_z is a python double in the oracle, rounded to fp32 when it meets the fp32 tensor
+    const float dz = (float)(((double)v_max - (double)v_min) / (double)(n_atom - 1));
+    hipLaunchKernelGGL(dist_nstep_fwd_kernel, dim3(blocks), dim3(256), 0, st, dist, next_n_dist, action,
+                       next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma,
+                       (float)pow((double)gamma, (double)nstep), v_min, v_max, dz, scale);
+    int rc = last_error();
+    if (rc) return rc;
+    return finalize_sums(partials, blocks, 1, &scale, loss, st);
+}
+
+extern "C" int hpc_rll_dist_nstep_td_backward(const float* grad_loss, const float* buf, const int64_t* action,
+                                              float* grad_dist, int B, int N, int n_atom, void* stream) {
+    if (B < 0 || N <= 0 || n_atom <= 0) return HPC_RLL_EINVAL;
+    if (B == 0) return HPC_RLL_OK;
+    if (!grad_loss || !buf || !action || !grad_dist) return HPC_RLL_EINVAL;
+    return onehot_scatter(grad_loss, buf, action, grad_dist, B, N, n_atom, (hipStream_t)stream);
+}
+
+extern "C" int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_q, const int64_t* action,
+                                            const int64_t* next_n_action, const float* reward, const float* done,
+                                            const float* replay_quantiles, const float* weight,
+                                            const float* value_gamma, float* loss, float* td_err, float* buf,
+                                            float* partials, int tau, int tau_prime, int nstep, int B, int N,
+                                            float gamma, float kappa, float scale, void* stream) {
+    if (tau <= 0 || tau_prime <= 0 || nstep < 0 || B < 0 || N <= 0 || !loss || !(kappa > 0.f)) return HPC_RLL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return (int)hipMemsetAsync(loss, 0, sizeof(float), st);
+    if (!q || !next_n_q || !action || !next_n_action || (nstep && !reward) || !done || !replay_quantiles || !td_err ||
+        !buf || !partials)
+        return HPC_RLL_EINVAL;
+    const int blocks = (B + 3) / 4;
+    hipLaunchKernelGGL(iqn_fwd_kernel, dim3(blocks), dim3(256), 0, st, q, next_n_q, action, next_n_action, reward,
+                       done, replay_quantiles, weight, value_gamma, td_err, buf, partials, tau, tau_prime, nstep, B, N,
+                       gamma, (float)pow((double)gamma, (double)nstep), kappa, scale);
+    int rc = last_error();
+    if (rc) return rc;
+    return finalize_sums(partials, blocks, 1, &scale, loss, st);
+}
+
+extern "C" int hpc_rll_iqn_nstep_td_backward(const float* grad_loss, const float* buf, const int64_t* action,
+                                             float* grad_q, int tau, int B, int N, void* stream) {
+    if (tau <= 0 || B < 0 || N <= 0) return HPC_RLL_EINVAL;
+    if (B == 0) return HPC_RLL_OK;
+    if (!grad_loss || !buf || !action || !grad_q) return HPC_RLL_EINVAL;
+    long blocks = ((long)tau * B * N + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(iqn_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad_loss, buf,
+                       action, grad_q, tau, B, N);
+    return last_error();
+}
+
+extern "C" int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_n_q, const int64_t* action,
+                                              const int64_t* next_n_action, const float* reward, const float* done,
+                                              const float* weight, const float* value_gamma, float* loss,
+                                              float* td_err, float* buf, float* partials, int tau, int nstep, int B,
+                                              int N, float gamma, float tau_value, float scale, void* stream) {
+    if (tau <= 0 || nstep < 0 || B < 0 || N <= 0 || !loss) return HPC_RLL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return (int)hipMemsetAsync(loss, 0, sizeof(float), st);
+    if (!q || !next_n_q || !action || !next_n_action || (nstep && !reward) || !done || !td_err || !buf || !partials)
+        return HPC_RLL_EINVAL;
+    const int blocks = (B + 3) / 4;
+    hipLaunchKernelGGL(qrdqn_fwd_kernel, dim3(blocks), dim3(256), 0, st, q, next_n_q, action, next_n_action, reward,
+                       done, weight, value_gamma, td_err, buf, partials, tau, nstep, B, N, gamma,
+                       (float)pow((double)gamma, (double)nstep), tau_value, scale);
+    int rc = last_error();
+    if (rc) return rc;
+    return finalize_sums(partials, blocks, 1, &scale, loss, st);
+}
+
+extern "C" int hpc_rll_qrdqn_nstep_td_backward(const float* grad_loss, const float* buf, const int64_t* action,
+                                               float* grad_q, int tau, int B, int N, void* stream) {
+    if (tau <= 0 || B < 0 || N <= 0) return HPC_RLL_EINVAL;
+    if (B == 0) return HPC_RLL_OK;
+    if (!grad_loss || !buf || !action || !grad_q) return HPC_RLL_EINVAL;
+    return onehot_scatter(grad_loss, buf, action, grad_q, B, N, tau, (hipStream_t)stream);
+}

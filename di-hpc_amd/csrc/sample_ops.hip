@@ -1,0 +1,233 @@
+// sample_ops.hip -- per-sample (batch-parallel) loss ops for gfx950: PPO and the q n-step TD errors.
+//
+// Replaces (under /root/reference):
+//   PPOForward/Backward              src/rl_utils/ppo.cu:8-111, ppo_kernel.h:12-283
+//   QNStepTdForward/Backward         src/rl_utils/q_nstep_td.cu, q_nstep_td_kernel.h:11-62
+//   QNStepTdRescaleForward/Backward  src/rl_utils/q_nstep_td_rescale.cu, q_nstep_td_rescale_kernel.h:11-72
+// Semantics: hpc_rll/origin/ppo.py:51-80, origin/td.py:9-22,280-291,326-354.
+//
+// One lane per sample, coalesced along B; scalar losses by deterministic two-stage reduction
+// (wave butterfly -> LDS -> one partial per workgroup -> fixed-order fp64 finalize), no float atomics.
+#include <hip/hip_runtime.h>
+
+#include "colscan.hpp"
+#include "hpc_rll_hip.h"
+
+namespace hpc_rll {
+
+int categorical_forward(const float* logits, const int64_t* action, float* logp, float* ent, long rows, int N,
+                        hipStream_t st);
+int categorical_backward(const float* logits, const int64_t* action, const float* c1, const float* g1,
+                         const float* c2, const float* g2, float* grad, long rows, int N, hipStream_t st);
+
+namespace {
+
+inline int last_error() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HPC_RLL_OK : (int)e;
+}
+
+// Generic "one lane per sample + NACC sums" kernel.  grid = ceil(n/256) workgroups (<= partial capacity).
+template <class Op>
+__global__ __launch_bounds__(256) void sample_kernel(const Op op, long n, float* __restrict__ partials) {
+    constexpr int NACC = Op::NACC;
+    __shared__ float red[NACC * 4];
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) op(i, acc);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        const float s = wave_sum(acc[k]);
+        if (lane == 0) red[k * 4 + w] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC)
+        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+            (red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1]) + (red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------- PPO
+struct PpoOp {
+    static constexpr int NACC = 5;
+    const float *logp_new, *ent, *logp_old, *value_new, *value_old, *adv, *ret, *weight;
+    float *coef_logp, *coef_ent, *gv_unit;
+    float clip, dual_clip, scale;
+    int use_value_clip;
+    __device__ void operator()(long i, float (&acc)[NACC]) const {
+        const float w = weight ? weight[i] : 1.f;
+        const float lpn = logp_new[i], lpo = logp_old[i], a = adv[i];
+        const float ratio = expf(lpn - lpo);
+        const float s1 = ratio * a;
+        const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+        const float s2 = rc * a;
+        // min(s1, s2): s1 wins ties (identical value and identical derivative whenever they tie inside the clip range)
+        float inner = s1, dinner = s1;  // d inner / d logp_new = ratio * adv on the s1 branch
+        if (s2 < s1) { inner = s2; dinner = (rc == ratio) ? s1 : 0.f; }
+        if (dual_clip >= 1.f) {          // reference encodes "None" as 0 (rl_utils/ppo.py:136-137, ppo_kernel.h:188)
+            const float d = dual_clip * a;
+            if (d > inner) { inner = d; dinner = 0.f; }
+        }
+        acc[0] -= inner * w;
+        coef_logp[i] = -dinner * w * scale;
+        const float vn = value_new[i], r = ret[i];
+        float v = (r - vn) * (r - vn);
+        float dv = -(r - vn);            // d(0.5 v)/d value_new on the unclipped branch
+        if (use_value_clip) {
+            const float vo = value_old[i];
+            const float vc = vo + fminf(fmaxf(vn - vo, -clip), clip);
+            const float v2 = (r - vc) * (r - vc);
+            if (v2 > v) { v = v2; dv = (vc == vn) ? -(r - vn) : 0.f; }
+        }
+        acc[1] = fmaf(v, w, acc[1]);
+        gv_unit[i] = dv * w * scale;
+        acc[2] = fmaf(ent[i], w, acc[2]);
+        coef_ent[i] = w * scale;
+        acc[3] += lpo - lpn;
+        acc[4] += (ratio > 1.f + clip || ratio < 1.f - clip) ? 1.f : 0.f;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- q n-step TD
+__device__ __forceinline__ float h_transform(float x, float eps) {
+    const float s = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+    return s * (sqrtf(fabsf(x) + 1.f) - 1.f) + eps * x;
+}
+__device__ __forceinline__ float h_inverse(float x, float eps) {
+    const float s = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+    const float t = (sqrtf(1.f + 4.f * eps * (fabsf(x) + 1.f + eps)) - 1.f) / (2.f * eps);
+    return s * (t * t - 1.f);
+}
+
+struct QNStepOp {
+    static constexpr int NACC = 1;
+    const float *q, *next_q; const int64_t *action, *next_action; const float *reward, *done, *weight;
+    float *td_err, *grad_buf;
+    int nstep, B, N; float gamma, gamma_n, scale; int rescale;
+    __device__ void operator()(long b, float (&acc)[NACC]) const {
+        const float qsa = q[b * N + action[b]];
+        float tq = next_q[b * N + next_action[b]];
+        if (rescale) tq = h_inverse(tq, 1e-2f);
+        float R = 0.f, f = 1.f;
+        for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
+        float tgt = R + gamma_n * tq * (1.f - done[b]);
+        if (rescale) tgt = h_transform(tgt, 1e-2f);
+        const float w = weight ? weight[b] : 1.f;
+        const float d = qsa - tgt;
+        td_err[b] = d * d;
+        acc[0] = fmaf(d * d, w, acc[0]);
+        grad_buf[b] = 2.f * d * w * scale;
+    }
+};
+
+// grad[b, n] = (n == action[b]) ? g * buf[b] : 0     (rows of N; also used with an inner dimension K:
+// grad[b, n, k] = (n == action[b]) ? g * buf[b*K + k] : 0)
+__global__ __launch_bounds__(256) void onehot_scatter_kernel(const float* __restrict__ g, const float* __restrict__ buf,
+                                                             const int64_t* __restrict__ action,
+                                                             float* __restrict__ grad, long B, int N, int K) {
+    const float u = g[0];
+    const long total = B * N * K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / ((long)N * K);
+        const int rem = (int)(i - b * (long)N * K);
+        const int n = rem / K, k = rem - n * K;
+        __builtin_nontemporal_store(((long)n == action[b]) ? u * buf[b * K + k] : 0.f, grad + i);
+    }
+}
+
+}  // namespace
+
+int onehot_scatter(const float* g, const float* buf, const int64_t* action, float* grad, long B, int N, int K,
+                   hipStream_t st) {
+    const long total = B * N * K;
+    if (total == 0) return HPC_RLL_OK;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(onehot_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, buf, action, grad, B, N, K);
+    return last_error();
+}
+
+}  // namespace hpc_rll
+
+using namespace hpc_rll;
+
+// ws layout (floats): [coef_logp B | coef_ent B | gv_unit B | logp_new B | ent B | logp_old B | partials]
+extern "C" int64_t hpc_rll_ppo_workspace_floats(int B) { return 6 * (int64_t)B + 8 * (((int64_t)B + 255) / 256 + 1); }
+
+extern "C" int hpc_rll_ppo_forward(const float* logits_new, const float* logits_old, const int64_t* action,
+                                   const float* value_new, const float* value_old, const float* adv,
+                                   const float* ret, const float* weight, float* out5, float* ws, int B, int N,
+                                   float clip_ratio, int use_value_clip, float dual_clip, float scale,
+                                   void* stream) {
+    if (B < 0 || N <= 0 || !out5) return HPC_RLL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return (int)hipMemsetAsync(out5, 0, 5 * sizeof(float), st);
+    if (!logits_new || !logits_old || !action || !value_new || !value_old || !adv || !ret || !ws)
+        return HPC_RLL_EINVAL;
+    float *coef_logp = ws, *coef_ent = ws + B, *gv_unit = ws + 2 * (size_t)B, *lpn = ws + 3 * (size_t)B,
+          *ent = ws + 4 * (size_t)B, *lpo = ws + 5 * (size_t)B, *partials = ws + 6 * (size_t)B;
+    int rc = categorical_forward(logits_new, action, lpn, ent, B, N, st);
+    if (rc) return rc;
+    rc = categorical_forward(logits_old, action, lpo, nullptr, B, N, st);
+    if (rc) return rc;
+    PpoOp op{lpn, ent, lpo, value_new, value_old, adv, ret, weight, coef_logp, coef_ent, gv_unit,
+             clip_ratio, dual_clip, scale, use_value_clip};
+    const int blocks = (B + 255) / 256;
+    hipLaunchKernelGGL(sample_kernel<PpoOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials);
+    rc = last_error();
+    if (rc) return rc;
+    // approx_kl and clipfrac are plain (unweighted) means over the LOCAL batch: scale by 1/B
+    const float sc[5] = {scale, 0.5f * scale, scale, 1.f / (float)B, 1.f / (float)B};
+    return finalize_sums(partials, blocks, 5, sc, out5, st);
+}
+
+extern "C" int hpc_rll_ppo_backward(const float* g_policy, const float* g_value, const float* g_ent,
+                                    const float* logits_new, const int64_t* action, const float* ws,
+                                    float* grad_logits_new, float* grad_value_new, int B, int N, void* stream) {
+    if (B < 0 || N <= 0) return HPC_RLL_EINVAL;
+    if (B == 0) return HPC_RLL_OK;
+    if (!ws) return HPC_RLL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = HPC_RLL_OK;
+    if (grad_value_new) {
+        if (!g_value) return HPC_RLL_EINVAL;
+        rc = scale_rows(g_value, ws + 2 * (size_t)B, grad_value_new, B, B, st);
+        if (rc) return rc;
+    }
+    if (grad_logits_new) {
+        if (!logits_new || !action) return HPC_RLL_EINVAL;
+        rc = categorical_backward(logits_new, action, ws, g_policy, ws + B, g_ent, grad_logits_new, B, N, st);
+    }
+    return rc;
+}
+
+// q n-step TD (rescale = 0) and with value rescaling (rescale = 1).
+extern "C" int hpc_rll_q_nstep_td_forward(const float* q, const float* next_n_q, const int64_t* action,
+                                          const int64_t* next_n_action, const float* reward, const float* done,
+                                          const float* weight, float* loss, float* td_err, float* grad_buf,
+                                          float* partials, int nstep, int B, int N, float gamma, int rescale,
+                                          float scale, void* stream) {
+    if (nstep < 0 || B < 0 || N <= 0 || !loss) return HPC_RLL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return (int)hipMemsetAsync(loss, 0, sizeof(float), st);
+    if (!q || !next_n_q || !action || !next_n_action || (nstep && !reward) || !done || !td_err || !grad_buf ||
+        !partials)
+        return HPC_RLL_EINVAL;
+    QNStepOp op{q, next_n_q, action, next_n_action, reward, done, weight, td_err, grad_buf,
+                nstep, B, N, gamma, (float)pow((double)gamma, (double)nstep), scale, rescale};
+    const int blocks = (B + 255) / 256;
+    hipLaunchKernelGGL(sample_kernel<QNStepOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials);
+    int rc = last_error();
+    if (rc) return rc;
+    return finalize_sums(partials, blocks, 1, &scale, loss, st);
+}
+
+extern "C" int hpc_rll_q_nstep_td_backward(const float* grad_loss, const float* grad_buf, const int64_t* action,
+                                           float* grad_q, int B, int N, void* stream) {
+    if (B < 0 || N <= 0) return HPC_RLL_EINVAL;
+    if (B == 0) return HPC_RLL_OK;
+    if (!grad_loss || !grad_buf || !action || !grad_q) return HPC_RLL_EINVAL;
+    return onehot_scatter(grad_loss, grad_buf, action, grad_q, B, N, 1, (hipStream_t)stream);
+}

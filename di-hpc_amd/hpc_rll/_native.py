@@ -1,7 +1,10 @@
 """ctypes loader for the C-ABI HIP library (include/hpc_rll_hip.h).
 
-There is deliberately NO fallback: if ``libhpc_rll_hip.so`` is missing or does not export a symbol,
+There is deliberately NO fallback: if ``libhpc_rll_hip.so`` is missing or does not export a declared symbol,
 importing this module raises -- the product path never silently degrades to eager PyTorch.
+
+The ctypes prototypes are generated from the C header itself (the single source of truth for the ABI), so
+the Python binding cannot drift from ``include/hpc_rll_hip.h``.
 
 torch is imported first on purpose: torch's bundled ``libamdhip64.so`` has the same soname
 (``libamdhip64.so.7``) as the ROCm one the library was linked against, so once torch is loaded the
@@ -10,11 +13,13 @@ device pointers are valid inside our launches.
 """
 import ctypes
 import os
+import re
 
 import torch  # noqa: F401  (must precede the dlopen below, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HPC_RLL_LIB") or os.path.join(_HERE, "_lib", "libhpc_rll_hip.so")  # env: kernel experiments
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "hpc_rll_hip.h")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -23,28 +28,37 @@ if not os.path.exists(LIB_PATH):
 
 lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 
-c_f = ctypes.c_float
-c_i = ctypes.c_int
-c_p = ctypes.c_void_p
-c_l = ctypes.c_int64
+_CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t}
 
-# name -> argtypes; restype is always int (status) unless noted.  Mirrors include/hpc_rll_hip.h.
-SIGNATURES = {
-    "hpc_rll_gae_coef": [c_p, c_i, c_f, c_f, c_p],
-    "hpc_rll_gae_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
-    "hpc_rll_gae_backward": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
-    "hpc_rll_gae_forward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
-    "hpc_rll_gae_backward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
-}
 
-for _name, _args in SIGNATURES.items():
+def _parse_header(path):
+    """{name: (restype, [argtypes])} for every ``hpc_rll_*`` prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(hpc_rll_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "*" in ret:
+            restype = ctypes.c_char_p if "char" in ret else ctypes.c_void_p
+        else:
+            restype = _CTYPES[ret.replace("const", "").strip()]
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPES[a.replace("const", "").split()[0]])
+        sigs[name] = (restype, argtypes)
+    return sigs
+
+
+SIGNATURES = _parse_header(HEADER_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError if the .so is stale: loud by design
     _fn.argtypes = _args
-    _fn.restype = c_i
-lib.hpc_rll_abi_version.restype = c_i
-lib.hpc_rll_abi_version.argtypes = []
-lib.hpc_rll_status_string.restype = ctypes.c_char_p
-lib.hpc_rll_status_string.argtypes = [c_i]
+    _fn.restype = _res
 
 ABI_VERSION = 1
 if lib.hpc_rll_abi_version() != ABI_VERSION:
@@ -82,3 +96,9 @@ def require(t, name, dtype=torch.float32, shape=None, device=None):
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise RuntimeError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
     return t
+
+
+def call(name, dev, *args):
+    """Launch a C-ABI entry point on torch's current stream of ``dev`` (appended as the last argument)."""
+    with torch.cuda.device(dev):
+        check(getattr(lib, name)(*args, stream_ptr(dev)), name)

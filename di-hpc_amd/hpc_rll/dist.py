@@ -1,0 +1,53 @@
+"""Batch-axis data parallelism for the scalar-loss ops: one process per GPU, each rank holds a
+contiguous (T, B/R) shard of the trajectories, every op computes per-rank SUMS scaled by 1/(GLOBAL count) and the
+loss scalars (1 for TD-lambda/UPGO/TD family, 3 for V-trace, 5 for PPO) are summed with ONE all-reduce -- RCCL over
+xGMI on GPUs (torch.distributed backend "nccl"), gloo in the CPU tests.  Per-sample outputs (adv, td_err) stay
+sharded; GAE needs no collective at all.  The reference has no distributed path (no NCCL/MPI call sites).
+
+The backward pass needs no communication: each rank's unit gradients already carry the global 1/count, so the
+gradients equal the corresponding rows of the single-GPU result.
+"""
+from typing import Optional
+
+import torch
+
+
+def world_size(group=None) -> int:
+    import torch.distributed as dist
+    if group is None and not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(group)
+
+
+def loss_scale(local_count: int, group=None, sharded: bool = False) -> float:
+    """1 / (global element count), assuming equal shards on every rank when ``sharded``."""
+    n = max(int(local_count), 1)
+    if sharded:
+        n *= world_size(group)
+    return 1.0 / n
+
+
+def all_reduce_losses_(losses: torch.Tensor, group=None, sharded: bool = False, mean_slots=()) -> torch.Tensor:
+    """In-place sum of the per-rank loss scalars.  ``mean_slots``: indices that hold per-rank MEANS (PPO's
+    approx_kl / clipfrac monitors) and must be averaged instead of summed."""
+    if not sharded:
+        return losses
+    import torch.distributed as dist
+    ws = world_size(group)
+    if ws == 1:
+        return losses
+    if mean_slots:
+        idx = torch.as_tensor(list(mean_slots), device=losses.device)
+        losses[idx] = losses[idx] / ws
+    dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=group)
+    return losses
+
+
+def shard_batch(t: Optional[torch.Tensor], dim: int, rank: int, world: int) -> Optional[torch.Tensor]:
+    """Contiguous shard ``rank`` of ``world`` along the batch axis ``dim`` (None passes through)."""
+    if t is None:
+        return None
+    n = t.shape[dim]
+    assert n % world == 0, f"batch {n} not divisible by world size {world}"
+    k = n // world
+    return t.narrow(dim, rank * k, k).contiguous()

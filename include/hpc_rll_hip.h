@@ -64,6 +64,117 @@ int hpc_rll_gae_forward_ex(const float* value, const float* reward, float* adv, 
 int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value, float* grad_reward, const float* coef,
                             int T, int B, float gamma, int vec, int lc, int nw, int flags, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Shared helpers of the scalar-loss ops.
+ *   hpc_rll_partials_floats(n): floats of scratch ("partials") an op over n columns/samples needs.
+ *   hpc_rll_scale_rows: out[i] = g[0]*in[i] (i < n_in), 0 (n_in <= i < n_out) -- the generic
+ *     "upstream scalar x saved unit gradient" backward step.
+ * Every *_forward writes per-rank SUMS times `scale`; pass scale = 1/(global count) so that a
+ * data-parallel caller gets the global mean with one all-reduce(sum) of the loss scalars.
+ * ------------------------------------------------------------------------------------------ */
+int64_t hpc_rll_partials_floats(int64_t n);
+int hpc_rll_scale_rows(const float* g, const float* in, float* out, int64_t n_in, int64_t n_out, void* stream);
+
+/* Categorical head over `rows` rows of N logits (rows = T*B or B), action int64 per row.
+ * Replaces categoricalTarget/categoricalBehaviour (vtrace_kernel.h:11-151), crossEntropyKernel
+ * (upgo_kernel.h:40-81), categoricalProbEntropy/categoricalProb (ppo_kernel.h:12-150) and the
+ * backward kernels that consume their saved buffers.  forward: logp[row] = log softmax(logits)[a],
+ * entropy[row] (nullable).  backward: grad[row,i] = g_logp*coef_logp[row]*(1[i==a]-p_i)
+ *   + g_ent*coef_ent[row]*(-p_i*(log p_i + H));  g_* are device scalars (NULL = 1), coef_ent may
+ *   be NULL (no entropy term). */
+int hpc_rll_categorical_forward(const float* logits, const int64_t* action, float* logp, float* entropy,
+                                int64_t rows, int N, void* stream);
+int hpc_rll_categorical_backward(const float* logits, const int64_t* action, const float* coef_logp,
+                                 const float* g_logp, const float* coef_ent, const float* g_ent,
+                                 float* grad_logits, int64_t rows, int N, void* stream);
+
+/* TD(lambda) -- replaces TdLambdaForward/Backward (rl_utils/entry.h:68-77, src/rl_utils/td_lambda.cu:8-52).
+ * value (T+1,B), reward (T,B), weight: mode 0 none, 1 (B,), 2 (T,B).  loss (1,) =
+ * 0.5*scale*sum w (ret-V)^2; grad_buf (T,B) = d loss / d value[:T]; partials >= partials_floats(B).
+ * backward: grad_value (T+1,B) = grad_loss[0] * grad_buf, last row 0. */
+int hpc_rll_td_lambda_forward(const float* value, const float* reward, const float* weight, int weight_mode,
+                              float* loss, float* grad_buf, float* partials, int T, int B, float gamma,
+                              float lambda, float scale, void* stream);
+int hpc_rll_td_lambda_backward(const float* grad_loss, const float* grad_buf, float* grad_value, int T, int B,
+                               void* stream);
+
+/* V-trace -- replaces VTraceForward/Backward (rl_utils/entry.h:131-146, src/rl_utils/vtrace.cu:8-130).
+ * target/behaviour_output (T,B,N), action (T,B) int64, value (T+1,B), reward (T,B), weight (T,B) or
+ * NULL.  losses (3,) = policy, value, entropy.  ws: hpc_rll_vtrace_workspace_floats(T,B) floats; its
+ * first 3*T*B floats (pg / entropy coefficients, unit value gradient) must survive until backward.
+ * backward recomputes the softmax from target_output (no saved (T,B,N) buffers). */
+int64_t hpc_rll_vtrace_workspace_floats(int T, int B);
+int hpc_rll_vtrace_forward(const float* target_output, const float* behaviour_output, const int64_t* action,
+                           const float* value, const float* reward, const float* weight, float* losses, float* ws,
+                           int T, int B, int N, float gamma, float lambda, float rho_clip, float c_clip,
+                           float rho_pg_clip, float scale, void* stream);
+int hpc_rll_vtrace_backward(const float* g_pg, const float* g_value, const float* g_ent, const float* target_output,
+                            const int64_t* action, const float* ws, float* grad_target_output, float* grad_value,
+                            int T, int B, int N, void* stream);
+
+/* UPGO -- replaces UpgoForward/Backward (rl_utils/entry.h:148-156, src/rl_utils/upgo.cu:8-70).
+ * target_output (T,B,N), rho (T,B), action (T,B), reward (T,B), value (T+1,B); loss (1,). */
+int64_t hpc_rll_upgo_workspace_floats(int T, int B);
+int hpc_rll_upgo_forward(const float* target_output, const float* rho, const int64_t* action, const float* reward,
+                         const float* value, float* loss, float* ws, int T, int B, int N, float scale, void* stream);
+int hpc_rll_upgo_backward(const float* g, const float* target_output, const int64_t* action, const float* ws,
+                          float* grad_target_output, int T, int B, int N, void* stream);
+
+/* PPO -- replaces PPOForward/Backward (rl_utils/entry.h:158-165, src/rl_utils/ppo.cu:8-111).
+ * logits (B,N), action (B,), value_new/old, adv, ret, weight (B,) (weight NULL = ones).
+ * out5 = policy_loss, value_loss, entropy_loss, approx_kl, clipfrac.  dual_clip < 1 disables dual clip
+ * (the reference encodes None as 0: hpc_rll/rl_utils/ppo.py:136-137). */
+int64_t hpc_rll_ppo_workspace_floats(int B);
+int hpc_rll_ppo_forward(const float* logits_new, const float* logits_old, const int64_t* action,
+                        const float* value_new, const float* value_old, const float* adv, const float* ret,
+                        const float* weight, float* out5, float* ws, int B, int N, float clip_ratio,
+                        int use_value_clip, float dual_clip, float scale, void* stream);
+int hpc_rll_ppo_backward(const float* g_policy, const float* g_value, const float* g_ent, const float* logits_new,
+                         const int64_t* action, const float* ws, float* grad_logits_new, float* grad_value_new,
+                         int B, int N, void* stream);
+
+/* q n-step TD (rescale=0) / with value rescaling (rescale=1) -- replaces QNStepTd{,Rescale}Forward/Backward
+ * (rl_utils/entry.h:89-109).  q,next_n_q (B,N); action,next_n_action (B,) int64; reward (nstep,B); done,
+ * weight (B,) float (weight NULL = ones).  loss (1,), td_err (B,), grad_buf (B,). */
+int hpc_rll_q_nstep_td_forward(const float* q, const float* next_n_q, const int64_t* action,
+                               const int64_t* next_n_action, const float* reward, const float* done,
+                               const float* weight, float* loss, float* td_err, float* grad_buf, float* partials,
+                               int nstep, int B, int N, float gamma, int rescale, float scale, void* stream);
+int hpc_rll_q_nstep_td_backward(const float* grad_loss, const float* grad_buf, const int64_t* action, float* grad_q,
+                                int B, int N, void* stream);
+
+/* dist (C51) n-step TD -- replaces DistNStepTdForward/Backward (rl_utils/entry.h:79-87).
+ * dist,next_n_dist (B,N,n_atom); buf (B,n_atom) = unit gradient wrt dist[b,a_b,:]. */
+int hpc_rll_dist_nstep_td_forward(const float* dist, const float* next_n_dist, const int64_t* action,
+                                  const int64_t* next_n_action, const float* reward, const float* done,
+                                  const float* weight, float* loss, float* td_err, float* buf, float* partials,
+                                  int nstep, int B, int N, int n_atom, float gamma, float v_min, float v_max,
+                                  float scale, void* stream);
+int hpc_rll_dist_nstep_td_backward(const float* grad_loss, const float* buf, const int64_t* action,
+                                   float* grad_dist, int B, int N, int n_atom, void* stream);
+
+/* IQN n-step TD -- replaces IQNNStepTDErrorForward/Backward (rl_utils/entry.h:111-119).
+ * q (tau,B,N), next_n_q (tau',B,N), replay_quantiles (tau,B), value_gamma (B,) or NULL (= gamma^nstep);
+ * buf (B,tau) = unit gradient wrt q[:,b,a_b]. */
+int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_q, const int64_t* action,
+                                 const int64_t* next_n_action, const float* reward, const float* done,
+                                 const float* replay_quantiles, const float* weight, const float* value_gamma,
+                                 float* loss, float* td_err, float* buf, float* partials, int tau, int tau_prime,
+                                 int nstep, int B, int N, float gamma, float kappa, float scale, void* stream);
+int hpc_rll_iqn_nstep_td_backward(const float* grad_loss, const float* buf, const int64_t* action, float* grad_q,
+                                  int tau, int B, int N, void* stream);
+
+/* QR-DQN n-step TD -- replaces QRDQNNStepTDErrorForward/Backward (rl_utils/entry.h:121-129).
+ * q,next_n_q (B,N,tau); tau_value = the `tau` the caller passes to the oracle (the reference kernel hard
+ * codes the integer count, qrdqn_nstep_td_error_kernel.h:60); buf (B,tau). */
+int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_n_q, const int64_t* action,
+                                   const int64_t* next_n_action, const float* reward, const float* done,
+                                   const float* weight, const float* value_gamma, float* loss, float* td_err,
+                                   float* buf, float* partials, int tau, int nstep, int B, int N, float gamma,
+                                   float tau_value, float scale, void* stream);
+int hpc_rll_qrdqn_nstep_td_backward(const float* grad_loss, const float* buf, const int64_t* action, float* grad_q,
+                                    int tau, int B, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,8 +29,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_python_signature_table_matches_header():
     from hpc_rll import _native
-    declared = set(declared_symbols()) - {"hpc_rll_abi_version", "hpc_rll_status_string"}
+    declared = set(declared_symbols())
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    assert len(declared) >= 30
 
 
 def test_abi_version_and_status_strings():
