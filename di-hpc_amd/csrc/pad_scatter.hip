@@ -1,0 +1,375 @@
+// pad_scatter.hip -- ragged Pad/Unpad (1-3D) and ScatterConnection for gfx950: integer/index work, bit exact.
+//
+// Replaces (under /root/reference):
+//   Pad{1,2,3}DForward, GroupPad{1,2,3}DForward, Unpad{1,2,3}DForward, sample/oracle_split_group
+//       src/rl_utils/padding.cu:8-582, padding_kernel.h:92-247
+//   ScatterConnectionForward/Backward
+//       src/torch_utils/network/scatter_connection.cu:8-73, scatter_connection_kernel.h:15-106
+// Semantics: hpc_rll/origin/padding.py:53-173 and origin/scatter_connection.py:49-65.
+//
+// Pad/Unpad.  Reference: one block per tensor, per-call cudaMalloc + synchronous cudaMemcpy of pointer tables +
+// cudaFree (padding.cu:118-138).  Here: ONE launch over the dense output index space for any rank 1..3 (a 1-D
+// tensor is the shape (1,1,len) so the contiguous axis is innermost), the caller hands a device table
+// {pointer|offset, d0, d1, d2} per tensor, nothing is allocated or synchronised.  Unpad writes ONE flat buffer
+// (the python layer returns views of it) and finds the owning tensor of each flat element by binary search.
+//
+// ScatterConnection.  Reference: memset of the whole output, then one thread per (b,m,n) storing 4 bytes with
+// stride H*W between consecutive n (uncoalesced); `cover` is a last-writer-wins race, `add` uses float atomics.
+// Here the scatter is turned into a GATHER driven by a per-cell owner list:
+//   1. index kernel (per b, in LDS): head[cell] = smallest m at that cell, next[m] = next larger m at the same
+//      cell, last[cell] = largest m.  Integer only, deterministic.
+//   2. output kernel: lanes <-> consecutive cells (the contiguous axis of (B,N,H,W)), 4 channels per step read as
+//      one float4 of x[b,m,n:n+4]; `cover` takes x[b,last[cell]] (the CPU oracle's sequential "largest m wins"),
+//      `add` walks the chain in ascending m (the oracle's sequential summation order -> bit exact), empty cells
+//      get 0.  Every output element is written exactly once with a nontemporal store: no memset pass, no atomics.
+//   3. backward: grad_x[b,m,n] = grad_out[b,n,cell_m].  Planes of grad_out are staged through LDS with
+//      coalesced loads (a 4-byte gather from HBM would fetch the whole plane anyway, sector by sector).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "hpc_rll_hip.h"
+#include "wave.hpp"
+
+namespace hpc_rll {
+namespace {
+
+inline int last_error() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HPC_RLL_OK : (int)e;
+}
+
+// ------------------------------------------------------------------------------------------------ pad
+// table[i] = {src pointer, d0, d1, d2}; output (n, m0, m1, m2); one thread per output element.
+__global__ __launch_bounds__(256) void pad_kernel(const int64_t* __restrict__ table, float* __restrict__ new_x,
+                                                  int32_t* __restrict__ mask, long n, unsigned m0, unsigned m1,
+                                                  unsigned m2, float fill, int ifill) {
+    const unsigned inner = m0 * m1 * m2;
+    const long total = n * (long)inner;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const long i = o / inner;
+        unsigned rem = (unsigned)(o - i * inner);
+        const unsigned c = rem % m2; rem /= m2;
+        const unsigned b = rem % m1;
+        const unsigned a = rem / m1;
+        const int64_t* __restrict__ e = table + i * 4;
+        const unsigned d0 = (unsigned)e[1], d1 = (unsigned)e[2], d2 = (unsigned)e[3];
+        const bool in = a < d0 && b < d1 && c < d2;
+        float v = fill;
+        if (in) v = reinterpret_cast<const float*>(e[0])[((size_t)a * d1 + b) * d2 + c];
+        __builtin_nontemporal_store(v, new_x + o);
+        __builtin_nontemporal_store(in ? 1 : ifill, mask + o);
+    }
+}
+
+// table[i] = {flat offset of tensor i (elements), d0, d1, d2}; one thread per element of the flat output.
+__global__ __launch_bounds__(256) void unpad_kernel(const float* __restrict__ padded,
+                                                    const int64_t* __restrict__ table, float* __restrict__ flat,
+                                                    long n, long total, unsigned m0, unsigned m1, unsigned m2) {
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        long lo = 0, hi = n - 1;  // last i with offset_i <= o (empty tensors share an offset: skip them)
+        while (lo < hi) {
+            const long mid = (lo + hi + 1) >> 1;
+            if (table[mid * 4] <= o) lo = mid; else hi = mid - 1;
+        }
+        const int64_t* __restrict__ e = table + lo * 4;
+        const unsigned d1 = (unsigned)e[2], d2 = (unsigned)e[3];
+        unsigned rem = (unsigned)(o - e[0]);
+        const unsigned c = rem % d2; rem /= d2;
+        const unsigned b = rem % d1;
+        const unsigned a = rem / d1;
+        flat[o] = padded[(((size_t)lo * m0 + a) * m1 + b) * m2 + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scatter
+// idx layout per b (int32): [head HW | last HW | next M]
+__global__ __launch_bounds__(256) void scatter_index_kernel(const int64_t* __restrict__ location,
+                                                            int32_t* __restrict__ idx, int M, int H, int W) {
+    extern __shared__ int32_t s_cell[];  // M cell ids
+    const int b = blockIdx.x;
+    const int HW = H * W;
+    const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
+    int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
+    int32_t* __restrict__ last = head + HW;
+    int32_t* __restrict__ next = last + HW;
+    for (int m = threadIdx.x; m < M; m += 256) {
+        const long y = loc[2 * m], x = loc[2 * m + 1];
+        // out-of-range locations are dropped (the reference would write out of bounds)
+        s_cell[m] = (y >= 0 && y < H && x >= 0 && x < W) ? (int32_t)(y * W + x) : -1;
+    }
+    for (int c = threadIdx.x; c < HW; c += 256) { head[c] = -1; last[c] = -1; }
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += 256) {
+        const int32_t c = s_cell[m];
+        int32_t nx = -1;
+        bool first = true;
+        if (c >= 0) {
+            for (int k = m + 1; k < M; ++k)
+                if (s_cell[k] == c) { nx = k; break; }
+            for (int k = m - 1; k >= 0; --k)
+                if (s_cell[k] == c) { first = false; break; }
+            if (first) head[c] = m;     // exactly one writer per cell
+            if (nx < 0) last[c] = m;    // exactly one writer per cell
+        }
+        next[m] = nx;
+    }
+}
+
+// grid: (cell blocks, n groups, B); lanes <-> consecutive cells; NPT channels per thread step of 4.
+template <bool ADD>
+__global__ __launch_bounds__(256) void scatter_out_kernel(const float* __restrict__ x,
+                                                          const int32_t* __restrict__ idx,
+                                                          float* __restrict__ out, int M, int N, int HW,
+                                                          int n_per_block, bool vec) {
+    const int b = blockIdx.z;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= HW) return;
+    const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
+    const int32_t* __restrict__ last = head + HW;
+    const int32_t* __restrict__ next = last + HW;
+    const float* __restrict__ xb = x + (size_t)b * M * N;
+    float* __restrict__ ob = out + (size_t)b * N * HW + cell;
+    const int n0 = blockIdx.y * n_per_block;
+    const int n1 = min(N, n0 + n_per_block);
+    const int32_t first = ADD ? head[cell] : last[cell];
+    for (int n = n0; n < n1; n += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int32_t m = first; m >= 0; m = ADD ? next[m] : -1) {
+            const float* __restrict__ src = xb + (size_t)m * N + n;
+            if (vec) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (n + k < n1) acc[k] += src[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (n + k < n1) __builtin_nontemporal_store(acc[k], ob + (size_t)(n + k) * HW);
+    }
+}
+
+// backward: workgroup = (b, group of NG channels); stage NG planes of grad_out in LDS, gather per entity.
+__global__ __launch_bounds__(256) void scatter_bwd_lds_kernel(const float* __restrict__ grad_out,
+                                                              const int64_t* __restrict__ location,
+                                                              float* __restrict__ grad_x, int M, int N, int H,
+                                                              int W, int NG) {
+    extern __shared__ float s_plane[];  // NG * HW
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * NG;
+    const int ng = min(NG, N - n0);
+    const int HW = H * W;
+    const float* __restrict__ g = grad_out + ((size_t)b * N + n0) * HW;
+    for (int i = threadIdx.x; i < ng * HW; i += 256) s_plane[i] = g[i];
+    __syncthreads();
+    const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
+    float* __restrict__ gx = grad_x + (size_t)b * M * N + n0;
+    // thread <-> (entity m, channel k) with k fastest so that each entity's ng outputs are contiguous
+    for (int i = threadIdx.x; i < M * ng; i += 256) {
+        const int m = i / ng, k = i - m * ng;
+        const long y = loc[2 * m], xx = loc[2 * m + 1];
+        const bool ok = y >= 0 && y < H && xx >= 0 && xx < W;
+        gx[(size_t)m * N + k] = ok ? s_plane[k * HW + (int)(y * W + xx)] : 0.f;
+    }
+}
+
+// fallback for planes too large for LDS: direct gather
+__global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __restrict__ grad_out,
+                                                                 const int64_t* __restrict__ location,
+                                                                 float* __restrict__ grad_x, long total, int M,
+                                                                 int N, int H, int W) {
+    const long HW = (long)H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i % N);
+        const long bm = i / N;
+        const long b = bm / M;
+        const long y = location[2 * bm], xx = location[2 * bm + 1];
+        const bool ok = y >= 0 && y < H && xx >= 0 && xx < W;
+        grad_x[i] = ok ? grad_out[(b * N + n) * HW + y * W + xx] : 0.f;
+    }
+}
+
+}  // namespace
+}  // namespace hpc_rll
+
+using namespace hpc_rll;
+
+extern "C" int hpc_rll_pad_forward(const int64_t* table, float* new_x, int32_t* mask, int64_t n, int m0, int m1,
+                                   int m2, int value, void* stream) {
+    if (n < 0 || m0 < 0 || m1 < 0 || m2 < 0) return HPC_RLL_EINVAL;
+    const long inner = (long)m0 * m1 * m2;
+    if (inner >= (1L << 31)) return HPC_RLL_EUNSUPPORTED;
+    const long total = n * inner;
+    if (total == 0) return HPC_RLL_OK;
+    if (!table || !new_x || !mask) return HPC_RLL_EINVAL;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL(pad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, new_x, mask,
+                       (long)n, (unsigned)m0, (unsigned)m1, (unsigned)m2, (float)value, value);
+    return last_error();
+}
+
+extern "C" int hpc_rll_unpad_forward(const float* padded, const int64_t* table, float* flat, int64_t n,
+                                     int64_t total, int m0, int m1, int m2, void* stream) {
+    if (n < 0 || total < 0 || m0 < 0 || m1 < 0 || m2 < 0) return HPC_RLL_EINVAL;
+    if (total == 0 || n == 0) return HPC_RLL_OK;
+    if (!padded || !table || !flat) return HPC_RLL_EINVAL;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, padded, table, flat,
+                       (long)n, (long)total, (unsigned)m0, (unsigned)m1, (unsigned)m2);
+    return last_error();
+}
+
+// ---- group splitting policies (host logic; reference: padding.cu:8-108).  sizes: n x dim, row-major, the list is
+// already sorted by numel.  Outputs: group_shapes (<= group rows of dim ints), positions (<= group+1 ints).
+// Returns the number of groups (>= 1) or a negative error.
+extern "C" int hpc_rll_oracle_split_group(const int32_t* sizes, int n, int dim, int group, int32_t* group_shapes,
+                                          int32_t* positions) {
+    if (!sizes || n <= 0 || dim <= 0 || dim > 3 || group <= 0 || !group_shapes || !positions) return HPC_RLL_EINVAL;
+    const int M = group < n ? group : n;  // more groups than tensors is meaningless (the reference would walk off)
+    const int64_t INF = INT64_MAX / 4;
+    std::vector<int64_t> cost((size_t)(n + 1) * (M + 1), INF);
+    std::vector<int32_t> pos((size_t)(n + 1) * (M + 1), 0);
+    auto C = [&](int i, int j) -> int64_t& { return cost[(size_t)i * (M + 1) + j]; };
+    auto P = [&](int i, int j) -> int32_t& { return pos[(size_t)i * (M + 1) + j]; };
+    C(0, 0) = 0;
+    std::vector<int64_t> elems(n);  // elems[k] = prod_d max_{k<=t<=i-1} sizes[t][d]
+    for (int i = 1; i <= n; ++i) {
+        int32_t mx[3] = {0, 0, 0};
+        for (int k = i - 1; k >= 0; --k) {
+            int64_t e = 1;
+            for (int d = 0; d < dim; ++d) {
+                mx[d] = std::max(mx[d], sizes[(size_t)k * dim + d]);
+                e *= mx[d];
+            }
+            elems[k] = e;
+        }
+        for (int j = 1; j <= M; ++j) {
+            int64_t best = INF;
+            int32_t arg = 0;
+            for (int k = 0; k < i; ++k) {
+                if (C(k, j - 1) >= INF) continue;
+                const int64_t c = C(k, j - 1) + elems[k] * (i - k);
+                if (c < best) { best = c; arg = k; }  // strict: the smallest k wins ties, like the reference
+            }
+            C(i, j) = best;
+            P(i, j) = arg;
+        }
+    }
+    std::vector<int32_t> ps;
+    int lp = n, lc = M;
+    ps.push_back(n);
+    while (lp > 0) { lp = P(lp, lc); --lc; ps.push_back(lp); }
+    std::reverse(ps.begin(), ps.end());
+    const int ng = (int)ps.size() - 1;
+    for (int g = 0; g < ng; ++g) {
+        for (int d = 0; d < dim; ++d) {
+            int32_t m = 0;
+            for (int t = ps[g]; t < ps[g + 1]; ++t) m = std::max(m, sizes[(size_t)t * dim + d]);
+            group_shapes[g * dim + d] = m;
+        }
+    }
+    for (int g = 0; g <= ng; ++g) positions[g] = ps[g];
+    return ng;
+}
+
+extern "C" int hpc_rll_sample_split_group(const int32_t* sizes, int n, int dim, int group, uint64_t seed,
+                                          int32_t* group_shapes, int32_t* positions) {
+    if (!sizes || n <= 0 || dim <= 0 || dim > 3 || group <= 0 || !group_shapes || !positions) return HPC_RLL_EINVAL;
+    auto next_rand = [&seed]() {  // splitmix64
+        uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    std::vector<int> cut;
+    if (n >= 3) {  // the reference draws from [1, n-2] and divides by zero for n = 2 (padding.cu:17)
+        int last = -1;
+        for (int i = 0; i < group - 1; ++i) {
+            int now = last;
+            if (n == 3) now = 1;
+            else while (now == last) now = (int)(next_rand() % (uint64_t)(n - 2)) + 1;
+            cut.push_back(now);
+            last = now;
+        }
+        std::sort(cut.begin(), cut.end());
+    }
+    cut.push_back(n - 1);
+    int ng = 0, last_idx = -1;
+    for (int idx : cut) {
+        if (idx <= last_idx) continue;
+        int32_t shape[3] = {-1, -1, -1};
+        for (int t = last_idx + 1; t <= idx; ++t)
+            for (int d = 0; d < dim; ++d) shape[d] = std::max(shape[d], sizes[(size_t)t * dim + d]);
+        if (ng > 0 && std::memcmp(shape, group_shapes + (ng - 1) * dim, sizeof(int32_t) * dim) == 0) {
+            // same padded shape as the previous group: merge into it (the reference skips the cut)
+            last_idx = idx;
+            continue;
+        }
+        for (int d = 0; d < dim; ++d) group_shapes[ng * dim + d] = shape[d];
+        positions[ng] = last_idx + 1;
+        ++ng;
+        last_idx = idx;
+    }
+    positions[ng] = n;
+    return ng;
+}
+
+// ---- ScatterConnection
+extern "C" int64_t hpc_rll_scatter_workspace_ints(int B, int M, int H, int W) {
+    return (int64_t)B * (2 * (int64_t)H * W + M);
+}
+
+extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t* location, float* out,
+                                                  int32_t* ws, int B, int M, int N, int H, int W, int add,
+                                                  void* stream) {
+    if (B < 0 || M < 0 || N < 0 || H < 0 || W < 0) return HPC_RLL_EINVAL;
+    const long HW = (long)H * W;
+    if ((size_t)B * N * HW == 0) return HPC_RLL_OK;
+    if (!out || !ws || (M > 0 && (!x || !location))) return HPC_RLL_EINVAL;
+    if (HW >= (1L << 31) || (size_t)M * sizeof(int32_t) > 64 * 1024 || B > 65535) return HPC_RLL_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(scatter_index_kernel, dim3(B), dim3(256), (size_t)M * sizeof(int32_t), st, location, ws, M, H,
+                       W);
+    int rc = last_error();
+    if (rc) return rc;
+    const int cell_blocks = (int)((HW + 255) / 256);
+    // enough workgroups to cover the chip: split the channel axis when B * cell_blocks is small
+    int n_per_block = N;
+    while (n_per_block > 4 && (long)B * cell_blocks * ((N + n_per_block - 1) / n_per_block) < 2048) n_per_block = (n_per_block / 2 + 3) / 4 * 4;
+    const dim3 grid(cell_blocks, (N + n_per_block - 1) / n_per_block, B);
+    const bool vec = (N % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (add) hipLaunchKernelGGL(scatter_out_kernel<true>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block, vec);
+    else hipLaunchKernelGGL(scatter_out_kernel<false>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block, vec);
+    return last_error();
+}
+
+extern "C" int hpc_rll_scatter_connection_backward(const float* grad_out, const int64_t* location, float* grad_x,
+                                                   int B, int M, int N, int H, int W, void* stream) {
+    if (B < 0 || M < 0 || N < 0 || H < 0 || W < 0) return HPC_RLL_EINVAL;
+    if ((size_t)B * M * N == 0) return HPC_RLL_OK;
+    if (!grad_out || !location || !grad_x) return HPC_RLL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const long plane_bytes = HW * 4;
+    if (plane_bytes <= 64 * 1024 && B <= 65535) {
+        int NG = (int)std::min<long>(N, std::max<long>(1, (64 * 1024) / plane_bytes));
+        if (NG > 16) NG = 16;
+        const dim3 grid((N + NG - 1) / NG, B);
+        hipLaunchKernelGGL(scatter_bwd_lds_kernel, grid, dim3(256), (size_t)NG * plane_bytes, st, grad_out, location,
+                           grad_x, M, N, H, W, NG);
+    } else {
+        const long total = (long)B * M * N;
+        long blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(scatter_bwd_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad_out, location,
+                           grad_x, total, M, N, H, W);
+    }
+    return last_error();
+}

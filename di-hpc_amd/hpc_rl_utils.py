@@ -416,3 +416,163 @@ def QRDQNNStepTDErrorBackward(inputs, outputs) -> None:
     g = N.require(grad_loss.reshape(1), "grad_loss", device=dev)
     N.call("hpc_rll_qrdqn_nstep_td_backward", dev, g.data_ptr(), grad_buf.data_ptr(), action.data_ptr(),
            grad_q.data_ptr(), tau, B, NA)
+
+
+# ------------------------------------------------------------------------------------------------ Pad / Unpad
+def _dims3(shape):
+    """(d0,d1,d2) with the tensor's own axes right-aligned: a rank-1 tensor is (1,1,L)."""
+    s = tuple(int(v) for v in shape)
+    return (1,) * (3 - len(s)) + s
+
+
+def _device_table(rows, dev):
+    """n x 4 int64 host table -> device (pinned staging, async copy on the current stream)."""
+    t = torch.tensor(rows, dtype=I64).reshape(-1, 4)
+    if t.numel() == 0:
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
+def _pad_forward(inputs, value, rank, max_shape=None):
+    if len(inputs) == 0:
+        raise RuntimeError("Padding: empty input list")
+    dev = inputs[0].device
+    for i, t in enumerate(inputs):
+        N.require(t, f"inputs[{i}]", device=dev)
+        if t.dim() != rank:
+            raise RuntimeError(f"inputs[{i}]: rank {t.dim()}, expected {rank}")
+    if max_shape is None:
+        max_shape = [max(t.shape[d] for t in inputs) for d in range(rank)]
+    m = _dims3(max_shape)
+    n = len(inputs)
+    table = _device_table([[t.data_ptr(), *_dims3(t.shape)] for t in inputs], dev)
+    new_x = torch.empty([n] + list(max_shape), dtype=F32, device=dev)
+    mask = torch.empty([n] + list(max_shape), dtype=torch.int32, device=dev)
+    N.call("hpc_rll_pad_forward", dev, table.data_ptr(), new_x.data_ptr(), mask.data_ptr(), n, m[0], m[1], m[2],
+           int(value))
+    return [new_x, mask]
+
+
+def Pad1DForward(inputs, value: int):
+    """list of n (L_i,) tensors -> [new_x (n,maxL) fp32, mask (n,maxL) int32].  Reference: padding.cu:111-140."""
+    return _pad_forward(inputs, value, 1)
+
+
+def Pad2DForward(inputs, value: int):
+    """Reference: padding.cu:262-297."""
+    return _pad_forward(inputs, value, 2)
+
+
+def Pad3DForward(inputs, value: int):
+    """Reference: padding.cu:417-456."""
+    return _pad_forward(inputs, value, 3)
+
+
+def _group_pad_forward(inputs, group_cnt, max_shape, group_id, group_idx, value, rank):
+    """inputs sorted by numel; group g = inputs[group_idx[g]:group_idx[g+1]], padded to max_shape[g*rank:(g+1)*rank].
+    One pad launch per group.  Returns [list of new_x, list of mask]."""
+    xs, ms = [], []
+    for g in range(len(group_cnt)):
+        sub = inputs[group_idx[g]:group_idx[g + 1]]
+        shape = [int(v) for v in max_shape[g * rank:(g + 1) * rank]]
+        x, m = _pad_forward(sub, value, rank, shape)
+        xs.append(x)
+        ms.append(m)
+    return [xs, ms]
+
+
+def GroupPad1DForward(inputs, group_cnt, max_shape, group_id, group_idx, value: int):
+    """Reference: padding.cu:142-226."""
+    return _group_pad_forward(inputs, group_cnt, max_shape, group_id, group_idx, value, 1)
+
+
+def GroupPad2DForward(inputs, group_cnt, max_shape, group_id, group_idx, value: int):
+    """Reference: padding.cu:299-379."""
+    return _group_pad_forward(inputs, group_cnt, max_shape, group_id, group_idx, value, 2)
+
+
+def GroupPad3DForward(inputs, group_cnt, max_shape, group_id, group_idx, value: int):
+    """Reference: padding.cu:458-541."""
+    return _group_pad_forward(inputs, group_cnt, max_shape, group_id, group_idx, value, 3)
+
+
+def _unpad_forward(x, shapes, rank):
+    """x (n, m...) padded; shapes = flat int list (rank ints per tensor, the hpc convention,
+    rl_utils/padding.py:101-104).  Returns n tensors that are views of ONE flat buffer."""
+    N.require(x, "x")
+    if x.dim() != rank + 1:
+        raise RuntimeError(f"x: rank {x.dim()}, expected {rank + 1}")
+    n = x.shape[0]
+    shapes = [int(v) for v in shapes]
+    if len(shapes) != n * rank:
+        raise RuntimeError(f"shapes: {len(shapes)} ints, expected {n}*{rank}")
+    dev = x.device
+    rows, offs, total = [], [], 0
+    per = [tuple(shapes[i * rank:(i + 1) * rank]) for i in range(n)]
+    for s in per:
+        for d in range(rank):
+            if s[d] > x.shape[d + 1] or s[d] < 0:
+                raise RuntimeError(f"shapes: {s} does not fit the padded tensor {tuple(x.shape[1:])}")
+        rows.append([total, *_dims3(s)])
+        offs.append(total)
+        k = 1
+        for v in s:
+            k *= v
+        total += k
+    flat = torch.empty(total, dtype=F32, device=dev)
+    if n and total:
+        m = _dims3(x.shape[1:])
+        table = _device_table(rows, dev)
+        N.call("hpc_rll_unpad_forward", dev, x.data_ptr(), table.data_ptr(), flat.data_ptr(), n, total, m[0], m[1], m[2])
+    out = []
+    for s, o in zip(per, offs):
+        k = 1
+        for v in s:
+            k *= v
+        out.append(flat[o:o + k].view(*s))
+    return out
+
+
+def Unpad1DForward(x, shapes):
+    """Reference: padding.cu:228-260."""
+    return _unpad_forward(x, shapes, 1)
+
+
+def Unpad2DForward(x, shapes):
+    """Reference: padding.cu:381-415."""
+    return _unpad_forward(x, shapes, 2)
+
+
+def Unpad3DForward(x, shapes):
+    """Reference: padding.cu:543-582."""
+    return _unpad_forward(x, shapes, 3)
+
+
+def _split_group(inputs, group, fn, *extra):
+    import ctypes
+    n = len(inputs)
+    rank = inputs[0].dim()
+    sizes = (ctypes.c_int32 * (n * rank))(*[int(v) for t in inputs for v in t.shape])
+    shapes = (ctypes.c_int32 * (max(group, 1) * rank))()
+    pos = (ctypes.c_int32 * (max(group, 1) + 1))()
+    ng = fn(ctypes.cast(sizes, ctypes.c_void_p), n, rank, int(group), *extra, ctypes.cast(shapes, ctypes.c_void_p),
+            ctypes.cast(pos, ctypes.c_void_p))
+    if ng < 0:
+        N.check(ng, "split_group")
+    res = [[int(shapes[g * rank + d]) for d in range(rank)] for g in range(ng)]
+    res.append([int(pos[g]) for g in range(ng + 1)])
+    return res
+
+
+def oracle_split_group(inputs, group: int):
+    """Inputs sorted by numel -> [shape_0, ..., shape_{g-1}, positions].  DP minimising the padded element count
+    (padding.cu:44-108; same result as hpc_rll/origin/padding.py:11-50 for 1-D lists)."""
+    return _split_group(inputs, group, _lib.hpc_rll_oracle_split_group)
+
+
+def sample_split_group(inputs, group: int, seed=None):
+    """Random cuts (padding.cu:8-43).  The reference uses C rand(); here a splitmix64 stream seeded from python's
+    ``random`` (or ``seed``), so a run is reproducible under ``random.seed``."""
+    import random
+    s = random.getrandbits(63) if seed is None else int(seed)
+    return _split_group(inputs, group, _lib.hpc_rll_sample_split_group, s)

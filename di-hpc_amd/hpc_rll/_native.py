@@ -28,7 +28,8 @@ if not os.path.exists(LIB_PATH):
 
 lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 
-_CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t}
+_CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
+           "uint64_t": ctypes.c_uint64}
 
 
 def _parse_header(path):

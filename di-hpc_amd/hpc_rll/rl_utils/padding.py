@@ -1,0 +1,79 @@
+"""``hpc_rll.rl_utils.padding`` -- drop-in for /root/reference/hpc_rll/rl_utils/padding.py:14-180:
+``Padding{1,2,3}D(inputs, mode='constant', value=0, group=1, group_mode='sample')`` and
+``UnPadding{1,2,3}D(x, shapes)`` with the reference's return conventions: ``(new_x, mask, shapes)`` where ``mask`` is
+int32 and ``shapes`` is a FLAT int list (rank ints per tensor), or ``[tuple(new_x), tuple(mask), tuple(shapes)]`` when
+``group > 1`` (inputs are then sorted by element count first)."""
+from functools import reduce
+from typing import List, Union
+
+import torch
+
+import hpc_rl_utils
+
+
+def cum(t: List[int]) -> int:
+    return reduce(lambda x, y: x * y, t)
+
+
+def _padding(inputs, mode, value, group, group_mode, rank):
+    assert mode in ['constant'], mode
+    assert group_mode in ['sample', 'oracle'], group_mode
+    assert group >= 1, group
+    pad = {1: hpc_rl_utils.Pad1DForward, 2: hpc_rl_utils.Pad2DForward, 3: hpc_rl_utils.Pad3DForward}[rank]
+    gpad = {1: hpc_rl_utils.GroupPad1DForward, 2: hpc_rl_utils.GroupPad2DForward, 3: hpc_rl_utils.GroupPad3DForward}[rank]
+    if group > 1:
+        inputs = sorted(inputs, key=lambda t: cum(t.shape))
+        split = hpc_rl_utils.sample_split_group if group_mode == 'sample' else hpc_rl_utils.oracle_split_group
+        res = split(inputs, group)
+        group_idx, group_shape = res[-1], res[:-1]
+        assert len(group_idx) == len(group_shape) + 1
+        max_shape = [d for s in group_shape for d in s]
+        group_cnt = [group_idx[i + 1] - group_idx[i] for i in range(len(group_shape))]
+        shapes, group_id, k = [], [], 0
+        for i, cnt in enumerate(group_cnt):
+            shape = []
+            for _ in range(cnt):
+                shape.extend(int(v) for v in inputs[k].shape)
+                group_id.append(i)
+                k += 1
+            shapes.append(shape)
+        assert len(group_id) == len(inputs)
+        new_x, mask = gpad(inputs, group_cnt, max_shape, group_id, group_idx, value)
+        return [tuple(new_x), tuple(mask), tuple(shapes)]
+    shapes = [int(v) for t in inputs for v in t.shape]
+    new_x, mask = pad(inputs, value)
+    return new_x, mask, shapes
+
+
+def _unpadding(x, shapes, rank):
+    un = {1: hpc_rl_utils.Unpad1DForward, 2: hpc_rl_utils.Unpad2DForward, 3: hpc_rl_utils.Unpad3DForward}[rank]
+    if isinstance(x, torch.Tensor):
+        return un(x, shapes)
+    ret = []
+    for t, s in zip(x, shapes):
+        ret.append(un(t, s))
+    return sum(ret, [])
+
+
+def Padding1D(inputs: List[torch.Tensor], mode='constant', value: int = 0, group: int = 1, group_mode='sample'):
+    return _padding(inputs, mode, value, group, group_mode, 1)
+
+
+def UnPadding1D(x: Union[torch.Tensor, List[torch.Tensor]], shapes: Union[List, List[List]]) -> List[torch.Tensor]:
+    return _unpadding(x, shapes, 1)
+
+
+def Padding2D(inputs: List[torch.Tensor], mode='constant', value: int = 0, group: int = 1, group_mode='sample'):
+    return _padding(inputs, mode, value, group, group_mode, 2)
+
+
+def UnPadding2D(x: Union[torch.Tensor, List[torch.Tensor]], shapes: Union[List, List[List]]) -> List[torch.Tensor]:
+    return _unpadding(x, shapes, 2)
+
+
+def Padding3D(inputs: List[torch.Tensor], mode='constant', value: int = 0, group: int = 1, group_mode='sample'):
+    return _padding(inputs, mode, value, group, group_mode, 3)
+
+
+def UnPadding3D(x: Union[torch.Tensor, List[torch.Tensor]], shapes: Union[List, List[List]]) -> List[torch.Tensor]:
+    return _unpadding(x, shapes, 3)

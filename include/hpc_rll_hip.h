@@ -175,6 +175,40 @@ int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_n_q, const 
 int hpc_rll_qrdqn_nstep_td_backward(const float* grad_loss, const float* buf, const int64_t* action, float* grad_q,
                                     int tau, int B, int N, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Pad / Unpad of a ragged list of n contiguous fp32 tensors of rank 1..3 -- replaces Pad{1,2,3}DForward,
+ * GroupPad{1,2,3}DForward, Unpad{1,2,3}DForward (rl_utils/entry.h:10-59, src/rl_utils/padding.cu:111-582).
+ * A rank-1 tensor of length L is described as (d0,d1,d2) = (1,1,L), rank-2 (a,b) as (1,a,b).
+ *   pad  : table (device, n x 4 int64) = {source pointer, d0, d1, d2}; new_x (n,m0,m1,m2) fp32 gets the
+ *          data and `value` elsewhere; mask (same shape, int32) gets 1 inside and `value` outside.
+ *   unpad: table (device, n x 4 int64) = {offset of tensor i in `flat` (elements), d0, d1, d2}, offsets
+ *          ascending; flat (total floats) receives the tensors back to back.
+ * Group padding = one pad call per group (the grouping policy is host logic, below).
+ * ------------------------------------------------------------------------------------------ */
+int hpc_rll_pad_forward(const int64_t* table, float* new_x, int32_t* mask, int64_t n, int m0, int m1, int m2,
+                        int value, void* stream);
+int hpc_rll_unpad_forward(const float* padded, const int64_t* table, float* flat, int64_t n, int64_t total,
+                          int m0, int m1, int m2, void* stream);
+/* Group-split policies over a list sorted by numel (host code; padding.cu:8-108).  sizes: n x dim int32.
+ * Write <= `group` rows of `dim` ints to group_shapes and <= group+1 boundaries to positions; return the
+ * number of groups (>= 1) or a negative HPC_RLL_E* code.  oracle = the O(group * n^2) DP minimising padded
+ * elements (ties -> smallest split point); sample = random cuts (deterministic for a given seed). */
+int hpc_rll_oracle_split_group(const int32_t* sizes, int n, int dim, int group, int32_t* group_shapes,
+                               int32_t* positions);
+int hpc_rll_sample_split_group(const int32_t* sizes, int n, int dim, int group, uint64_t seed,
+                               int32_t* group_shapes, int32_t* positions);
+
+/* ScatterConnection -- replaces ScatterConnectionForward/Backward (torch_utils/network/entry.h:21-29,
+ * src/torch_utils/network/scatter_connection.cu:8-73).  x (B,M,N) fp32, location (B,M,2) int64 (y,x),
+ * out (B,N,H,W) fp32 (fully written: no pre-zeroing needed); add=0: "cover" (the largest m at a cell wins,
+ * like the CPU oracle), add=1: sum in ascending m.  ws: hpc_rll_scatter_workspace_ints(B,M,H,W) int32.
+ * backward: grad_x[b,m,:] = grad_out[b,:,y,x] for every entity (also the covered ones). */
+int64_t hpc_rll_scatter_workspace_ints(int B, int M, int H, int W);
+int hpc_rll_scatter_connection_forward(const float* x, const int64_t* location, float* out, int32_t* ws, int B,
+                                       int M, int N, int H, int W, int add, void* stream);
+int hpc_rll_scatter_connection_backward(const float* grad_out, const int64_t* location, float* grad_x, int B, int M,
+                                        int N, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
