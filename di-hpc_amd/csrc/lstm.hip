@@ -1,0 +1,455 @@
+// lstm.hip -- multi-layer LayerNorm-LSTM forward + full BPTT backward for gfx950.
+//
+// Replaces LstmForward/LstmBackward (src/torch_utils/network/lstm.cu:29-379, lstm_kernel.h:12-183).
+// Semantics: hpc_rll/origin/rnn.py:193-248:
+//     gate = LN_x(x_s Wx) + LN_h(h Wh) + bias ;  i,f,o = sigmoid, u = tanh (order i,f,o,u)
+//     c = f*c + i*u ;  h = o*tanh(c) ;  dropout between layers only.
+//
+// Reference structure per (layer, step): cublasSgemm + layernorm kernel + activation kernel (3 launches), a cuBLAS
+// handle created per call, LayerNorm of the x-branch as a separate pass over (S*B,4H), per-step SGEMMs with beta=1
+// for dWx/dWh, float atomics for dbias/dgamma/dbeta, and the incoming dh/dc of the final states are zeroed
+// (lstm.cu:309-310: gradients through hn/cn are dropped).  Here:
+//   * all GEMMs are exact-fp32 MFMA (gemm_f32.hpp); the x-branch GEMM, dWx, dWh and dx are ONE large GEMM per
+//     layer each (K = S*B for the weight gradients) instead of S small accumulating ones;
+//   * per step: 1 GEMM + 1 fused cell kernel.  The cell kernel does BOTH LayerNorms (two-pass mean/variance in
+//     registers), bias, gates and the state update; the x-branch LN is never materialised;
+//   * backward: 1 fused cell kernel (gate adjoint + both LayerNorm adjoints) + 1 GEMM per step; bias / gamma /
+//     beta gradients are a single deterministic column reduction over the saved gate gradients per layer (no
+//     atomics); gradients through hn / cn are propagated (the correct adjoint, matches the oracle).
+//   * dropout masks are a stateless hash of (seed, layer, element): nothing to store, backward recomputes them
+//     (the reference draws cuRAND numbers seeded from /dev/urandom: parity-unpinned, tests use dropout = 0).
+#include <hip/hip_runtime.h>
+
+#include "gemm_f32.hpp"
+#include "hpc_rll_hip.h"
+#include "wave.hpp"
+
+namespace hpc_rll {
+namespace {
+
+constexpr float kLnEps = 1e-5f;
+
+inline int last_error() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HPC_RLL_OK : (int)e;
+}
+
+// Sum K values over the 256 threads of the workgroup; every thread gets the totals.  `lds` holds >= K*4 floats.
+template <int K>
+__device__ __forceinline__ void block_allsum(float (&v)[K], float* lds) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s = wave_sum(v[k]);
+        if (lane == 0) lds[k * 4 + w] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = (lds[k * 4] + lds[k * 4 + 1]) + (lds[k * 4 + 2] + lds[k * 4 + 3]);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ forward cell
+// one workgroup per batch row; thread t owns hidden units j = t, t+256, ... (JPT of them) x 4 gates x 2 branches.
+template <int JPT>
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
+    const float* __restrict__ xw, const float* __restrict__ hw, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ c_prev,
+    float* __restrict__ gates, float* __restrict__ c_out, float* __restrict__ h_out, float* __restrict__ stats,
+    int H) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    const int G = 4 * H;
+    const float* __restrict__ xr = xw + (size_t)b * G;
+    const float* __restrict__ hr = hw + (size_t)b * G;
+    float x[JPT][4], h[JPT][4];
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) {
+        const int j = threadIdx.x + q * 256;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            x[q][g] = (j < H) ? xr[g * H + j] : 0.f;
+            h[q][g] = (j < H) ? hr[g * H + j] : 0.f;
+            s[0] += x[q][g];
+            s[1] += h[q][g];
+        }
+    }
+    block_allsum<2>(s, red);
+    const float inv_g = 1.f / (float)G;
+    const float mx = s[0] * inv_g, mh = s[1] * inv_g;
+    float v[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) {
+        const int j = threadIdx.x + q * 256;
+        if (j < H) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v[0] += (x[q][g] - mx) * (x[q][g] - mx);
+                v[1] += (h[q][g] - mh) * (h[q][g] - mh);
+            }
+        }
+    }
+    block_allsum<2>(v, red);
+    const float rx = rsqrtf(v[0] * inv_g + kLnEps), rh = rsqrtf(v[1] * inv_g + kLnEps);
+    if (threadIdx.x == 0) {
+        float* st = stats + (size_t)b * 4;
+        st[0] = mx; st[1] = rx; st[2] = mh; st[3] = rh;
+    }
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) {
+        const int j = threadIdx.x + q * 256;
+        if (j < H) {
+            float a[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = g * H + j;
+                a[g] = (x[q][g] - mx) * rx * gamma[col] + beta[col] + (h[q][g] - mh) * rh * gamma[G + col] +
+                       beta[G + col] + bias[col];
+            }
+            const float ig = 1.f / (1.f + expf(-a[0]));
+            const float fg = 1.f / (1.f + expf(-a[1]));
+            const float og = 1.f / (1.f + expf(-a[2]));
+            const float ug = tanhf(a[3]);
+            const float c = fg * c_prev[(size_t)b * H + j] + ig * ug;
+            float* gr = gates + (size_t)b * G;
+            gr[j] = ig; gr[H + j] = fg; gr[2 * H + j] = og; gr[3 * H + j] = ug;
+            c_out[(size_t)b * H + j] = c;
+            h_out[(size_t)b * H + j] = og * tanhf(c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward cell
+// dh = dh_a + dh_b (either may be null); outputs dgate, dXW, dHW rows and dc_prev.
+template <int JPT>
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
+    const float* __restrict__ dh_a, const float* __restrict__ dh_b, const float* dc_in /* may alias dc_prev */,
+    const float* __restrict__ gates, const float* __restrict__ c_new, const float* __restrict__ c_prev,
+    const float* __restrict__ xw, const float* __restrict__ hw, const float* __restrict__ stats,
+    const float* __restrict__ gamma, float* __restrict__ dgate, float* __restrict__ dxw, float* __restrict__ dhw,
+    float* dc_prev, int H) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    const int G = 4 * H;
+    const float* st = stats + (size_t)b * 4;
+    const float mx = st[0], rx = st[1], mh = st[2], rh = st[3];
+    float da[JPT][4], xh[JPT][4], hh[JPT][4];   // gate adjoint, normalised x-branch, normalised h-branch
+    float r[4] = {0.f, 0.f, 0.f, 0.f};          // sum dy_g (x), sum dy_g*xhat (x), same for h
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) {
+        const int j = threadIdx.x + q * 256;
+        if (j < H) {
+            const size_t o = (size_t)b * H + j;
+            const float* gr = gates + (size_t)b * G;
+            const float ig = gr[j], fg = gr[H + j], og = gr[2 * H + j], ug = gr[3 * H + j];
+            const float dh = (dh_a ? dh_a[o] : 0.f) + (dh_b ? dh_b[o] : 0.f);
+            const float tc = tanhf(c_new[o]);
+            const float dc = (dc_in ? dc_in[o] : 0.f) + dh * og * (1.f - tc * tc);
+            da[q][0] = dc * ug * ig * (1.f - ig);
+            da[q][1] = dc * c_prev[o] * fg * (1.f - fg);
+            da[q][2] = dh * tc * og * (1.f - og);
+            da[q][3] = dc * ig * (1.f - ug * ug);
+            dc_prev[o] = dc * fg;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = g * H + j;
+                xh[q][g] = (xw[(size_t)b * G + col] - mx) * rx;
+                hh[q][g] = (hw[(size_t)b * G + col] - mh) * rh;
+                const float dyx = da[q][g] * gamma[col], dyh = da[q][g] * gamma[G + col];
+                r[0] += dyx; r[1] += dyx * xh[q][g];
+                r[2] += dyh; r[3] += dyh * hh[q][g];
+                dgate[(size_t)b * G + col] = da[q][g];
+            }
+        }
+    }
+    block_allsum<4>(r, red);
+    const float inv_g = 1.f / (float)G;
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) {
+        const int j = threadIdx.x + q * 256;
+        if (j < H) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = g * H + j;
+                const float dyx = da[q][g] * gamma[col], dyh = da[q][g] * gamma[G + col];
+                dxw[(size_t)b * G + col] = rx * (dyx - r[0] * inv_g - xh[q][g] * r[1] * inv_g);
+                dhw[(size_t)b * G + col] = rh * (dyh - r[2] * inv_g - hh[q][g] * r[3] * inv_g);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column reductions
+// dbias[col] = sum_rows dgate ; dbeta (both halves) = the same sum ; dgamma_x[col] = sum dgate * xhat_x ; dgamma_h
+// likewise.  One workgroup per 64 columns: 4 waves stride over the rows, lanes over columns (coalesced), fixed
+// summation order (deterministic).
+__global__ __launch_bounds__(256) void lstm_colreduce_kernel(const float* __restrict__ dgate,
+                                                             const float* __restrict__ xw,
+                                                             const float* __restrict__ hw,
+                                                             const float* __restrict__ stats, long rows, int G,
+                                                             float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    __shared__ float red[3][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float sb = 0.f, sx = 0.f, sh = 0.f;
+    if (col < G) {
+        for (long row = w; row < rows; row += 4) {
+            const float* st = stats + row * 4;
+            const float d = dgate[row * G + col];
+            sb += d;
+            sx = fmaf(d, (xw[row * G + col] - st[0]) * st[1], sx);
+            sh = fmaf(d, (hw[row * G + col] - st[2]) * st[3], sh);
+        }
+    }
+    red[0][w][lane] = sb; red[1][w][lane] = sx; red[2][w][lane] = sh;
+    __syncthreads();
+    if (w == 0 && col < G) {
+        const float b = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        dbias[col] = b;
+        dbeta[col] = b;
+        dbeta[G + col] = b;
+        dgamma[col] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+        dgamma[G + col] = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dropout
+__device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+// out[i] = in[i] * keep(i) / (1-p); keep(i) = hash > p * 2^32 (the reference's rule, lstm_kernel.h:88-94)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* in, float* out, long n,  // in == out allowed
+                                                      uint64_t seed, uint32_t threshold, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = (mix_hash(seed, (uint64_t)i) > threshold) ? in[i] * scale : 0.f;
+}
+
+template <class... Args>
+inline void launch_cell_fwd(int H, int B, hipStream_t st, Args... a) {
+    const int jpt = (H + 255) / 256;
+    if (jpt <= 1) hipLaunchKernelGGL(lstm_cell_fwd_kernel<1>, dim3(B), dim3(256), 0, st, a..., H);
+    else if (jpt <= 2) hipLaunchKernelGGL(lstm_cell_fwd_kernel<2>, dim3(B), dim3(256), 0, st, a..., H);
+    else if (jpt <= 4) hipLaunchKernelGGL(lstm_cell_fwd_kernel<4>, dim3(B), dim3(256), 0, st, a..., H);
+    else hipLaunchKernelGGL(lstm_cell_fwd_kernel<8>, dim3(B), dim3(256), 0, st, a..., H);
+}
+template <class... Args>
+inline void launch_cell_bwd(int H, int B, hipStream_t st, Args... a) {
+    const int jpt = (H + 255) / 256;
+    if (jpt <= 1) hipLaunchKernelGGL(lstm_cell_bwd_kernel<1>, dim3(B), dim3(256), 0, st, a..., H);
+    else if (jpt <= 2) hipLaunchKernelGGL(lstm_cell_bwd_kernel<2>, dim3(B), dim3(256), 0, st, a..., H);
+    else if (jpt <= 4) hipLaunchKernelGGL(lstm_cell_bwd_kernel<4>, dim3(B), dim3(256), 0, st, a..., H);
+    else hipLaunchKernelGGL(lstm_cell_bwd_kernel<8>, dim3(B), dim3(256), 0, st, a..., H);
+}
+
+// workspace carving --------------------------------------------------------------------------------------------
+struct LayerWs { float *xw, *hw, *gates, *c, *hseq, *stats, *xin_next; };
+struct Ws {
+    LayerWs layer[16];
+    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b;
+    size_t total;
+};
+inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
+    Ws w;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 3) / 4 * 4; return p; };
+    const size_t SB = (size_t)S * B, G = 4 * (size_t)H;
+    for (int l = 0; l < L; ++l) {
+        w.layer[l].xw = take(SB * G);
+        w.layer[l].hw = take(SB * G);
+        w.layer[l].gates = take(SB * G);
+        w.layer[l].c = take(SB * H);
+        w.layer[l].hseq = take(SB * H);
+        w.layer[l].stats = take(SB * 4);
+        w.layer[l].xin_next = (dropout && l < L - 1) ? take(SB * H) : w.layer[l].hseq;
+    }
+    w.dgate = take(SB * G);
+    w.dxw = take(SB * G);
+    w.dhw = take(SB * G);
+    w.dh = take((size_t)B * H);
+    w.dc = take((size_t)B * H);
+    const size_t widest = SB * (size_t)(I > H ? I : H);
+    w.dseq_a = take(widest);
+    w.dseq_b = take(widest);
+    w.total = off;
+    return w;
+}
+
+inline int copy_async(float* dst, const float* src, size_t n, hipStream_t st) {
+    return (int)hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+}
+
+}  // namespace
+}  // namespace hpc_rll
+
+using namespace hpc_rll;
+
+extern "C" int64_t hpc_rll_lstm_workspace_floats(int S, int B, int I, int H, int L, float dropout_p) {
+    if (S < 0 || B < 0 || I < 0 || H < 0 || L < 0 || L > 16) return -1;
+    return (int64_t)carve(nullptr, S, B, I, H, L, dropout_p > 0.f).total;
+}
+
+extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float* c0, const float* wx,
+                                    const float* wh, const float* bias, const float* ln_gamma, const float* ln_beta,
+                                    float* y, float* hn, float* cn, float* ws, int S, int B, int I, int H, int L,
+                                    float dropout_p, uint64_t seed, void* stream) {
+    if (S < 0 || B < 0 || I <= 0 || H <= 0 || L <= 0 || L > 16) return HPC_RLL_EINVAL;
+    if (H > 2048) return HPC_RLL_EUNSUPPORTED;
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return HPC_RLL_EINVAL;
+    if (B == 0) return HPC_RLL_OK;
+    if (!h0 || !c0 || !wx || !wh || !bias || !ln_gamma || !ln_beta || !hn || !cn) return HPC_RLL_EINVAL;
+    if (S > 0 && (!x || !y || !ws)) return HPC_RLL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t SB = (size_t)S * B, G = 4 * (size_t)H, BH = (size_t)B * H;
+    const Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
+    size_t wx_off = 0;
+    for (int l = 0; l < L; ++l) {
+        const int in_l = l == 0 ? I : H;
+        const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
+        const float* wx_l = wx + wx_off;
+        const float* wh_l = wh + (size_t)l * H * G;
+        const LayerWs& lw = w.layer[l];
+        if (S > 0) {
+            GemmArgs g{xin, wx_l, lw.xw, (int)SB, (int)G, in_l, in_l, 1, (long)G, 1, (long)G, 0};
+            launch_gemm(g, st);
+        }
+        for (int s = 0; s < S; ++s) {
+            const float* h_prev = s == 0 ? h0 + (size_t)l * BH : lw.hseq + (size_t)(s - 1) * BH;
+            const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
+            GemmArgs g{h_prev, wh_l, lw.hw + (size_t)s * B * G, B, (int)G, H, H, 1, (long)G, 1, (long)G, 0};
+            launch_gemm(g, st);
+            launch_cell_fwd(H, B, st, (const float*)(lw.xw + (size_t)s * B * G),
+                            (const float*)(lw.hw + (size_t)s * B * G), bias + (size_t)l * G,
+                            ln_gamma + (size_t)l * 2 * G, ln_beta + (size_t)l * 2 * G, c_prev,
+                            lw.gates + (size_t)s * B * G, lw.c + (size_t)s * BH, lw.hseq + (size_t)s * BH,
+                            lw.stats + (size_t)s * B * 4);
+        }
+        int rc = last_error();
+        if (rc) return rc;
+        const float* h_last = S > 0 ? lw.hseq + (size_t)(S - 1) * BH : h0 + (size_t)l * BH;
+        const float* c_last = S > 0 ? lw.c + (size_t)(S - 1) * BH : c0 + (size_t)l * BH;
+        if ((rc = copy_async(hn + (size_t)l * BH, h_last, BH, st))) return rc;
+        if ((rc = copy_async(cn + (size_t)l * BH, c_last, BH, st))) return rc;
+        if (dropout_p > 0.f && l < L - 1 && S > 0) {
+            const long n = (long)(SB * H);
+            long blocks = (n + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)lw.hseq,
+                               lw.xin_next, n, seed + 0x1000003ull * (uint64_t)(l + 1),
+                               (uint32_t)((double)dropout_p * 4294967295.0), 1.f / (1.f - dropout_p));
+        }
+        wx_off += (size_t)in_l * G;
+    }
+    if (S > 0) {
+        const int rc = copy_async(y, w.layer[L - 1].hseq, SB * H, st);
+        if (rc) return rc;
+    }
+    return last_error();
+}
+
+extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const float* dcn, const float* x,
+                                     const float* h0, const float* c0, const float* wx, const float* wh,
+                                     const float* ln_gamma, float* ws, float* dx, float* dh0, float* dc0, float* dwx,
+                                     float* dwh, float* dbias, float* dln_gamma, float* dln_beta, int S, int B, int I,
+                                     int H, int L, float dropout_p, uint64_t seed, void* stream) {
+    if (S <= 0 || B <= 0 || I <= 0 || H <= 0 || L <= 0 || L > 16) return HPC_RLL_EINVAL;
+    if (H > 2048) return HPC_RLL_EUNSUPPORTED;
+    if (!x || !h0 || !c0 || !wx || !wh || !ln_gamma || !ws || !dx || !dh0 || !dc0 || !dwx || !dwh || !dbias ||
+        !dln_gamma || !dln_beta)
+        return HPC_RLL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t SB = (size_t)S * B, G = 4 * (size_t)H, BH = (size_t)B * H;
+    const Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
+    size_t wx_offs[16];
+    {
+        size_t o = 0;
+        for (int l = 0; l < L; ++l) { wx_offs[l] = o; o += (size_t)(l == 0 ? I : H) * G; }
+    }
+    // gradient w.r.t. the current layer's output sequence (S,B,H): dy for the top layer
+    const float* d_out = dy;   // may be null (no gradient through y)
+    float* seq_bufs[2] = {w.dseq_a, w.dseq_b};
+    int flip = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        const int in_l = l == 0 ? I : H;
+        const LayerWs& lw = w.layer[l];
+        const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
+        const float* wx_l = wx + wx_offs[l];
+        const float* wh_l = wh + (size_t)l * H * G;
+        const float* gamma_l = ln_gamma + (size_t)l * 2 * G;
+        const float* dh_carry = dhn ? dhn + (size_t)l * BH : nullptr;
+        const float* dc_carry = dcn ? dcn + (size_t)l * BH : nullptr;
+        for (int s = S - 1; s >= 0; --s) {
+            const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
+            launch_cell_bwd(H, B, st, d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dc_carry,
+                            (const float*)(lw.gates + (size_t)s * B * G), (const float*)(lw.c + (size_t)s * BH),
+                            c_prev, (const float*)(lw.xw + (size_t)s * B * G),
+                            (const float*)(lw.hw + (size_t)s * B * G), (const float*)(lw.stats + (size_t)s * B * 4),
+                            gamma_l, w.dgate + (size_t)s * B * G, w.dxw + (size_t)s * B * G,
+                            w.dhw + (size_t)s * B * G, w.dc);
+            // dh_prev (B,H) = dHW_s (B,G) @ Wh^T : B(k=g, n=h) = Wh[h*G + g]
+            GemmArgs g{w.dhw + (size_t)s * B * G, wh_l, w.dh, B, H, (int)G, (long)G, 1, 1, (long)G, (long)H, 0};
+            launch_gemm(g, st);
+            dh_carry = w.dh;
+            dc_carry = w.dc;
+        }
+        int rc = last_error();
+        if (rc) return rc;
+        if ((rc = copy_async(dh0 + (size_t)l * BH, w.dh, BH, st))) return rc;
+        if ((rc = copy_async(dc0 + (size_t)l * BH, w.dc, BH, st))) return rc;
+        // dWh (H,G) = [h0 ; hseq[0..S-2]]^T @ dHW
+        {
+            GemmArgs g0{h0 + (size_t)l * BH, w.dhw, dwh + (size_t)l * H * G, H, (int)G, B, 1, (long)H, (long)G, 1,
+                        (long)G, 0};
+            launch_gemm(g0, st);
+            if (S > 1) {
+                GemmArgs g1{lw.hseq, w.dhw + (size_t)B * G, dwh + (size_t)l * H * G, H, (int)G, (int)((S - 1) * (size_t)B),
+                            1, (long)H, (long)G, 1, (long)G, 1};
+                launch_gemm(g1, st);
+            }
+        }
+        // dWx (in,G) = xin^T @ dXW
+        {
+            GemmArgs g{xin, w.dxw, dwx + wx_offs[l], in_l, (int)G, (int)SB, 1, (long)in_l, (long)G, 1, (long)G, 0};
+            launch_gemm(g, st);
+        }
+        // d xin (S*B, in) = dXW @ Wx^T : B(k=g, n=i) = Wx[i*G + g]
+        float* dxin = l == 0 ? dx : seq_bufs[flip];
+        {
+            GemmArgs g{w.dxw, wx_l, dxin, (int)SB, in_l, (int)G, (long)G, 1, 1, (long)G, (long)in_l, 0};
+            launch_gemm(g, st);
+        }
+        hipLaunchKernelGGL(lstm_colreduce_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st,
+                           (const float*)w.dgate, (const float*)lw.xw, (const float*)lw.hw, (const float*)lw.stats,
+                           (long)SB, (int)G, dbias + (size_t)l * G, dln_gamma + (size_t)l * 2 * G,
+                           dln_beta + (size_t)l * 2 * G);
+        if (l > 0) {
+            if (dropout_p > 0.f) {   // backward of the dropout between layer l-1 and l: same mask, same scale
+                const long n = (long)(SB * H);
+                long blocks = (n + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)dxin, dxin,
+                                   n, seed + 0x1000003ull * (uint64_t)l, (uint32_t)((double)dropout_p * 4294967295.0),
+                                   1.f / (1.f - dropout_p));
+            }
+            d_out = dxin;
+            flip ^= 1;
+        }
+        rc = last_error();
+        if (rc) return rc;
+    }
+    return HPC_RLL_OK;
+}
+
+extern "C" int hpc_rll_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_sm,
+                                int64_t a_sk, int64_t b_sk, int64_t b_sn, int64_t ldc, int accumulate, void* stream) {
+    if (M < 0 || N < 0 || K < 0) return HPC_RLL_EINVAL;
+    if (M == 0 || N == 0) return HPC_RLL_OK;
+    if (!C || (K > 0 && (!A || !B))) return HPC_RLL_EINVAL;
+    GemmArgs g{A, B, C, M, N, K, (long)a_sm, (long)a_sk, (long)b_sk, (long)b_sn, (long)ldc, accumulate};
+    launch_gemm(g, (hipStream_t)stream);
+    return last_error();
+}

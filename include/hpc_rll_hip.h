@@ -209,6 +209,31 @@ int hpc_rll_scatter_connection_forward(const float* x, const int64_t* location, 
 int hpc_rll_scatter_connection_backward(const float* grad_out, const int64_t* location, float* grad_x, int B, int M,
                                         int N, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm-LSTM -- replaces LstmForward/LstmBackward (torch_utils/network/entry.h:11-19,
+ * src/torch_utils/network/lstm.cu:29-379).  x (S,B,I); h0,c0 (L,B,H); wx = concat_l row-major [in_l,4H]
+ * (in_0 = I, in_l = H); wh = L x [H,4H]; bias (L,4H); ln_gamma/ln_beta (L, 2*4H) = [x-half | h-half];
+ * gate order i,f,o,u.  Outputs y (S,B,H), hn,cn (L,B,H).  ws: hpc_rll_lstm_workspace_floats(...) floats,
+ * must be kept (unmodified) from forward to backward.  All GEMMs are exact fp32 on the matrix cores.
+ * dropout_p in [0,1): inter-layer dropout, mask = stateless hash of (seed, layer, element).
+ * backward: dy (S,B,H), dhn, dcn (L,B,H) may each be NULL (= zero).  Unlike the reference, gradients
+ * flowing in through hn / cn are honoured.
+ * ------------------------------------------------------------------------------------------ */
+int64_t hpc_rll_lstm_workspace_floats(int S, int B, int I, int H, int L, float dropout_p);
+int hpc_rll_lstm_forward(const float* x, const float* h0, const float* c0, const float* wx, const float* wh,
+                         const float* bias, const float* ln_gamma, const float* ln_beta, float* y, float* hn,
+                         float* cn, float* ws, int S, int B, int I, int H, int L, float dropout_p, uint64_t seed,
+                         void* stream);
+int hpc_rll_lstm_backward(const float* dy, const float* dhn, const float* dcn, const float* x, const float* h0,
+                          const float* c0, const float* wx, const float* wh, const float* ln_gamma, float* ws,
+                          float* dx, float* dh0, float* dc0, float* dwx, float* dwh, float* dbias, float* dln_gamma,
+                          float* dln_beta, int S, int B, int I, int H, int L, float dropout_p, uint64_t seed,
+                          void* stream);
+/* Exact-fp32 MFMA GEMM used by the LSTM, exposed for tests/benchmarks: C (M,N; row stride ldc) (+)= A * B with
+ * A(m,k) = A[m*a_sm + k*a_sk], B(k,n) = B[k*b_sk + n*b_sn]. */
+int hpc_rll_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_sm, int64_t a_sk,
+                     int64_t b_sk, int64_t b_sn, int64_t ldc, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
