@@ -13,6 +13,11 @@
 //   * forward emits only per-row scalars (log pi(a), entropy); backward RECOMPUTES the softmax from the
 //     logits instead of loading saved buffers:  forward writes 8 B/row instead of 12*N B/row.
 //
+//   * R rows are processed per group per iteration (independent reduction chains interleave, hiding the
+//     cross-lane latency), the 16-lane part of every butterfly is DPP (no LDS traffic), exp/log are the
+//     hardware v_exp_f32 / v_log_f32 forms: first version (1 row at a time, ds_bpermute butterflies, libm expf)
+//     was row-rate bound at 3.3 TB/s.
+//
 // Algorithmic HBM bytes: forward 4*N + 8 (+8 for the int64 action) per row; backward 4*N read + 4*N write.
 #include <hip/hip_runtime.h>
 
@@ -24,6 +29,22 @@ namespace {
 
 constexpr float kNegInf = -3.0e38f;
 
+// ---- all-reduce butterflies over aligned groups of G lanes: DPP inside a 16-lane row, ds_bpermute above it.
+template <int CTRL> __device__ __forceinline__ float dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+struct SumOp { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+struct MaxOp { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+template <int G, class Op> __device__ __forceinline__ float group_all(float x) {
+    if (G >= 2) x = Op::f(x, dpp<0xB1>(x));    // quad_perm [1,0,3,2]
+    if (G >= 4) x = Op::f(x, dpp<0x4E>(x));    // quad_perm [2,3,0,1]
+    if (G >= 8) x = Op::f(x, dpp<0x141>(x));   // row_half_mirror: lane i <-> 7-i
+    if (G >= 16) x = Op::f(x, dpp<0x140>(x));  // row_mirror: lane i <-> 15-i
+    if (G >= 32) x = Op::f(x, __shfl_xor(x, 16, 64));
+    if (G >= 64) x = Op::f(x, __shfl_xor(x, 32, 64));
+    return x;
+}
+
 // Per-lane slice of one row: E pieces of VEC consecutive floats, piece e at column (e*G + gl)*VEC.
 template <int G, int VEC, int E>
 struct RowSlice {
@@ -34,13 +55,14 @@ struct RowSlice {
             const int c = (e * G + gl) * VEC;
             if (VEC == 4) {
                 if (c < N) {
-                    const float4 t = *reinterpret_cast<const float4*>(row + c);
+                    // logits are read exactly once: nontemporal (streaming) load
+                    const vfloat4 t = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(row + c));
                     x[e * 4 + 0] = t.x; x[e * 4 + 1] = t.y; x[e * 4 + 2] = t.z; x[e * 4 + 3] = t.w;
                 } else {
                     x[e * 4 + 0] = x[e * 4 + 1] = x[e * 4 + 2] = x[e * 4 + 3] = kNegInf;
                 }
             } else {
-                x[e] = (c < N) ? row[c] : kNegInf;
+                x[e] = (c < N) ? __builtin_nontemporal_load(row + c) : kNegInf;
             }
         }
     }
@@ -53,7 +75,7 @@ __device__ __forceinline__ void row_stats(const RowSlice<G, VEC, E>& r, int N, i
     float m = kNegInf;
 #pragma unroll
     for (int i = 0; i < E * VEC; ++i) m = fmaxf(m, r.x[i]);
-    m = group_max<G>(m);
+    m = group_all<G, MaxOp>(m);
     float s = 0.f, xa = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e)
@@ -61,13 +83,13 @@ __device__ __forceinline__ void row_stats(const RowSlice<G, VEC, E>& r, int N, i
         for (int k = 0; k < VEC; ++k) {
             const int i = e * VEC + k;
             const int c = (e * G + gl) * VEC + k;
-            ex[i] = (c < N) ? expf(r.x[i] - m) : 0.f;
+            ex[i] = (c < N) ? __expf(r.x[i] - m) : 0.f;
             s += ex[i];
             xa += ((long)c == action) ? r.x[i] : 0.f;
         }
-    s = group_sum<G>(s);
-    xa = group_sum<G>(xa);
-    const float ls = logf(s);
+    s = group_all<G, SumOp>(s);
+    xa = group_all<G, SumOp>(xa);
+    const float ls = __logf(s);
     lse = m + ls;
     sum = s;
     logp_a = xa - lse;
@@ -82,26 +104,43 @@ __device__ __forceinline__ void row_stats(const RowSlice<G, VEC, E>& r, int N, i
             const int c = (e * G + gl) * VEC + k;
             if (c < N) h -= (ex[i] * inv) * (r.x[i] - lse);
         }
-    ent = group_sum<G>(h);
+    ent = group_all<G, SumOp>(h);
 }
+
+// R rows per group per iteration: R independent load + reduction chains in flight.
+template <int G, int VEC, int E> struct RowsPerIter { static constexpr int value = (E * VEC <= 4) ? 4 : ((E * VEC <= 8) ? 2 : 1); };
 
 template <int G, int VEC, int E>
 __global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* __restrict__ logits,
                                                               const int64_t* __restrict__ action,
                                                               float* __restrict__ logp_out,
                                                               float* __restrict__ ent_out, long rows, int N) {
-    constexpr int RPB = 256 / G;  // rows per block per sweep
+    constexpr int GPB = 256 / G;  // groups per block
+    constexpr int R = RowsPerIter<G, VEC, E>::value;
     const int gl = threadIdx.x % G;
     const int gi = threadIdx.x / G;
-    for (long row = (long)blockIdx.x * RPB + gi; row < rows; row += (long)gridDim.x * RPB) {
-        RowSlice<G, VEC, E> r;
-        r.load(logits + row * (long)N, N, gl);
-        const long a = action[row];
-        float ex[E * VEC], lse, sum, lp, h;
-        row_stats<G, VEC, E>(r, N, gl, a, ex, lse, sum, lp, h);
+    for (long base = ((long)blockIdx.x * GPB + gi) * R; base < rows; base += (long)gridDim.x * GPB * R) {
+        RowSlice<G, VEC, E> r[R];
+        long a[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const long row = (base + k < rows) ? base + k : rows - 1;   // clamp: uniform control flow, store is guarded
+            r[k].load(logits + row * (long)N, N, gl);
+            a[k] = action[row];
+        }
+        float lp[R], h[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            float ex[E * VEC], lse, sum;
+            row_stats<G, VEC, E>(r[k], N, gl, a[k], ex, lse, sum, lp[k], h[k]);
+        }
         if (gl == 0) {
-            logp_out[row] = lp;
-            if (ent_out) ent_out[row] = h;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (base + k < rows) {
+                    logp_out[base + k] = lp[k];
+                    if (ent_out) ent_out[base + k] = h[k];
+                }
         }
     }
 }
@@ -115,37 +154,49 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __res
                                                               const float* __restrict__ c2,
                                                               const float* __restrict__ g2,
                                                               float* __restrict__ grad, long rows, int N) {
-    constexpr int RPB = 256 / G;
+    constexpr int GPB = 256 / G;
+    constexpr int R = RowsPerIter<G, VEC, E>::value;
     const int gl = threadIdx.x % G;
     const int gi = threadIdx.x / G;
     const float u1 = g1 ? g1[0] : 1.f;
     const float u2 = (c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
-    for (long row = (long)blockIdx.x * RPB + gi; row < rows; row += (long)gridDim.x * RPB) {
-        RowSlice<G, VEC, E> r;
-        r.load(logits + row * (long)N, N, gl);
-        const long a = action[row];
-        const float k1 = u1 * c1[row];
-        const float k2 = (c2 != nullptr) ? u2 * c2[row] : 0.f;
-        float ex[E * VEC], lse, sum, lp, h;
-        row_stats<G, VEC, E>(r, N, gl, a, ex, lse, sum, lp, h);
-        const float inv = 1.f / sum;
-        float* __restrict__ out = grad + row * (long)N;
+    for (long base = ((long)blockIdx.x * GPB + gi) * R; base < rows; base += (long)gridDim.x * GPB * R) {
+        RowSlice<G, VEC, E> r[R];
+        long a[R];
+        float k1[R], k2[R];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int c0 = (e * G + gl) * VEC;
-            float o[VEC];
+        for (int k = 0; k < R; ++k) {
+            const long row = (base + k < rows) ? base + k : rows - 1;
+            r[k].load(logits + row * (long)N, N, gl);
+            a[k] = action[row];
+            k1[k] = u1 * c1[row];
+            k2[k] = (c2 != nullptr) ? u2 * c2[row] : 0.f;
+        }
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const int i = e * VEC + k;
-                const float p = ex[i] * inv;
-                const float onehot = ((long)(c0 + k) == a) ? 1.f : 0.f;
-                o[k] = k1 * (onehot - p) - k2 * p * ((r.x[i] - lse) + h);
-            }
-            if (c0 < N) {
-                if (VEC == 4) {
-                    *reinterpret_cast<float4*>(out + c0) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-                    out[c0] = o[0];
+        for (int k = 0; k < R; ++k) {
+            float ex[E * VEC], lse, sum, lp, h;
+            row_stats<G, VEC, E>(r[k], N, gl, a[k], ex, lse, sum, lp, h);
+            if (base + k >= rows) continue;
+            const float inv = 1.f / sum;
+            float* __restrict__ out = grad + (base + k) * (long)N;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int c0 = (e * G + gl) * VEC;
+                float o[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const int i = e * VEC + q;
+                    const float p = ex[i] * inv;
+                    const float onehot = ((long)(c0 + q) == a[k]) ? 1.f : 0.f;
+                    o[q] = k1[k] * (onehot - p) - k2[k] * p * ((r[k].x[i] - lse) + h);
+                }
+                if (c0 < N) {
+                    if (VEC == 4) {
+                        vfloat4 t; t.x = o[0]; t.y = o[1]; t.z = o[2]; t.w = o[3];
+                        __builtin_nontemporal_store(t, reinterpret_cast<vfloat4*>(out + c0));
+                    } else {
+                        __builtin_nontemporal_store(o[0], out + c0);
+                    }
                 }
             }
         }
@@ -220,9 +271,12 @@ __global__ __launch_bounds__(256) void categorical_bwd_long_kernel(const float* 
     }
 }
 
+}  // namespace
+int g_blocks_per_cu = 12;  // tuning knob (hpc_rll_tune_set key 0); 12 measured best at the C3 shape
+namespace {  // tuning knob (hpc_rll_tune_set key 0)
 inline unsigned grid_for(long rows, int rows_per_block) {
     long g = (rows + rows_per_block - 1) / rows_per_block;
-    const long cap = 256L * 8;  // 256 CUs x 8 blocks of 256 threads
+    const long cap = 256L * g_blocks_per_cu;  // 256 CUs x resident blocks of 256 threads
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (unsigned)g;
@@ -244,7 +298,8 @@ inline RowCfg row_cfg(int N, bool can_vec4) {
 
 #define HPC_RLL_ROW_CASE(G_, V_, E_, KERNEL, ...)                                                         \
     if (cfg.g == G_ && cfg.vec == V_ && cfg.e == E_) {                                                    \
-        hipLaunchKernelGGL((KERNEL<G_, V_, E_>), dim3(grid_for(rows, 256 / G_)), dim3(256), 0, st,        \
+        hipLaunchKernelGGL((KERNEL<G_, V_, E_>),                                                           \
+                           dim3(grid_for(rows, (256 / G_) * RowsPerIter<G_, V_, E_>::value)), dim3(256), 0, st, \
                            __VA_ARGS__);                                                                  \
         return true;                                                                                      \
     }
@@ -304,6 +359,11 @@ int categorical_backward(const float* logits, const int64_t* action, const float
 }
 
 }  // namespace hpc_rll
+
+extern "C" int hpc_rll_tune_set(int key, int value) {
+    if (key == 0 && value >= 1 && value <= 64) { hpc_rll::g_blocks_per_cu = value; return HPC_RLL_OK; }
+    return HPC_RLL_EINVAL;
+}
 
 extern "C" int hpc_rll_categorical_forward(const float* logits, const int64_t* action, float* logp, float* entropy,
                                            int64_t rows, int N, void* stream) {

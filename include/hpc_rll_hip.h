@@ -88,6 +88,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
                                  const float* g_logp, const float* coef_ent, const float* g_ent,
                                  float* grad_logits, int64_t rows, int N, void* stream);
 
+/* Tuning knob for experiments (key 0: resident 256-thread blocks per CU targeted by the row kernels, 1..64). */
+int hpc_rll_tune_set(int key, int value);
+
 /* TD(lambda) -- replaces TdLambdaForward/Backward (rl_utils/entry.h:68-77, src/rl_utils/td_lambda.cu:8-52).
  * value (T+1,B), reward (T,B), weight: mode 0 none, 1 (B,), 2 (T,B).  loss (1,) =
  * 0.5*scale*sum w (ret-V)^2; grad_buf (T,B) = d loss / d value[:T]; partials >= partials_floats(B).

@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Suite benchmark at the BASELINE.json configs[2..4] shapes (plus the reference test shapes): per-op forward /
+backward time (HIP events on the launch stream, median of interleaved repeats) against the algorithmic-bytes or
+flop roofline.  Not the headline bench (bench.py); these are the numbers DESIGN.md quotes.
+Writes gpurun_out/suite_<tag>.json and .txt.   Usage: bench_suite.py [c3|c4|c5|small|all]"""
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+import torch  # noqa: E402
+
+dev = torch.device("cuda:0")
+HBM, MFMA_F32 = 8000.0, 157.3   # GB/s, TFLOP/s (MI355X_MICROARCH.md)
+rows = []
+
+
+def timed(fn, n=5, rounds=3):
+    fn()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) / n * 1e-3)
+    return statistics.median(ts)
+
+
+def report(name, shape, t_f, bytes_f, t_b=None, bytes_b=None, flops_f=None, flops_b=None):
+    r = dict(op=name, shape=shape, fwd_ms=t_f * 1e3)
+    if flops_f:
+        r.update(fwd_tflops=flops_f / t_f / 1e12, fwd_frac=flops_f / t_f / 1e12 / MFMA_F32, bound="mfma")
+    else:
+        r.update(fwd_gbs=bytes_f / t_f / 1e9, fwd_frac=bytes_f / t_f / 1e9 / HBM, bound="hbm")
+    if t_b is not None:
+        r.update(bwd_ms=t_b * 1e3)
+        if flops_b:
+            r.update(bwd_tflops=flops_b / t_b / 1e12, bwd_frac=flops_b / t_b / 1e12 / MFMA_F32)
+        else:
+            r.update(bwd_gbs=bytes_b / t_b / 1e9, bwd_frac=bytes_b / t_b / 1e9 / HBM)
+    rows.append(r)
+    print(json.dumps(r), flush=True)
+
+
+def fwd_bwd(make_loss, grads_of):
+    """time forward alone and backward alone (retain_graph) of a closure returning a scalar-ish loss"""
+    loss = make_loss()
+    t_f = timed(make_loss)
+    loss = make_loss()
+    g = torch.ones_like(loss)
+
+    def bwd():
+        for p in grads_of:
+            p.grad = None
+        loss.backward(g, retain_graph=True)
+
+    t_b = timed(bwd)
+    return t_f, t_b
+
+
+def suite_c3(T=256, B=16384, N=128):
+    from hpc_rll.rl_utils.td import TDLambda
+    from hpc_rll.rl_utils.upgo import UPGO
+    from hpc_rll.rl_utils.vtrace import VTrace
+    g = torch.Generator(device=dev).manual_seed(0)
+    TB = T * B
+    value = torch.randn(T + 1, B, device=dev, generator=g, requires_grad=True)
+    reward = torch.randn(T, B, device=dev, generator=g)
+    weight = torch.rand(T, B, device=dev, generator=g)
+    target = torch.randn(T, B, N, device=dev, generator=g, requires_grad=True)
+    behaviour = torch.randn(T, B, N, device=dev, generator=g)
+    action = torch.randint(0, N, (T, B), device=dev, generator=g)
+    rho = torch.rand(T, B, device=dev, generator=g)
+    shape = f"T={T} B={B} N={N}"
+    m = TDLambda(T, B)
+    t_f, t_b = fwd_bwd(lambda: m(value, reward, weight), [value])
+    report("td_lambda", shape, t_f, 16 * TB, t_b, 8 * TB)
+    m = VTrace(T, B, N)
+    t_f, t_b = fwd_bwd(lambda: sum(m(target, behaviour, action, value, reward)), [target, value])
+    # algorithmic minimum: two logits reads (+ action + O(TB)) forward; logits read + grad write backward
+    report("vtrace", shape, t_f, 2 * 4 * TB * N + 8 * TB + 12 * TB, t_b, 2 * 4 * TB * N + 8 * TB)
+    m = UPGO(T, B, N)
+    t_f, t_b = fwd_bwd(lambda: m(target, rho, action, reward, value.detach()), [target])
+    report("upgo", shape, t_f, 4 * TB * N + 8 * TB + 16 * TB, t_b, 2 * 4 * TB * N + 8 * TB)
+
+
+def suite_ppo(B=65536, N=128):
+    from hpc_rll.rl_utils.ppo import PPO
+    g = torch.Generator(device=dev).manual_seed(0)
+    ln = torch.randn(B, N, device=dev, generator=g, requires_grad=True)
+    lo = torch.randn(B, N, device=dev, generator=g)
+    a = torch.randint(0, N, (B,), device=dev, generator=g)
+    vn = torch.randn(B, device=dev, generator=g, requires_grad=True)
+    vo, adv, ret = (torch.randn(B, device=dev, generator=g) for _ in range(3))
+    import hpc_rl_utils as U
+    out5, ws = torch.empty(5, device=dev), U.ppo_workspace(B, dev)
+    t_f = timed(lambda: U.PPOForward([ln.detach(), lo, a, vn.detach(), vo, adv, ret, None], [out5, ws], True, 0.2, 0.0))
+    g1 = torch.ones(1, device=dev)
+    gl, gv = torch.empty(B, N, device=dev), torch.empty(B, device=dev)
+    t_b = timed(lambda: U.PPOBackward([g1, g1, g1, ln.detach(), a, ws], [gl, gv]))
+    report("ppo", f"B={B} N={N}", t_f, 2 * 4 * B * N + 8 * B + 20 * B, t_b, 2 * 4 * B * N + 8 * B)
+
+
+def suite_c4(S=128, B=4096, I=1024, H=1024, L=1):
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(0)
+    m = LSTM(S, B, I, H, L).to(dev)
+    x = torch.randn(S, B, I, device=dev, requires_grad=True)
+    h0 = torch.randn(L, B, H, device=dev)
+    c0 = torch.randn(L, B, H, device=dev)
+    flops_f = 2.0 * S * B * 4 * H * (I + H) * L          # x-branch + recurrent GEMM
+    flops_b = 2.0 * flops_f                               # dX/dH and dW GEMMs
+    y, _ = m(x, (h0, c0))
+    t_f = timed(lambda: m(x, (h0, c0)), n=2, rounds=3)
+    g = torch.ones_like(y)
+
+    def bwd():
+        x.grad = None
+        for p in m.parameters():
+            p.grad = None
+        y.backward(g, retain_graph=True)
+
+    t_b = timed(bwd, n=2, rounds=3)
+    report("lstm", f"S={S} B={B} I={I} H={H} L={L}", t_f, None, t_b, None, flops_f, flops_b)
+
+
+def suite_gemm():
+    import hpc_torch_utils_network as U
+    for (M, N, K) in [(4096, 4096, 4096), (4096, 4096, 1024), (524288, 4096, 1024)]:
+        a = torch.randn(M, K, device=dev)
+        b = torch.randn(K, N, device=dev)
+        c = torch.empty(M, N, device=dev)
+        t = timed(lambda: U.gemm_f32(a, b, out=c), n=3)
+        report("gemm_f32_nn", f"M={M} N={N} K={K}", t, None, flops_f=2.0 * M * N * K)
+        del a, b, c
+
+
+def suite_c5(B=4096, M=256, N=64, H=64, W=64):
+    from hpc_rll.torch_utils.network.scatter_connection import ScatterConnection
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(B, M, N, device=dev, generator=g, requires_grad=True)
+    loc = torch.stack([torch.randint(0, H, (B, M), device=dev, generator=g),
+                       torch.randint(0, W, (B, M), device=dev, generator=g)], -1)
+    for st in ("cover", "add"):
+        m = ScatterConnection(B, M, N, H, W, st)
+        out = m(x, loc)
+        t_f = timed(lambda: m(x, loc), n=3)
+        go = torch.randn_like(out)
+
+        def bwd():
+            x.grad = None
+            out.backward(go, retain_graph=True)
+
+        t_b = timed(bwd, n=3)
+        by_f = 4 * B * M * N + 16 * B * M + 4 * B * N * H * W
+        # backward: the gather touches essentially every 64-B sector of grad_out at this density
+        report(f"scatter_{st}", f"B={B} M={M} N={N} H={H} W={W}", t_f, by_f, t_b, 4 * B * N * H * W + 4 * B * M * N)
+        del out, go
+    # Pad1D / Unpad1D over n ragged tensors (views of one buffer), len ~ U[32,128)
+    from hpc_rll.rl_utils import padding as P
+    import numpy as np
+    n = 1 << 17
+    lens = np.random.default_rng(0).integers(32, 128, n)
+    flat = torch.randn(int(lens.sum()), device=dev)
+    xs = list(torch.split(flat, [int(v) for v in lens]))
+    new_x, mask, shapes = P.Padding1D(xs)
+    import hpc_rl_utils as U
+    table = U._device_table([[t.data_ptr(), 1, 1, t.shape[0]] for t in xs], dev)
+    mx = int(lens.max())
+    t_k = timed(lambda: U.N.call("hpc_rll_pad_forward", dev, table.data_ptr(), new_x.data_ptr(), mask.data_ptr(), n, 1, 1, mx, 0), n=5)
+    report("pad1d_kernel", f"n={n} len~U[32,128)", t_k, 4 * int(lens.sum()) + 8 * n * mx)
+    t_api = timed(lambda: P.Padding1D(xs), n=1, rounds=2)
+    rows.append(dict(op="pad1d_python_api", shape=f"n={n}", fwd_ms=t_api * 1e3, note="list-of-tensors API incl. host table build"))
+    print(json.dumps(rows[-1]), flush=True)
+
+
+def suite_small():
+    """reference test shapes: launch-latency regime"""
+    from hpc_rll.rl_utils.gae import GAE
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    T, B = 1024, 64
+    v = torch.randn(T + 1, B, device=dev, requires_grad=True)
+    r = torch.randn(T, B, device=dev)
+    m = GAE(T, B)
+    t_f, t_b = fwd_bwd(lambda: m(v, r), [v])
+    report("gae_small", f"T={T} B={B}", t_f, 12 * T * B, t_b, 12 * T * B)
+    S, B, I, H, L = 64, 3, 1792, 384, 3
+    m = LSTM(S, B, I, H, L).to(dev)
+    x = torch.randn(S, B, I, device=dev, requires_grad=True)
+    y, _ = m(x, None)
+    t_f = timed(lambda: m(x, None), n=2)
+    g = torch.ones_like(y)
+
+    def bwd():
+        x.grad = None
+        y.backward(g, retain_graph=True)
+
+    t_b = timed(bwd, n=2)
+    fl = 2.0 * S * B * 4 * H * ((I + H) + 2 * (H + H))
+    report("lstm_small", f"S={S} B={B} I={I} H={H} L={L}", t_f, None, t_b, None, fl, 2 * fl)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("c3", "all"):
+        suite_c3()
+        suite_ppo()
+    if which in ("gemm", "all"):
+        suite_gemm()
+    if which in ("c4", "all"):
+        suite_c4()
+    if which in ("c5", "all"):
+        suite_c5()
+    if which in ("small", "all"):
+        suite_small()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", f"suite_{which}.json"), "w"), indent=1)
