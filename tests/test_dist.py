@@ -1,0 +1,157 @@
+"""Batch-axis data parallelism: per-rank sums scaled by 1/(global count) + ONE all-reduce of the loss
+scalars reproduce the single-process result; gradients of a shard equal the corresponding rows of the full
+gradient; GAE needs no collective.
+
+CPU tier (gloo, world_size 2): the host logic in hpc_rll.dist with the ORACLE as the per-rank op.
+GPU tier (2 processes sharing cuda:0, gloo backend on device tensors): the real HIP kernels through the drop-in
+modules with ``sharded=True`` (the driver's 8-GPU runs use the same code with backend "nccl" = RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, rel_err
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _data(seed, T, B, N):
+    rng = np.random.default_rng(seed)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    return dict(value=f(T + 1, B), reward=f(T, B), weight=rng.random((T, B)).astype(np.float32), target=f(T, B, N),
+                behaviour=f(T, B, N), action=rng.integers(0, N, (T, B)).astype(np.int64))
+
+
+# ------------------------------------------------------------------------------------------------ CPU / oracle
+def _cpu_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+    from hpc_rll import dist as D
+    from oracle import ref_torch as R
+    _init(rank, world, port)
+    T, B, N = 12, 10, 5
+    d = {k: torch.from_numpy(v) for k, v in _data(3, T, B, N).items()}
+    sh = {k: D.shard_batch(v, 1, rank, world) for k, v in d.items()}
+    # TD-lambda: local mean * (local/global count) == local sum * global scale
+    v = sh["value"].double().requires_grad_(True)
+    local = R.td_lambda_error(v, sh["reward"].double(), sh["weight"].double(), 0.9, 0.8)
+    scale = D.loss_scale(T * (B // world), None, sharded=True)
+    contrib = (local * (T * (B // world)) * scale).reshape(1)
+    contrib.backward()
+    loss = D.all_reduce_losses_(contrib.detach().clone(), None, sharded=True)
+    # V-trace: three scalars in one all-reduce
+    to = sh["target"].double().requires_grad_(True)
+    ls = R.vtrace_error(to, sh["behaviour"].double(), sh["action"], sh["value"].double(), sh["reward"].double(), None)
+    three = torch.stack([x.detach() for x in ls]) * (T * (B // world)) * scale
+    D.all_reduce_losses_(three, None, sharded=True)
+    # PPO-style info slots are means: averaged, not summed
+    info = torch.tensor([1.0, 2.0, 3.0, float(rank), float(rank) * 2])
+    D.all_reduce_losses_(info, None, sharded=True, mean_slots=(3, 4))
+    q.put((rank, loss.item(), v.grad.numpy(), three.numpy(), info.numpy()))
+    dist.destroy_process_group()
+
+
+def test_cpu_gloo_two_ranks_match_single_process():
+    from oracle import ref_torch as R
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_cpu_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    T, B, N = 12, 10, 5
+    d = {k: torch.from_numpy(v) for k, v in _data(3, T, B, N).items()}
+    v = d["value"].double().requires_grad_(True)
+    full = R.td_lambda_error(v, d["reward"].double(), d["weight"].double(), 0.9, 0.8)
+    full.backward()
+    ls = R.vtrace_error(d["target"].double(), d["behaviour"].double(), d["action"], d["value"].double(), d["reward"].double(), None)
+    for rank, loss, gshard, three, info in res:
+        assert abs(loss - full.item()) < 1e-12
+        k = B // world
+        assert np.allclose(gshard, v.grad.numpy()[:, rank * k:(rank + 1) * k], atol=1e-14)
+        assert np.allclose(three, [x.item() for x in ls], atol=1e-12)
+        assert np.allclose(info, [2.0, 4.0, 6.0, 0.5, 1.0])
+
+
+def test_shard_and_scale_helpers():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+    from hpc_rll import dist as D
+    x = torch.arange(24).reshape(2, 12)
+    assert torch.equal(D.shard_batch(x, 1, 1, 3), x[:, 4:8])
+    assert D.shard_batch(None, 1, 0, 2) is None
+    assert D.loss_scale(10) == 0.1 and D.world_size() == 1
+    t = torch.ones(3)
+    assert D.all_reduce_losses_(t, None, sharded=False) is t
+
+
+# ------------------------------------------------------------------------------------------------ GPU / HIP kernels
+def _gpu_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+    from hpc_rll import dist as D
+    from hpc_rll.rl_utils.gae import GAE
+    from hpc_rll.rl_utils.td import TDLambda
+    from hpc_rll.rl_utils.vtrace import VTrace
+    _init(rank, world, port)
+    dev = torch.device("cuda:0")
+    T, B, N = 40, 256, 12
+    d = {k: torch.from_numpy(v) for k, v in _data(4, T, B, N).items()}
+    sh = {k: D.shard_batch(v, 1, rank, world).to(dev) for k, v in d.items()}
+    v = sh["value"].clone().requires_grad_(True)
+    to = sh["target"].clone().requires_grad_(True)
+    l1 = TDLambda(T, B // world, sharded=True)(v, sh["reward"], sh["weight"])
+    l3 = VTrace(T, B // world, N, sharded=True)(to, sh["behaviour"], sh["action"], v, sh["reward"])
+    (l1 + sum(l3)).sum().backward()
+    adv = GAE(T, B // world)(sh["value"], sh["reward"])          # no collective
+    q.put((rank, l1.item(), [x.item() for x in l3], v.grad.cpu().numpy(), to.grad.cpu().numpy(), adv.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gpu_two_ranks_match_single_process():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+    from hpc_rll.rl_utils.gae import GAE
+    from hpc_rll.rl_utils.td import TDLambda
+    from hpc_rll.rl_utils.vtrace import VTrace
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    dev = torch.device("cuda:0")
+    T, B, N = 40, 256, 12
+    d = {k: torch.from_numpy(v).to(dev) for k, v in _data(4, T, B, N).items()}
+    v = d["value"].clone().requires_grad_(True)
+    to = d["target"].clone().requires_grad_(True)
+    l1 = TDLambda(T, B)(v, d["reward"], d["weight"])
+    l3 = VTrace(T, B, N)(to, d["behaviour"], d["action"], v, d["reward"])
+    (l1 + sum(l3)).sum().backward()
+    adv = GAE(T, B)(d["value"], d["reward"]).cpu().numpy()
+    k = B // world
+    for rank, r1, r3, gv, gt, radv in res:
+        assert rel_err(l1.item(), r1) < 1e-6
+        assert rel_err([x.item() for x in l3], r3) < 1e-6
+        assert rel_err(v.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gv) < 1e-6
+        assert rel_err(to.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gt) < 1e-6
+        assert np.array_equal(adv[:, rank * k:(rank + 1) * k], radv)     # GAE columns are independent: bit equal
