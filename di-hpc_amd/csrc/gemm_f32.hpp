@@ -5,24 +5,30 @@
 // results are plain fp32 matmul results at the 157 TFLOP/s matrix rate.
 //
 //   C (M x N, row stride ldc) (+)= A (M x K) * B (K x N)
-// with arbitrary element strides for A and B, so the three layouts the LSTM needs are one kernel:
+// with arbitrary element strides for A and B, so the three layouts the LSTM needs are one kernel family:
 //   NN  x @ W          A(m,k) = A[m*lda + k]   B(k,n) = B[k*ldb + n]
 //   NT  dY @ W^T       A(m,k) = A[m*lda + k]   B(k,n) = W[n*ldb + k]
 //   TN  X^T @ dY       A(m,k) = X[k*lda + m]   B(k,n) = B[k*ldb + n]
 //
-// Tiling: workgroup = 4 waves (2 x 2), block tile 128 x 128 x 16; each wave owns a 64 x 64 quadrant as 2 x 2
-// MFMA blocks of 32 x 32 (4 x f32x16 accumulators).  Operand tiles are staged in LDS k-major
-// (As[k][m], Bs[k][n]) so the MFMA operand fetch  a = As[k0 + (lane>>5)][m0 + (lane&31)]  is a conflict-free
-// ds_read_b32 (the two 32-lane halves are separate LDS lane groups).  The next tile's global loads are issued
-// into registers before the current tile's MFMAs and written to the other LDS buffer afterwards (register
-// prefetch + LDS double buffer, one barrier per k-tile).  A skinny variant (BM = 32, tile 32 x 256) serves the
-// per-timestep recurrent GEMM when the batch is small.
+// Tiling: workgroup = 4 waves, block tile BM x BN x 32; each wave owns WM x WN MFMA blocks of 32 x 32.
+// Operand tiles live in LDS k-major (As[k][m], Bs[k][n]) so the MFMA operand fetch
+//     a = As[k0 + (lane>>5)][m0 + (lane&31)]
+// is a conflict-free ds_read_b32 (the two 32-lane halves are separate LDS lane groups).  Staging per operand:
+//   * contiguous along m/n : float4 global loads along m, one ds_write_b128 each;
+//   * contiguous along k   : four float4 loads along k from four consecutive rows, a 4x4 register transpose, four
+//     ds_write_b128 along m;
+//   * anything else        : guarded scalar loads (odd sizes / unaligned pointers).
+// The 16-byte slots of a k-row are XOR-swizzled with (k>>2)&7 so that both the b128 writes (8 lanes = 8 different
+// k-rows or 8 consecutive slots) and the b32 reads (32 consecutive m) are bank-conflict free without padding.
+// The next tile's global loads are issued into registers before the current tile's MFMAs and written to the other
+// LDS buffer afterwards (register prefetch + LDS double buffer, one barrier per k-tile).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace hpc_rll {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float gf4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -33,66 +39,113 @@ struct GemmArgs {
     int accumulate;    // C += A*B instead of C = A*B
 };
 
-// BM x BN block tile, BK = 16, 256 threads.  WM x WN = MFMA blocks per wave; waves arranged (BM/(32*WM)) x (BN/(32*WN)).
-template <int BM, int BN, int WM, int WN>
+enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2 };
+
+constexpr int kGemmBK = 32;
+
+// LDS address (in floats) of element (k, x) of a k-major tile with X columns (X % 32 == 0).
+template <int X> __device__ __forceinline__ int lds_idx(int k, int x) {
+    return k * X + ((((x >> 2) ^ ((k >> 2) & 7)) << 2) | (x & 3));
+}
+
+// Stages one operand tile (X rows-of-the-operand by 32 k) through registers.
+//   MODE kContigMN: element (x,k) at base[x + k*sk]        (unit stride along x)
+//   MODE kContigK : element (x,k) at base[x*sx + k]        (unit stride along k)
+//   MODE kGeneric : element (x,k) at base[x*sx + k*sk], fully guarded
+template <int X, int MODE>
+struct TileStage {
+    static constexpr int NV = X * kGemmBK / (256 * 4);   // float4 per thread (contiguous along m/n)
+    static constexpr int NB = (2 * X + 255) / 256;       // 4x4 blocks per thread (contiguous along k); 2X blocks in all
+    static constexpr int NS = X * kGemmBK / 256;         // scalars per thread (generic)
+    gf4 v[MODE == kGeneric ? 1 : (MODE == kContigK ? NB * 4 : NV)];
+    float s[MODE == kGeneric ? NS : 1];
+
+    __device__ __forceinline__ void load(const float* __restrict__ base, long sx, long sk, int x0, int k0, int XD,
+                                         int KD) {
+        const int tid = threadIdx.x;
+        if (MODE == kContigMN) {
+            // thread -> (k = e / (X/4), xq = (e % (X/4))*4), e = tid + i*256
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = tid + i * 256;
+                const int k = k0 + e / (X / 4), x = x0 + (e % (X / 4)) * 4;
+                gf4 t = {0.f, 0.f, 0.f, 0.f};
+                if (k < KD && x < XD) t = *reinterpret_cast<const gf4*>(base + (long)k * sk + x);
+                v[i] = t;
+            }
+        } else if (MODE == kContigK) {
+            // thread -> 4x4 block: rows x = 4*(e / 8) .. +3, k = (e % 8)*4 .. +3 ; 2X blocks, NB per thread
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = tid + i * 256;
+                if (e >= 2 * X) break;
+                const int xr = x0 + 4 * (e / 8), k = k0 + (e % 8) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int x = xr + r;
+                    x = x < XD ? x : XD - 1;   // clamp: rows beyond the edge are never stored to C
+                    gf4 t = {0.f, 0.f, 0.f, 0.f};
+                    if (k < KD) t = *reinterpret_cast<const gf4*>(base + (long)x * sx + k);
+                    v[i * 4 + r] = t;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = tid + i * 256;
+                const int k = k0 + e / X, x = x0 + e % X;
+                s[i] = (k < KD && x < XD) ? base[(long)x * sx + (long)k * sk] : 0.f;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ tile) const {
+        const int tid = threadIdx.x;
+        if (MODE == kContigMN) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = tid + i * 256;
+                *reinterpret_cast<gf4*>(tile + lds_idx<X>(e / (X / 4), (e % (X / 4)) * 4)) = v[i];
+            }
+        } else if (MODE == kContigK) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = tid + i * 256;
+                if (e >= 2 * X) break;
+                const int xr = 4 * (e / 8), k = (e % 8) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gf4 t = {v[i * 4 + 0][j], v[i * 4 + 1][j], v[i * 4 + 2][j], v[i * 4 + 3][j]};
+                    *reinterpret_cast<gf4*>(tile + lds_idx<X>(k + j, xr)) = t;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = tid + i * 256;
+                tile[lds_idx<X>(e / X, e % X)] = s[i];
+            }
+        }
+    }
+};
+
+// BM x BN block tile, BK = 32, 256 threads.  WM x WN = MFMA blocks per wave; waves arranged (BM/(32*WM)) x (BN/(32*WN)).
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-    constexpr int BK = 16;
+    constexpr int BK = kGemmBK;
     constexpr int WAVES_M = BM / (32 * WM);
     static_assert(WAVES_M * (BN / (32 * WN)) == 4, "4 waves per workgroup");
-    constexpr int LDA = BM + 4, LDB = BN + 4;
-    __shared__ float lds[2 * BK * LDA + 2 * BK * LDB];
-    float* const As = lds;                       // [buf][BK][LDA]
-    float* const Bs = lds + 2 * BK * LDA;        // [buf][BK][LDB]
+    __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
+    float* const As = lds;                 // [buf][BK*BM]
+    float* const Bs = lds + 2 * BK * BM;   // [buf][BK*BN]
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    // ---- global -> register staging.  Element e of the A tile is (row = e % BM, k = e / BM) when A is contiguous
-    // along m, (row = e / BK, k = e % BK) when contiguous along k; each thread owns AE = BM*BK/256 elements.
-    constexpr int AE = BM * BK / 256, BE = BN * BK / 256;
-    const bool a_mc = (g.a_sm == 1);   // contiguous along m (TN)
-    const bool b_nc = (g.b_sn == 1);   // contiguous along n (NN, TN)
-    float ra[AE], rb[BE];
-
-    auto load_a = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < AE; ++i) {
-            const int e = tid + i * 256;
-            const int row = a_mc ? (e % BM) : (e / BK);
-            const int kk = a_mc ? (e / BM) : (e % BK);
-            const int m = m0 + row, k = k0 + kk;
-            ra[i] = (m < g.M && k < g.K) ? g.A[(long)m * g.a_sm + (long)k * g.a_sk] : 0.f;
-        }
-    };
-    auto load_b = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < BE; ++i) {
-            const int e = tid + i * 256;
-            const int col = b_nc ? (e % BN) : (e / BK);
-            const int kk = b_nc ? (e / BN) : (e % BK);
-            const int n = n0 + col, k = k0 + kk;
-            rb[i] = (n < g.N && k < g.K) ? g.B[(long)k * g.b_sk + (long)n * g.b_sn] : 0.f;
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AE; ++i) {
-            const int e = tid + i * 256;
-            const int row = a_mc ? (e % BM) : (e / BK);
-            const int kk = a_mc ? (e / BM) : (e % BK);
-            As[(buf * BK + kk) * LDA + row] = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < BE; ++i) {
-            const int e = tid + i * 256;
-            const int col = b_nc ? (e % BN) : (e / BK);
-            const int kk = b_nc ? (e / BN) : (e % BK);
-            Bs[(buf * BK + kk) * LDB + col] = rb[i];
-        }
-    };
+    TileStage<BM, AMODE> sa;
+    TileStage<BN, BMODE> sb;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -103,30 +156,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int ktiles = (g.K + BK - 1) / BK;
-    load_a(0);
-    load_b(0);
-    store_tiles(0);
+    sa.load(g.A, g.a_sm, g.a_sk, m0, 0, g.M, g.K);
+    sb.load(g.B, g.b_sn, g.b_sk, n0, 0, g.N, g.K);
+    sa.store(As);
+    sb.store(Bs);
     __syncthreads();
+    const int am = wm * 32 * WM + (lane & 31);
+    const int bn = wn * 32 * WN + (lane & 31);
     for (int kt = 0; kt < ktiles; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < ktiles) { load_a((kt + 1) * BK); load_b((kt + 1) * BK); }
-        const float* __restrict__ as = As + buf * BK * LDA + wm * 32 * WM + (lane & 31);
-        const float* __restrict__ bs = Bs + buf * BK * LDB + wn * 32 * WN + (lane & 31);
+        if (kt + 1 < ktiles) {
+            sa.load(g.A, g.a_sm, g.a_sk, m0, (kt + 1) * BK, g.M, g.K);
+            sb.load(g.B, g.b_sn, g.b_sk, n0, (kt + 1) * BK, g.N, g.K);
+        }
+        const float* __restrict__ as = As + buf * BK * BM;
+        const float* __restrict__ bs = Bs + buf * BK * BN;
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 2) {
             const int kr = ks + (lane >> 5);
             float a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = as[kr * LDA + i * 32];
+            for (int i = 0; i < WM; ++i) a[i] = as[lds_idx<BM>(kr, am + i * 32)];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = bs[kr * LDB + j * 32];
+            for (int j = 0; j < WN; ++j) b[j] = bs[lds_idx<BN>(kr, bn + j * 32)];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < ktiles) store_tiles(buf ^ 1);
+        if (kt + 1 < ktiles) {
+            sa.store(As + (buf ^ 1) * BK * BM);
+            sb.store(Bs + (buf ^ 1) * BK * BN);
+        }
         __syncthreads();
     }
 
@@ -147,15 +209,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         }
 }
 
+inline bool gemm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Staging mode an operand admits.  x = the operand's non-k axis (m for A, n for B).
+inline int gemm_mode(const float* p, long sx, long sk, int XD, int KD) {
+    if (sx == 1 && (sk % 4) == 0 && (XD % 4) == 0 && gemm_al16(p)) return kContigMN;
+    if (sk == 1 && (sx % 4) == 0 && (KD % 4) == 0 && gemm_al16(p)) return kContigK;
+    return kGeneric;
+}
+
+template <int BM, int BN, int WM, int WN>
+inline void launch_gemm_tile(const GemmArgs& g, int am, int bm, hipStream_t st) {
+    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+#define HPC_RLL_GEMM_CASE(AM, BMD)                                                                          \
+    if (am == AM && bm == BMD) {                                                                            \
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, AM, BMD>), grid, dim3(256), 0, st, g);          \
+        return;                                                                                             \
+    }
+    HPC_RLL_GEMM_CASE(kContigK, kContigMN)    // NN
+    HPC_RLL_GEMM_CASE(kContigK, kContigK)     // NT
+    HPC_RLL_GEMM_CASE(kContigMN, kContigMN)   // TN
+#undef HPC_RLL_GEMM_CASE
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, kGeneric, kGeneric>), grid, dim3(256), 0, st, g);
+}
+
 inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return;
-    if (g.M <= 32) {   // skinny: 32 x 256 tile, waves side by side along N
-        const dim3 grid((g.N + 255) / 256, (g.M + 31) / 32);
-        hipLaunchKernelGGL((gemm_f32_kernel<32, 256, 1, 2>), grid, dim3(256), 0, st, g);
-    } else {
-        const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128);
-        hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g);
-    }
+    const int am = gemm_mode(g.A, g.a_sm, g.a_sk, g.M, g.K);
+    const int bm = gemm_mode(g.B, g.b_sn, g.b_sk, g.N, g.K);
+    // Enough workgroups to keep >= 2 resident per CU (256 CUs): a lone 128x128 workgroup per CU cannot overlap its
+    // own staging with its MFMAs.
+    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const long t64 = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
+    if (g.M <= 32) launch_gemm_tile<32, 128, 1, 1>(g, am, bm, st);   // skinny: the 4 waves side by side along N
+    else if (t128 >= 512) launch_gemm_tile<128, 128, 2, 2>(g, am, bm, st);
+    else if (t64 >= 512 || g.M > 64) launch_gemm_tile<128, 64, 2, 1>(g, am, bm, st);
+    else launch_gemm_tile<64, 64, 1, 1>(g, am, bm, st);
 }
 
 }  // namespace hpc_rll

@@ -182,20 +182,24 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
 
 // ------------------------------------------------------------------------------------------------ column reductions
 // dbias[col] = sum_rows dgate ; dbeta (both halves) = the same sum ; dgamma_x[col] = sum dgate * xhat_x ; dgamma_h
-// likewise.  One workgroup per 64 columns: 4 waves stride over the rows, lanes over columns (coalesced), fixed
-// summation order (deterministic).
+// likewise.  Two deterministic stages: grid (column tiles of 64, row chunks) -> partials[chunk][3][G], then one
+// pass over the chunks in a fixed order.  (A single stage with one workgroup per 64 columns walked 26 GB through
+// 64 workgroups: 61 ms at the C4 shape.)
+constexpr int kColChunks = 128;
 __global__ __launch_bounds__(256) void lstm_colreduce_kernel(const float* __restrict__ dgate,
                                                              const float* __restrict__ xw,
                                                              const float* __restrict__ hw,
                                                              const float* __restrict__ stats, long rows, int G,
-                                                             float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta) {
+                                                             float* __restrict__ partials) {
     __shared__ float red[3][4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * per;
+    const long r1 = r0 + per < rows ? r0 + per : rows;
     float sb = 0.f, sx = 0.f, sh = 0.f;
     if (col < G) {
-        for (long row = w; row < rows; row += 4) {
+        for (long row = r0 + w; row < r1; row += 4) {
             const float* st = stats + row * 4;
             const float d = dgate[row * G + col];
             sb += d;
@@ -205,14 +209,24 @@ __global__ __launch_bounds__(256) void lstm_colreduce_kernel(const float* __rest
     }
     red[0][w][lane] = sb; red[1][w][lane] = sx; red[2][w][lane] = sh;
     __syncthreads();
-    if (w == 0 && col < G) {
-        const float b = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-        dbias[col] = b;
-        dbeta[col] = b;
-        dbeta[G + col] = b;
-        dgamma[col] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
-        dgamma[G + col] = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
-    }
+    if (w < 3 && col < G)
+        partials[((size_t)blockIdx.y * 3 + w) * G + col] =
+            (red[w][0][lane] + red[w][1][lane]) + (red[w][2][lane] + red[w][3][lane]);
+}
+__global__ __launch_bounds__(256) void lstm_colfinal_kernel(const float* __restrict__ partials, int chunks, int G,
+                                                            float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= G) return;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < chunks; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += partials[((size_t)c * 3 + k) * G + col];
+    dbias[col] = s[0];
+    dbeta[col] = s[0];
+    dbeta[G + col] = s[0];
+    dgamma[col] = s[1];
+    dgamma[G + col] = s[2];
 }
 
 // ------------------------------------------------------------------------------------------------ dropout
@@ -250,7 +264,7 @@ inline void launch_cell_bwd(int H, int B, hipStream_t st, Args... a) {
 struct LayerWs { float *xw, *hw, *gates, *c, *hseq, *stats, *xin_next; };
 struct Ws {
     LayerWs layer[16];
-    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b;
+    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart;
     size_t total;
 };
 inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
@@ -275,6 +289,7 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     const size_t widest = SB * (size_t)(I > H ? I : H);
     w.dseq_a = take(widest);
     w.dseq_b = take(widest);
+    w.colpart = take((size_t)kColChunks * 3 * G);
     w.total = off;
     return w;
 }
@@ -422,10 +437,15 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             GemmArgs g{w.dxw, wx_l, dxin, (int)SB, in_l, (int)G, (long)G, 1, 1, (long)G, (long)in_l, 0};
             launch_gemm(g, st);
         }
-        hipLaunchKernelGGL(lstm_colreduce_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st,
-                           (const float*)w.dgate, (const float*)lw.xw, (const float*)lw.hw, (const float*)lw.stats,
-                           (long)SB, (int)G, dbias + (size_t)l * G, dln_gamma + (size_t)l * 2 * G,
-                           dln_beta + (size_t)l * 2 * G);
+        {
+            const int chunks = (int)(SB < (size_t)kColChunks * 8 ? (SB + 7) / 8 : kColChunks);
+            hipLaunchKernelGGL(lstm_colreduce_kernel, dim3((unsigned)((G + 63) / 64), chunks), dim3(256), 0, st,
+                               (const float*)w.dgate, (const float*)lw.xw, (const float*)lw.hw,
+                               (const float*)lw.stats, (long)SB, (int)G, w.colpart);
+            hipLaunchKernelGGL(lstm_colfinal_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st,
+                               (const float*)w.colpart, chunks, (int)G, dbias + (size_t)l * G,
+                               dln_gamma + (size_t)l * 2 * G, dln_beta + (size_t)l * 2 * G);
+        }
         if (l > 0) {
             if (dropout_p > 0.f) {   // backward of the dropout between layer l-1 and l: same mask, same scale
                 const long n = (long)(SB * H);

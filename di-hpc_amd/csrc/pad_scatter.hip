@@ -154,6 +154,60 @@ __global__ __launch_bounds__(256) void scatter_out_kernel(const float* __restric
     }
 }
 
+// 4 consecutive cells x 4 channels per thread step: four float4 gathers, a 4x4 register transpose, four float4
+// nontemporal stores (1 KiB per wave-store instead of 256 B).  Needs HW % 4 == 0, N % 4 == 0, 16-byte aligned x/out.
+template <bool ADD>
+__global__ __launch_bounds__(256) void scatter_out4_kernel(const float* __restrict__ x,
+                                                           const int32_t* __restrict__ idx,
+                                                           float* __restrict__ out, int M, int N, int HW,
+                                                           int n_per_block) {
+    const int b = blockIdx.z;
+    const int cell = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (cell >= HW) return;
+    const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
+    const int32_t* __restrict__ last = head + HW;
+    const int32_t* __restrict__ next = last + HW;
+    const float* __restrict__ xb = x + (size_t)b * M * N;
+    float* __restrict__ ob = out + (size_t)b * N * HW + cell;
+    const int n0 = blockIdx.y * n_per_block;
+    const int n1 = min(N, n0 + n_per_block);
+    int32_t first[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) first[c] = ADD ? head[cell + c] : last[cell + c];
+    // 16 channels per iteration: all 16 gathers of an iteration are independent and issued together (a dependent
+    // gather costs ~2 us under streaming load; serialising them made the first version latency bound)
+    constexpr int U = 4;
+    for (int n = n0; n < n1; n += 4 * U) {
+        vfloat4 acc[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                vfloat4 a = {0.f, 0.f, 0.f, 0.f};
+                if (first[c] >= 0 && n + 4 * u < n1)
+                    a = *reinterpret_cast<const vfloat4*>(xb + (size_t)first[c] * N + n + 4 * u);
+                acc[u][c] = a;
+            }
+        if (ADD) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                for (int32_t m = first[c] >= 0 ? next[first[c]] : -1; m >= 0; m = next[m])
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (n + 4 * u < n1) acc[u][c] += *reinterpret_cast<const vfloat4*>(xb + (size_t)m * N + n + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (n + 4 * u < n1) {
+                    vfloat4 o = {acc[u][0][q], acc[u][1][q], acc[u][2][q], acc[u][3][q]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<vfloat4*>(ob + (size_t)(n + 4 * u + q) * HW));
+                }
+            }
+    }
+}
+
 // backward: workgroup = (b, group of NG channels); stage NG planes of grad_out in LDS, gather per entity.
 __global__ __launch_bounds__(256) void scatter_bwd_lds_kernel(const float* __restrict__ grad_out,
                                                               const int64_t* __restrict__ location,
@@ -339,11 +393,18 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
                        W);
     int rc = last_error();
     if (rc) return rc;
-    const int cell_blocks = (int)((HW + 255) / 256);
+    const bool v4 = (HW % 4) == 0 && (N % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    const int cell_blocks = (int)((HW + (v4 ? 1023 : 255)) / (v4 ? 1024 : 256));
     // enough workgroups to cover the chip: split the channel axis when B * cell_blocks is small
     int n_per_block = N;
     while (n_per_block > 4 && (long)B * cell_blocks * ((N + n_per_block - 1) / n_per_block) < 2048) n_per_block = (n_per_block / 2 + 3) / 4 * 4;
     const dim3 grid(cell_blocks, (N + n_per_block - 1) / n_per_block, B);
+    if (v4) {
+        if (add) hipLaunchKernelGGL(scatter_out4_kernel<true>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
+        else hipLaunchKernelGGL(scatter_out4_kernel<false>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
+        return last_error();
+    }
     const bool vec = (N % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     if (add) hipLaunchKernelGGL(scatter_out_kernel<true>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block, vec);
     else hipLaunchKernelGGL(scatter_out_kernel<false>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block, vec);
