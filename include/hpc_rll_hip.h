@@ -237,6 +237,22 @@ int hpc_rll_lstm_backward(const float* dy, const float* dhn, const float* dcn, c
 int hpc_rll_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_sm, int64_t a_sk,
                      int64_t b_sk, int64_t b_sn, int64_t ldc, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * hpc_models: AlphaStar actor-critic inference helpers, forward only -- replaces actor_critic_update_ae,
+ * actor_critic_lstm_activation, actor_critic_pre_sample (include/hpc/rll/cuda/models/entry.h:11-21,
+ * src/models/actor_critic.cu:8-83).
+ *   update_ae      : ae (B,D) += key_embeddings[b, sample_entity[b], :] unless sample_entity[b] == entity_num[b]
+ *   lstm_activation: gates = ih + hh + bias (B,4H; order i,f,g,o); c (B,H) updated in place, h (B,H) written
+ *   pre_sample     : out (B,E) = mask ? dot(mat[b,e,:], vec[b,:]) / div : mask_value / div   (mask: 1 byte per entry)
+ * ------------------------------------------------------------------------------------------ */
+int hpc_rll_actor_critic_update_ae(const float* key_embeddings, const int64_t* sample_entity,
+                                   const int64_t* entity_num, float* autoregressive_embedding, int64_t B, int64_t E,
+                                   int64_t D, void* stream);
+int hpc_rll_actor_critic_lstm_activation(const float* ih, const float* hh, const float* bias, float* h, float* c,
+                                         int64_t B, int64_t H, void* stream);
+int hpc_rll_actor_critic_pre_sample(const float* mat, const float* vec, const uint8_t* mask, float* out, int64_t B,
+                                    int64_t E, int64_t H, float mask_value, float div_factor, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
