@@ -283,37 +283,75 @@ extern "C" int hpc_rll_unpad_forward(const float* padded, const int64_t* table, 
 // ---- group splitting policies (host logic; reference: padding.cu:8-108).  sizes: n x dim, row-major, the list is
 // already sorted by numel.  Outputs: group_shapes (<= group rows of dim ints), positions (<= group+1 ints).
 // Returns the number of groups (>= 1) or a negative error.
+namespace {
+// 1-D lists sorted by length: cost(k,i) = len[i-1] * (i-k) satisfies the quadrangle inequality, so the smallest optimal
+// split point is monotone in i and each DP layer is a divide-and-conquer in O(n log n) instead of O(n^2)
+// (the reference's O(group * n^2) DP with stack VLAs breaks long before n ~ 1e6).  Ties resolve to
+// the smallest split point, exactly like the quadratic DP.
+void dc_layer(const int32_t* len, const int64_t* prev, int64_t* cur, int32_t* arg, int lo, int hi, int klo, int khi,
+              int64_t INF) {
+    if (lo > hi) return;
+    const int mid = (lo + hi) >> 1;
+    int64_t best = INF;
+    int32_t bk = klo;
+    const int kend = khi < mid - 1 ? khi : mid - 1;
+    for (int k = klo; k <= kend; ++k) {
+        if (prev[k] >= INF) continue;
+        const int64_t c = prev[k] + (int64_t)len[mid - 1] * (mid - k);
+        if (c < best) { best = c; bk = k; }
+    }
+    cur[mid] = best;
+    arg[mid] = bk;
+    dc_layer(len, prev, cur, arg, lo, mid - 1, klo, best >= INF ? khi : bk, INF);
+    dc_layer(len, prev, cur, arg, mid + 1, hi, best >= INF ? klo : bk, khi, INF);
+}
+}  // namespace
+
 extern "C" int hpc_rll_oracle_split_group(const int32_t* sizes, int n, int dim, int group, int32_t* group_shapes,
                                           int32_t* positions) {
     if (!sizes || n <= 0 || dim <= 0 || dim > 3 || group <= 0 || !group_shapes || !positions) return HPC_RLL_EINVAL;
     const int M = group < n ? group : n;  // more groups than tensors is meaningless (the reference would walk off)
     const int64_t INF = INT64_MAX / 4;
-    std::vector<int64_t> cost((size_t)(n + 1) * (M + 1), INF);
     std::vector<int32_t> pos((size_t)(n + 1) * (M + 1), 0);
-    auto C = [&](int i, int j) -> int64_t& { return cost[(size_t)i * (M + 1) + j]; };
     auto P = [&](int i, int j) -> int32_t& { return pos[(size_t)i * (M + 1) + j]; };
-    C(0, 0) = 0;
-    std::vector<int64_t> elems(n);  // elems[k] = prod_d max_{k<=t<=i-1} sizes[t][d]
-    for (int i = 1; i <= n; ++i) {
-        int32_t mx[3] = {0, 0, 0};
-        for (int k = i - 1; k >= 0; --k) {
-            int64_t e = 1;
-            for (int d = 0; d < dim; ++d) {
-                mx[d] = std::max(mx[d], sizes[(size_t)k * dim + d]);
-                e *= mx[d];
-            }
-            elems[k] = e;
-        }
+    bool sorted1d = (dim == 1);
+    for (int i = 1; sorted1d && i < n; ++i) sorted1d = sizes[i] >= sizes[i - 1];
+    if (sorted1d && n > 512) {
+        std::vector<int64_t> prev(n + 1, INF), cur(n + 1, INF);
+        std::vector<int32_t> arg(n + 1, 0);
+        prev[0] = 0;
         for (int j = 1; j <= M; ++j) {
-            int64_t best = INF;
-            int32_t arg = 0;
-            for (int k = 0; k < i; ++k) {
-                if (C(k, j - 1) >= INF) continue;
-                const int64_t c = C(k, j - 1) + elems[k] * (i - k);
-                if (c < best) { best = c; arg = k; }  // strict: the smallest k wins ties, like the reference
+            std::fill(cur.begin(), cur.end(), INF);
+            dc_layer(sizes, prev.data(), cur.data(), arg.data(), 1, n, 0, n - 1, INF);
+            for (int i = 1; i <= n; ++i) P(i, j) = arg[i];
+            prev.swap(cur);
+        }
+    } else {
+        std::vector<int64_t> cost((size_t)(n + 1) * (M + 1), INF);
+        auto C = [&](int i, int j) -> int64_t& { return cost[(size_t)i * (M + 1) + j]; };
+        C(0, 0) = 0;
+        std::vector<int64_t> elems(n);  // elems[k] = prod_d max_{k<=t<=i-1} sizes[t][d]
+        for (int i = 1; i <= n; ++i) {
+            int32_t mx[3] = {0, 0, 0};
+            for (int k = i - 1; k >= 0; --k) {
+                int64_t e = 1;
+                for (int d = 0; d < dim; ++d) {
+                    mx[d] = std::max(mx[d], sizes[(size_t)k * dim + d]);
+                    e *= mx[d];
+                }
+                elems[k] = e;
             }
-            C(i, j) = best;
-            P(i, j) = arg;
+            for (int j = 1; j <= M; ++j) {
+                int64_t best = INF;
+                int32_t arg = 0;
+                for (int k = 0; k < i; ++k) {
+                    if (C(k, j - 1) >= INF) continue;
+                    const int64_t c = C(k, j - 1) + elems[k] * (i - k);
+                    if (c < best) { best = c; arg = k; }  // strict: the smallest k wins ties, like the reference
+                }
+                C(i, j) = best;
+                P(i, j) = arg;
+            }
         }
     }
     std::vector<int32_t> ps;

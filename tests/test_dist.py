@@ -62,6 +62,8 @@ def _cpu_worker(rank, world, port, q):
     # PPO-style info slots are means: averaged, not summed
     info = torch.tensor([1.0, 2.0, 3.0, float(rank), float(rank) * 2])
     D.all_reduce_losses_(info, None, sharded=True, mean_slots=(3, 4))
+    gathered = D.all_gather_batch(sh["reward"], 1)                 # (T, B/R) shards -> (T, B) on every rank
+    assert torch.equal(gathered, d["reward"])
     q.put((rank, loss.item(), v.grad.numpy(), three.numpy(), info.numpy()))
     dist.destroy_process_group()
 

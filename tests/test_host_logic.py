@@ -1,0 +1,70 @@
+"""CPU tests of the host-side logic that lives in the C-ABI library (no GPU needed): the group-split policies of
+Pad*D (reference: src/rl_utils/padding.cu:8-108) against the oracle DP and the golden fixtures."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+
+
+def _split(nl, group):
+    import hpc_rl_utils as U
+    return U.oracle_split_group([torch.empty(n) for n in nl], group)
+
+
+def test_oracle_split_matches_golden(golden):
+    g = golden("padding")
+    for j in range(int(g["split_n"])):
+        nl = [int(v) for v in g[f"split{j}_numels"]]
+        res = _split(nl, int(g[f"split{j}_group"]))
+        assert res[-1] == [int(v) for v in g[f"split{j}_pos"]]
+        # group shapes are the per-group maxima
+        for k, shape in enumerate(res[:-1]):
+            assert shape == [max(nl[res[-1][k]:res[-1][k + 1]])]
+
+
+@pytest.mark.parametrize("n,group", [(600, 4), (1500, 7), (2000, 3), (513, 16), (700, 1)])
+def test_fast_split_equals_quadratic_dp(n, group):
+    """n > 512 sorted 1-D lists take the O(n log n) divide-and-conquer layer; it must return the quadratic DP's answer,
+    tie-breaking (smallest split point) included.  Lengths are drawn from a small range to force many ties."""
+    rng = np.random.default_rng(n)
+    nl = sorted(int(v) for v in rng.integers(1, 40, n))
+    assert _split(nl, group)[-1] == R.oracle_split_group(nl, group)
+
+
+def test_split_multi_dim_uses_elementwise_max():
+    import hpc_rl_utils as U
+    xs = [torch.empty(2, 9), torch.empty(5, 4), torch.empty(3, 8), torch.empty(6, 6)]
+    xs = sorted(xs, key=lambda t: t.numel())
+    res = U.oracle_split_group(xs, 2)
+    pos = res[-1]
+    for k, shape in enumerate(res[:-1]):
+        grp = xs[pos[k]:pos[k + 1]]
+        assert shape == [max(t.shape[0] for t in grp), max(t.shape[1] for t in grp)]
+
+
+def test_sample_split_is_valid_and_seeded():
+    import hpc_rl_utils as U
+    xs = [torch.empty(n) for n in sorted([5, 9, 9, 12, 30, 31, 40, 100, 100, 101])]
+    random.seed(3)
+    a = U.sample_split_group(xs, 4)
+    random.seed(3)
+    b = U.sample_split_group(xs, 4)
+    assert a == b
+    pos = a[-1]
+    assert pos[0] == 0 and pos[-1] == len(xs) and all(p < q for p, q in zip(pos, pos[1:]))
+    for k, shape in enumerate(a[:-1]):
+        assert shape == [max(t.numel() for t in xs[pos[k]:pos[k + 1]])]
+    assert U.sample_split_group(xs[:2], 3)[-1] == [0, 2]          # n = 2: the reference divides by zero here
+
+
+def test_large_list_is_fast():
+    import time
+    rng = np.random.default_rng(1)
+    nl = sorted(int(v) for v in rng.integers(32, 128, 200000))
+    t = time.time()
+    pos = _split(nl, 8)[-1]
+    assert time.time() - t < 20 and pos[0] == 0 and pos[-1] == len(nl) and len(pos) == 9
