@@ -210,7 +210,7 @@ def ppo_error(logit_new, logit_old, action, value_new, value_old, adv, return_, 
 def _nstep_reward(reward: torch.Tensor, gamma: float) -> torch.Tensor:
     """R_b = sum_t gamma^t r[t,b]  (origin/td.py:349-352)."""
     n = reward.shape[0]
-    f = torch.tensor([gamma ** i for i in range(n)], dtype=reward.dtype)
+    f = torch.tensor([gamma ** i for i in range(n)], dtype=reward.dtype, device=reward.device)
     return (f.unsqueeze(1) * reward).sum(0)
 
 
@@ -226,7 +226,7 @@ def q_nstep_td_error(q, next_n_q, action, next_n_action, reward, done, weight, g
     """(mean(w*(q[b,a]-tgt)^2), per-sample (q-tgt)^2).  origin/td.py:280-291 and :326-340 (rescale)."""
     nstep = reward.shape[0]
     B = action.shape[0]
-    idx = torch.arange(B)
+    idx = torch.arange(B, device=q.device)
     qsa = q[idx, action]
     with torch.no_grad():
         tq = next_n_q[idx, next_n_action]

@@ -1,0 +1,79 @@
+"""Edge cases across the op set: empty batches / zero-length trajectories, single elements, non-default device
+streams, non-contiguous gradients coming back from autograd."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def test_empty_batch_and_zero_length():
+    from hpc_rll.rl_utils.gae import GAE
+    from hpc_rll.rl_utils.td import TDLambda, QNStepTD
+    from hpc_rll.rl_utils.vtrace import VTrace
+    from hpc_rll.rl_utils.upgo import UPGO
+    from hpc_rll.rl_utils.ppo import PPO
+    for T, B in ((0, 8), (5, 0)):
+        v = torch.zeros(T + 1, B, device=DEV, requires_grad=True)
+        r = torch.zeros(T, B, device=DEV)
+        adv = GAE(T, B)(v, r)
+        assert adv.shape == (T, B)
+        adv.sum().backward()
+        assert v.grad.shape == (T + 1, B) and torch.equal(v.grad, torch.zeros_like(v.grad))
+        loss = TDLambda(T, B)(v, r)
+        assert loss.shape == (1,) and loss.item() == 0.0
+        N = 4
+        to = torch.zeros(T, B, N, device=DEV)
+        a = torch.zeros(T, B, dtype=torch.int64, device=DEV)
+        ls = VTrace(T, B, N)(to, to, a, v, r)
+        assert all(x.item() == 0.0 for x in ls)
+        assert UPGO(T, B, N)(to, r, a, r, v).item() == 0.0
+    B, N = 0, 3
+    z = torch.zeros(B, device=DEV)
+    ls, info = PPO(B, N)(torch.zeros(B, N, device=DEV), torch.zeros(B, N, device=DEV), torch.zeros(B, dtype=torch.int64, device=DEV), z, z, z, z)
+    assert all(x.item() == 0.0 for x in ls)
+    loss, per = QNStepTD(2, B, N)(torch.zeros(B, N, device=DEV), torch.zeros(B, N, device=DEV), torch.zeros(B, dtype=torch.int64, device=DEV),
+                                  torch.zeros(B, dtype=torch.int64, device=DEV), torch.zeros(2, B, device=DEV), z, None, 0.9)
+    assert loss.item() == 0.0 and per.shape == (0,)
+
+
+def test_expanded_upstream_gradient():
+    """`loss.sum().backward()` / weighted sums hand the Function an expanded (stride-0) or 0-dim grad tensor."""
+    from hpc_rll.rl_utils.td import TDLambda
+    rng = np.random.default_rng(0)
+    T, B = 9, 70
+    v = torch.from_numpy(rng.standard_normal((T + 1, B)).astype(np.float32)).to(DEV).requires_grad_(True)
+    r = torch.from_numpy(rng.standard_normal((T, B)).astype(np.float32)).to(DEV)
+    m = TDLambda(T, B)
+    m(v, r).sum().backward()
+    g1 = v.grad.clone()
+    v.grad = None
+    (2.5 * m(v, r)).squeeze().backward()
+    assert torch.allclose(v.grad, 2.5 * g1, rtol=1e-6, atol=0)
+
+
+def test_side_stream_and_graph_capture():
+    """Nothing in the GAE path allocates device memory behind torch's back or synchronises: it can be captured into a
+    HIP graph and replayed."""
+    import hpc_rl_utils as U
+    T, B = 64, 1024
+    g = torch.Generator(device=DEV).manual_seed(0)
+    v = torch.randn(T + 1, B, device=DEV, generator=g)
+    r = torch.randn(T, B, device=DEV, generator=g)
+    adv = torch.empty_like(r)
+    ref = torch.empty_like(r)
+    U.GaeForward([v, r], [ref], 0.99, 0.97)          # also warms the coefficient-table cache
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        U.GaeForward([v, r], [adv], 0.99, 0.97)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        U.GaeForward([v, r], [adv], 0.99, 0.97)
+    adv.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(adv, ref)
