@@ -181,7 +181,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "fwd_us": t_fwd * 1e6, "bwd_us": t_bwd * 1e6,
                          "fwd_bwd_frac": (2 * bytes_launch) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS},
-            "cpu_baseline": None if args.skip_cpu_baseline else cpu_baseline(T, B, gamma, lam),
+            "cpu_baseline": None if (args.skip_cpu_baseline or world > 1) else cpu_baseline(T, B, gamma, lam),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -73,8 +73,13 @@ def check(status: int, what: str = "") -> None:
         raise RuntimeError(f"{what}: {msg} (status {status})")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device=None) -> int:
     """The current torch HIP stream for ``device`` as an integer hipStream_t."""
+    if _raw_stream is not None and device is not None and device.index is not None:
+        return _raw_stream(device.index)          # ~0.3 us instead of ~5 us through torch.cuda.Stream
     return torch.cuda.current_stream(device).cuda_stream
 
 
@@ -100,6 +105,13 @@ def require(t, name, dtype=torch.float32, shape=None, device=None):
 
 
 def call(name, dev, *args):
-    """Launch a C-ABI entry point on torch's current stream of ``dev`` (appended as the last argument)."""
-    with torch.cuda.device(dev):
-        check(getattr(lib, name)(*args, stream_ptr(dev)), name)
+    """Launch a C-ABI entry point on torch's current stream of ``dev`` (appended as the last argument).
+    The device guard is only entered when ``dev`` is not already current (it costs ~10 us)."""
+    fn = getattr(lib, name)
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        st = fn(*args, stream_ptr(dev))
+    else:
+        with torch.cuda.device(dev):
+            st = fn(*args, stream_ptr(dev))
+    if st:
+        check(st, name)
