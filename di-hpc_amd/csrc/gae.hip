@@ -353,35 +353,51 @@ inline int max_vec(int B, std::initializer_list<const void*> ptrs) {
 
 // Launch-configuration heuristic, tuned on MI355X with forward and backward launches ALTERNATING (the real
 // access pattern; a kernel repeated back to back finds part of its input in the 256 MiB Infinity Cache and
-// looks faster than it is).  Sweeps of every instantiation: profiles/r01_gae_tuning_*.txt, DESIGN.md.
-//   * streaming regime (>= 512 workgroups): ~32 KiB of loads in flight per CU is enough, more resident
-//     waves do not help.  Forward: 2 columns/lane, 2 waves x 8 steps.  Backward: 4 columns/lane, 4 x 4.
-//     Stores are always NONTEMPORAL: a regular store leaves dirty lines in L2/MALL whose write-back lands in
-//     the NEXT kernel (measured: +35-45 us on the following launch); nontemporal loads help the forward.
-//   * small-B regime: 1 column per lane and up to 16 waves x 16 steps so that ~2048 waves cover the chip
-//     even when there are few column tiles (B=64 -> one workgroup walking T in 256-step strides).
+// looks faster than it is).  Sweeps: profiles/r01_gae_tuning_*.txt (every instantiation at T=1024,B=65536) and
+// profiles/r01_gae_heuristic_shapes.txt (candidate sets at 7 more shapes); summary in DESIGN.md.
+//   * ~32 KiB of loads in flight per CU saturates HBM; beyond ~2048 waves more occupancy does not help.
+//   * Stores are always NONTEMPORAL: a regular store leaves dirty lines in L2/MALL whose write-back lands in the
+//     NEXT kernel (+35-45 us on the following launch).  For working sets beyond the Infinity Cache the forward also
+//     loads nontemporally, which helps itself and the backward that follows it.
+//   * streaming regime (one launch moves >= 300 MB): forward 2 columns/lane from B = 65536 up, 512 workgroups x
+//     4 waves x 8 steps or >= 1024 workgroups x 8 waves x 16 steps; backward 4 columns/lane, 4 x 4 in the middle,
+//     1 column/lane 8 x 8 for narrow batches, 2 columns/lane 16 x 16 for very wide ones.
+//   * cache-resident regime: 1 column per lane and up to 16 waves x 16 steps so that ~2048 waves cover the chip even
+//     when there are few column tiles (B=64 -> one workgroup walking T in 256-step strides).
 inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, int flags) {
     auto wgs_for = [&](int vv) { return (B + 64 * vv - 1) / (64 * vv); };
-    if (v == 0) {
-        v = vmax > 2 ? 2 : vmax;
-        while (v > 1 && wgs_for(v) < 512) v >>= 1;
-        if (!fwd && vmax == 4 && wgs_for(4) >= 256 && wgs_for(2) >= 512) v = 4;
+    const bool streaming = (12.0 * (double)T * (double)B) >= 300e6;
+    int av, alc, anw, afl;
+    if (streaming && fwd) {
+        av = (B >= 65536 && vmax >= 2) ? 2 : 1;
+        const int wgs = wgs_for(av);
+        if (wgs >= 1024) { alc = 16; anw = 8; }
+        else if (wgs >= 512) { alc = 8; anw = av == 2 ? 2 : 4; }   // ~35 KiB of loads in flight per CU either way
+        else { alc = 16; anw = 8; }
+        afl = 3;
+    } else if (streaming) {
+        if (B >= 262144 && vmax >= 2) { av = 2; alc = 16; anw = 16; }
+        else if (B >= 65536 && vmax >= 4) { av = 4; alc = 4; anw = 4; }
+        else if (B >= 65536 && vmax >= 2) { av = 2; alc = 4; anw = 4; }
+        else { av = 1; alc = 8; anw = 8; }
+        afl = 2;
+    } else {
+        av = 1; alc = 16; anw = 4;
+        while (anw < 16 && wgs_for(1) * anw < 2048) anw <<= 1;
+        afl = 2;
     }
+    if (v == 0) v = av;
     if (v > vmax) v = vmax;
-    const int wgs = wgs_for(v);
-    const bool streaming = wgs_for(v > 2 ? 2 : v) >= 512;
     if (lc == 0) {
-        lc = streaming ? (fwd ? 8 : 4) : 16;
+        lc = alc;
         if (lc == 16 && v == 4) lc = 8;  // (4,16) is not instantiated (VGPR budget)
     }
     if (nw == 0) {
+        nw = anw;
         const int chunks = (T + lc - 1) / lc;
-        nw = streaming ? (fwd ? 2 : 4) : 4;
-        if (!streaming)
-            while (nw < 16 && wgs * nw < 2048) nw <<= 1;
         while (nw > 1 && nw > chunks) nw >>= 1;
     }
-    if (flags < 0) flags = (streaming && fwd) ? 3 : 2;
+    if (flags < 0) flags = afl;
     return Cfg{v, lc, nw, flags & 3};
 }
 

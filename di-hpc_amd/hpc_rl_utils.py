@@ -37,6 +37,10 @@ def gae_coef(T: int, gamma: float, lambda_: float, device: torch.device) -> torc
     if c is None:
         c = torch.empty(max(int(T), 1), dtype=F32, device=device)
         N.call("hpc_rll_gae_coef", device, c.data_ptr(), int(T), float(gamma), float(lambda_))
+        # the table is cached and may later be consumed on ANY stream: make it globally visible once (a one-off
+        # ~20 us host wait on a cache miss; skipped while a HIP graph is being captured, where the fill is captured too)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(device).synchronize()
         if len(_gae_coef_cache) > 64:
             _gae_coef_cache.clear()
         _gae_coef_cache[key] = c
