@@ -41,22 +41,25 @@ struct GemmArgs {
 
 enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2 };
 
-constexpr int kGemmBK = 32;
-
-// LDS address (in floats) of element (k, x) of a k-major tile with X columns (X % 32 == 0).
-template <int X> __device__ __forceinline__ int lds_idx(int k, int x) {
-    return k * X + ((((x >> 2) ^ ((k >> 2) & 7)) << 2) | (x & 3));
+// LDS address (in floats) of element (k, x) of a k-major tile with X columns (X % 32 == 0) and BK k-rows.  The 16-byte
+// slot index is XOR-ed with a function of k chosen so that the 8 lanes of a ds_write_b128 group (BK/4 k-groups x
+// 8/(BK/4) consecutive slots) hit 8 different slots, while 32 consecutive x of one k-row stay a permutation of 8 slots.
+template <int X, int BK> __device__ __forceinline__ int lds_idx(int k, int x) {
+    const int sw = (BK == 32) ? ((k >> 2) & 7) : (((k >> 2) & 3) << 1);
+    return k * X + ((((x >> 2) ^ sw) << 2) | (x & 3));
 }
 
-// Stages one operand tile (X rows-of-the-operand by 32 k) through registers.
+// Stages one operand tile (X rows-of-the-operand by BK k) through registers.
 //   MODE kContigMN: element (x,k) at base[x + k*sk]        (unit stride along x)
 //   MODE kContigK : element (x,k) at base[x*sx + k]        (unit stride along k)
 //   MODE kGeneric : element (x,k) at base[x*sx + k*sk], fully guarded
-template <int X, int MODE>
+template <int X, int BK, int MODE>
 struct TileStage {
-    static constexpr int NV = X * kGemmBK / (256 * 4);   // float4 per thread (contiguous along m/n)
-    static constexpr int NB = (2 * X + 255) / 256;       // 4x4 blocks per thread (contiguous along k); 2X blocks in all
-    static constexpr int NS = X * kGemmBK / 256;         // scalars per thread (generic)
+    static constexpr int KQ = BK / 4;                    // float4 per k-row of the tile
+    static constexpr int NBLK = X * BK / 16;             // 4x4 blocks in the tile
+    static constexpr int NV = (X * BK / 4 + 255) / 256;  // float4 per thread (contiguous along m/n)
+    static constexpr int NB = (NBLK + 255) / 256;        // 4x4 blocks per thread (contiguous along k)
+    static constexpr int NS = X * BK / 256;              // scalars per thread (generic)
     gf4 v[MODE == kGeneric ? 1 : (MODE == kContigK ? NB * 4 : NV)];
     float s[MODE == kGeneric ? NS : 1];
 
@@ -68,18 +71,19 @@ struct TileStage {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int e = tid + i * 256;
+                if (e >= X * BK / 4) break;
                 const int k = k0 + e / (X / 4), x = x0 + (e % (X / 4)) * 4;
                 gf4 t = {0.f, 0.f, 0.f, 0.f};
                 if (k < KD && x < XD) t = *reinterpret_cast<const gf4*>(base + (long)k * sk + x);
                 v[i] = t;
             }
         } else if (MODE == kContigK) {
-            // thread -> 4x4 block: rows x = 4*(e / 8) .. +3, k = (e % 8)*4 .. +3 ; 2X blocks, NB per thread
+            // thread -> 4x4 block: rows x = 4*(e / KQ) .. +3, k = (e % KQ)*4 .. +3 ; NBLK blocks, NB per thread
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int e = tid + i * 256;
-                if (e >= 2 * X) break;
-                const int xr = x0 + 4 * (e / 8), k = k0 + (e % 8) * 4;
+                if (e >= NBLK) break;
+                const int xr = x0 + 4 * (e / KQ), k = k0 + (e % KQ) * 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int x = xr + r;
@@ -105,34 +109,34 @@ struct TileStage {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int e = tid + i * 256;
-                *reinterpret_cast<gf4*>(tile + lds_idx<X>(e / (X / 4), (e % (X / 4)) * 4)) = v[i];
+                if (e >= X * BK / 4) break;
+                *reinterpret_cast<gf4*>(tile + lds_idx<X, BK>(e / (X / 4), (e % (X / 4)) * 4)) = v[i];
             }
         } else if (MODE == kContigK) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int e = tid + i * 256;
-                if (e >= 2 * X) break;
-                const int xr = 4 * (e / 8), k = (e % 8) * 4;
+                if (e >= NBLK) break;
+                const int xr = 4 * (e / KQ), k = (e % KQ) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     gf4 t = {v[i * 4 + 0][j], v[i * 4 + 1][j], v[i * 4 + 2][j], v[i * 4 + 3][j]};
-                    *reinterpret_cast<gf4*>(tile + lds_idx<X>(k + j, xr)) = t;
+                    *reinterpret_cast<gf4*>(tile + lds_idx<X, BK>(k + j, xr)) = t;
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int e = tid + i * 256;
-                tile[lds_idx<X>(e / X, e % X)] = s[i];
+                tile[lds_idx<X, BK>(e / X, e % X)] = s[i];
             }
         }
     }
 };
 
-// BM x BN block tile, BK = 32, 256 threads.  WM x WN = MFMA blocks per wave; waves arranged (BM/(32*WM)) x (BN/(32*WN)).
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+// BM x BN x BK block tile, 256 threads.  WM x WN = MFMA blocks per wave; waves arranged (BM/(32*WM)) x (BN/(32*WN)).
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-    constexpr int BK = kGemmBK;
     constexpr int WAVES_M = BM / (32 * WM);
     static_assert(WAVES_M * (BN / (32 * WN)) == 4, "4 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    TileStage<BM, AMODE> sa;
-    TileStage<BN, BMODE> sb;
+    TileStage<BM, BK, AMODE> sa;
+    TileStage<BN, BK, BMODE> sb;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -176,9 +180,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
             const int kr = ks + (lane >> 5);
             float a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = as[lds_idx<BM>(kr, am + i * 32)];
+            for (int i = 0; i < WM; ++i) a[i] = as[lds_idx<BM, BK>(kr, am + i * 32)];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = bs[lds_idx<BN>(kr, bn + j * 32)];
+            for (int j = 0; j < WN; ++j) b[j] = bs[lds_idx<BN, BK>(kr, bn + j * 32)];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -218,19 +222,19 @@ inline int gemm_mode(const float* p, long sx, long sk, int XD, int KD) {
     return kGeneric;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN>
 inline void launch_gemm_tile(const GemmArgs& g, int am, int bm, hipStream_t st) {
     const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
 #define HPC_RLL_GEMM_CASE(AM, BMD)                                                                          \
     if (am == AM && bm == BMD) {                                                                            \
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, AM, BMD>), grid, dim3(256), 0, st, g);          \
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, AM, BMD>), grid, dim3(256), 0, st, g);          \
         return;                                                                                             \
     }
     HPC_RLL_GEMM_CASE(kContigK, kContigMN)    // NN
     HPC_RLL_GEMM_CASE(kContigK, kContigK)     // NT
     HPC_RLL_GEMM_CASE(kContigMN, kContigMN)   // TN
 #undef HPC_RLL_GEMM_CASE
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, kGeneric, kGeneric>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, kGeneric, kGeneric>), grid, dim3(256), 0, st, g);
 }
 
 inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
@@ -241,10 +245,18 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     // own staging with its MFMAs.
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     const long t64 = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
-    if (g.M <= 32) launch_gemm_tile<32, 128, 1, 1>(g, am, bm, st);   // skinny: the 4 waves side by side along N
-    else if (t128 >= 512) launch_gemm_tile<128, 128, 2, 2>(g, am, bm, st);
-    else if (t64 >= 512 || g.M > 64) launch_gemm_tile<128, 64, 2, 1>(g, am, bm, st);
-    else launch_gemm_tile<64, 64, 1, 1>(g, am, bm, st);
+    extern int g_gemm_bk;   // tuning knob (hpc_rll_tune_set key 1): 16 / 32, 0 = by layout
+    // measured at the LSTM shapes: NN runs better with BK = 16 (4-5 workgroups resident per CU: 108 vs 94 TFLOP/s on
+    // the recurrent GEMM), TN (K = S*B) with BK = 32 (103 vs 79), NT is indifferent
+    const int bk = g_gemm_bk ? g_gemm_bk : ((am == kContigK && bm == kContigMN) ? 16 : 32);
+    if (g.M <= 32) launch_gemm_tile<32, 128, 32, 1, 1>(g, am, bm, st);   // skinny: the 4 waves side by side along N
+    else if (t128 >= 512) {
+        if (bk == 16) launch_gemm_tile<128, 128, 16, 2, 2>(g, am, bm, st);
+        else launch_gemm_tile<128, 128, 32, 2, 2>(g, am, bm, st);
+    } else if (t64 >= 512 || g.M > 64) {
+        if (bk == 16) launch_gemm_tile<128, 64, 16, 2, 1>(g, am, bm, st);
+        else launch_gemm_tile<128, 64, 32, 2, 1>(g, am, bm, st);
+    } else launch_gemm_tile<64, 64, 32, 1, 1>(g, am, bm, st);
 }
 
 }  // namespace hpc_rll

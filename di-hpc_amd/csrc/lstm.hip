@@ -25,6 +25,7 @@
 #include "wave.hpp"
 
 namespace hpc_rll {
+int g_gemm_bk = 0;
 namespace {
 
 constexpr float kLnEps = 1e-5f;

@@ -88,7 +88,8 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
                                  const float* g_logp, const float* coef_ent, const float* g_ent,
                                  float* grad_logits, int64_t rows, int N, void* stream);
 
-/* Tuning knob for experiments (key 0: resident 256-thread blocks per CU targeted by the row kernels, 1..64). */
+/* Tuning knobs for experiments.  key 0: resident 256-thread blocks per CU targeted by the categorical row kernels
+ * (1..64).  key 1: k-depth of the fp32 GEMM tiles (16, 32, or 0 = chosen by operand layout). */
 int hpc_rll_tune_set(int key, int value);
 
 /* TD(lambda) -- replaces TdLambdaForward/Backward (rl_utils/entry.h:68-77, src/rl_utils/td_lambda.cu:8-52).
