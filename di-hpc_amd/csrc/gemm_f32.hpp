@@ -37,6 +37,8 @@ struct GemmArgs {
     long b_sk, b_sn;   // B(k,n) = B[k*b_sk + n*b_sn]
     long ldc;
     int accumulate;    // C += A*B instead of C = A*B
+    int splitk = 1;    // > 1 (skinny path only): gridDim.z slices of K, slice z writes its PARTIAL product to
+    long c_split = 0;  //      C + z*c_split; the consumer adds the slices in a fixed order (deterministic)
 };
 
 enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2 };
@@ -159,9 +161,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int ktiles = (g.K + BK - 1) / BK;
-    sa.load(g.A, g.a_sm, g.a_sk, m0, 0, g.M, g.K);
-    sb.load(g.B, g.b_sn, g.b_sk, n0, 0, g.N, g.K);
+    // split-K: slice z owns k-tiles [z*per, (z+1)*per)
+    const int all_tiles = (g.K + BK - 1) / BK;
+    const int per = (all_tiles + g.splitk - 1) / g.splitk;
+    const int kbeg = (int)blockIdx.z * per * BK;
+    const int KE = min(g.K, kbeg + per * BK);            // exclusive k end of this slice
+    const int ktiles = KE > kbeg ? (KE - kbeg + BK - 1) / BK : 0;
+    float* const Cz = g.C + (long)blockIdx.z * g.c_split;
+    sa.load(g.A, g.a_sm, g.a_sk, m0, kbeg, g.M, KE);
+    sb.load(g.B, g.b_sn, g.b_sk, n0, kbeg, g.N, KE);
     sa.store(As);
     sb.store(Bs);
     __syncthreads();
@@ -170,8 +178,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     for (int kt = 0; kt < ktiles; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < ktiles) {
-            sa.load(g.A, g.a_sm, g.a_sk, m0, (kt + 1) * BK, g.M, g.K);
-            sb.load(g.B, g.b_sn, g.b_sk, n0, (kt + 1) * BK, g.N, g.K);
+            sa.load(g.A, g.a_sm, g.a_sk, m0, kbeg + (kt + 1) * BK, g.M, KE);
+            sb.load(g.B, g.b_sn, g.b_sk, n0, kbeg + (kt + 1) * BK, g.N, KE);
         }
         const float* __restrict__ as = As + buf * BK * BM;
         const float* __restrict__ bs = Bs + buf * BK * BN;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < g.M && n < g.N) {
-                    float* p = g.C + (long)m * g.ldc + n;
+                    float* p = Cz + (long)m * g.ldc + n;
                     *p = g.accumulate ? (*p + acc[i][j][r]) : acc[i][j][r];
                 }
             }
@@ -224,7 +232,7 @@ inline int gemm_mode(const float* p, long sx, long sk, int XD, int KD) {
 
 template <int BM, int BN, int BK, int WM, int WN>
 inline void launch_gemm_tile(const GemmArgs& g, int am, int bm, hipStream_t st) {
-    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
 #define HPC_RLL_GEMM_CASE(AM, BMD)                                                                          \
     if (am == AM && bm == BMD) {                                                                            \
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, AM, BMD>), grid, dim3(256), 0, st, g);          \
@@ -235,6 +243,16 @@ inline void launch_gemm_tile(const GemmArgs& g, int am, int bm, hipStream_t st) 
     HPC_RLL_GEMM_CASE(kContigMN, kContigMN)   // TN
 #undef HPC_RLL_GEMM_CASE
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, kGeneric, kGeneric>), grid, dim3(256), 0, st, g);
+}
+
+// Number of K slices worth using for a skinny (M <= 32) product so that ~48+ workgroups share the weight stream
+// (a handful of workgroups walking a long K serially is latency bound: 12 k-tiles ~ 10 us).  1 for everything else.
+inline int gemm_skinny_splitk(int M, int N, int K) {
+    if (M > 32) return 1;
+    const int ntiles = (N + 127) / 128, ktiles = (K + 31) / 32;
+    int s = 1;
+    while (s < 16 && ntiles * s < 48 && ktiles / (s * 2) >= 2) s *= 2;
+    return s;
 }
 
 inline void launch_gemm(const GemmArgs& g, hipStream_t st) {

@@ -54,15 +54,16 @@ __device__ __forceinline__ void block_allsum(float (&v)[K], float* lds) {
 // one workgroup per batch row; thread t owns hidden units j = t, t+256, ... (JPT of them) x 4 gates x 2 branches.
 template <int JPT>
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
-    const float* __restrict__ xw, const float* __restrict__ hw, const float* __restrict__ bias,
-    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ c_prev,
-    float* __restrict__ gates, float* __restrict__ c_out, float* __restrict__ h_out, float* __restrict__ stats,
-    int H) {
+    const float* __restrict__ xw, const float* hw /* nsplit partial products, stride part_stride */, int nsplit,
+    long part_stride, float* hw_out /* summed h-branch pre-activation (saved for backward); may alias hw */,
+    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ c_prev, float* __restrict__ gates, float* __restrict__ c_out,
+    float* __restrict__ h_out, float* __restrict__ stats, int H) {
     __shared__ float red[16];
     const int b = blockIdx.x;
     const int G = 4 * H;
     const float* __restrict__ xr = xw + (size_t)b * G;
-    const float* __restrict__ hr = hw + (size_t)b * G;
+    const float* hr = hw + (size_t)b * G;
     float x[JPT][4], h[JPT][4];
     float s[2] = {0.f, 0.f};
 #pragma unroll
@@ -71,7 +72,13 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             x[q][g] = (j < H) ? xr[g * H + j] : 0.f;
-            h[q][g] = (j < H) ? hr[g * H + j] : 0.f;
+            float hv = 0.f;
+            if (j < H) {
+                hv = hr[g * H + j];
+                for (int z = 1; z < nsplit; ++z) hv += hr[(size_t)z * part_stride + g * H + j];   // fixed order
+                if (nsplit > 1) hw_out[(size_t)b * G + g * H + j] = hv;
+            }
+            h[q][g] = hv;
             s[0] += x[q][g];
             s[1] += h[q][g];
         }
@@ -125,7 +132,8 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
 // dh = dh_a + dh_b (either may be null); outputs dgate, dXW, dHW rows and dc_prev.
 template <int JPT>
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
-    const float* __restrict__ dh_a, const float* __restrict__ dh_b, const float* dc_in /* may alias dc_prev */,
+    const float* __restrict__ dh_a, const float* __restrict__ dh_b /* nsplit partials, stride part_stride */,
+    int nsplit, long part_stride, const float* dc_in /* may alias dc_prev */,
     const float* __restrict__ gates, const float* __restrict__ c_new, const float* __restrict__ c_prev,
     const float* __restrict__ xw, const float* __restrict__ hw, const float* __restrict__ stats,
     const float* __restrict__ gamma, float* __restrict__ dgate, float* __restrict__ dxw, float* __restrict__ dhw,
@@ -144,7 +152,9 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
             const size_t o = (size_t)b * H + j;
             const float* gr = gates + (size_t)b * G;
             const float ig = gr[j], fg = gr[H + j], og = gr[2 * H + j], ug = gr[3 * H + j];
-            const float dh = (dh_a ? dh_a[o] : 0.f) + (dh_b ? dh_b[o] : 0.f);
+            float dh = dh_a ? dh_a[o] : 0.f;
+            if (dh_b)
+                for (int z = 0; z < nsplit; ++z) dh += dh_b[(size_t)z * part_stride + o];
             const float tc = tanhf(c_new[o]);
             const float dc = (dc_in ? dc_in[o] : 0.f) + dh * og * (1.f - tc * tc);
             da[q][0] = dc * ug * ig * (1.f - ig);
@@ -244,6 +254,16 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* in, float* ou
         out[i] = (mix_hash(seed, (uint64_t)i) > threshold) ? in[i] * scale : 0.f;
 }
 
+// out[i] = sum_z parts[z*n + i]  (fixed order)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ parts, int nparts, long n,
+                                                        float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = parts[i];
+    for (int z = 1; z < nparts; ++z) s += parts[(size_t)z * n + i];
+    out[i] = s;
+}
+
 template <class... Args>
 inline void launch_cell_fwd(int H, int B, hipStream_t st, Args... a) {
     const int jpt = (H + 255) / 256;
@@ -265,7 +285,7 @@ inline void launch_cell_bwd(int H, int B, hipStream_t st, Args... a) {
 struct LayerWs { float *xw, *hw, *gates, *c, *hseq, *stats, *xin_next; };
 struct Ws {
     LayerWs layer[16];
-    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart;
+    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part;
     size_t total;
 };
 inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
@@ -285,7 +305,8 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.dgate = take(SB * G);
     w.dxw = take(SB * G);
     w.dhw = take(SB * G);
-    w.dh = take((size_t)B * H);
+    w.dh = take((size_t)16 * B * H);            // up to 16 split-K partials of dh_prev
+    w.hw_part = take((size_t)16 * B * G);       // up to 16 split-K partials of h @ Wh
     w.dc = take((size_t)B * H);
     const size_t widest = SB * (size_t)(I > H ? I : H);
     w.dseq_a = take(widest);
@@ -336,10 +357,14 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
         for (int s = 0; s < S; ++s) {
             const float* h_prev = s == 0 ? h0 + (size_t)l * BH : lw.hseq + (size_t)(s - 1) * BH;
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
-            GemmArgs g{h_prev, wh_l, lw.hw + (size_t)s * B * G, B, (int)G, H, H, 1, (long)G, 1, (long)G, 0};
+            float* hw_s = lw.hw + (size_t)s * B * G;
+            const int sk = gemm_skinny_splitk(B, (int)G, H);
+            GemmArgs g{h_prev, wh_l, sk > 1 ? w.hw_part : hw_s, B, (int)G, H, H, 1, (long)G, 1, (long)G, 0, sk,
+                       (long)((size_t)B * G)};
             launch_gemm(g, st);
             launch_cell_fwd(H, B, st, (const float*)(lw.xw + (size_t)s * B * G),
-                            (const float*)(lw.hw + (size_t)s * B * G), bias + (size_t)l * G,
+                            (const float*)(sk > 1 ? w.hw_part : hw_s), sk, (long)((size_t)B * G), hw_s,
+                            bias + (size_t)l * G,
                             ln_gamma + (size_t)l * 2 * G, ln_beta + (size_t)l * 2 * G, c_prev,
                             lw.gates + (size_t)s * B * G, lw.c + (size_t)s * BH, lw.hseq + (size_t)s * BH,
                             lw.stats + (size_t)s * B * 4);
@@ -398,23 +423,29 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         const float* gamma_l = ln_gamma + (size_t)l * 2 * G;
         const float* dh_carry = dhn ? dhn + (size_t)l * BH : nullptr;
         const float* dc_carry = dcn ? dcn + (size_t)l * BH : nullptr;
+        int dh_parts = 1;                                   // how many split-K partials dh_carry consists of
+        const int sk_dh = gemm_skinny_splitk(B, H, (int)G);
         for (int s = S - 1; s >= 0; --s) {
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
-            launch_cell_bwd(H, B, st, d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dc_carry,
+            launch_cell_bwd(H, B, st, d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dh_parts,
+                            (long)BH, dc_carry,
                             (const float*)(lw.gates + (size_t)s * B * G), (const float*)(lw.c + (size_t)s * BH),
                             c_prev, (const float*)(lw.xw + (size_t)s * B * G),
                             (const float*)(lw.hw + (size_t)s * B * G), (const float*)(lw.stats + (size_t)s * B * 4),
                             gamma_l, w.dgate + (size_t)s * B * G, w.dxw + (size_t)s * B * G,
                             w.dhw + (size_t)s * B * G, w.dc);
             // dh_prev (B,H) = dHW_s (B,G) @ Wh^T : B(k=g, n=h) = Wh[h*G + g]
-            GemmArgs g{w.dhw + (size_t)s * B * G, wh_l, w.dh, B, H, (int)G, (long)G, 1, 1, (long)G, (long)H, 0};
+            GemmArgs g{w.dhw + (size_t)s * B * G, wh_l, w.dh, B, H, (int)G, (long)G, 1, 1, (long)G, (long)H, 0, sk_dh,
+                       (long)BH};
             launch_gemm(g, st);
             dh_carry = w.dh;
+            dh_parts = sk_dh;
             dc_carry = w.dc;
         }
         int rc = last_error();
         if (rc) return rc;
-        if ((rc = copy_async(dh0 + (size_t)l * BH, w.dh, BH, st))) return rc;
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((BH + 255) / 256)), dim3(256), 0, st, (const float*)w.dh,
+                           dh_parts, (long)BH, dh0 + (size_t)l * BH);
         if ((rc = copy_async(dc0 + (size_t)l * BH, w.dc, BH, st))) return rc;
         // dWh (H,G) = [h0 ; hseq[0..S-2]]^T @ dHW
         {
