@@ -99,6 +99,25 @@ def test_padding_many_small_tensors():
     assert torch.equal(torch.cat(back), flat)
 
 
+def test_packed_padding_matches_list_api_at_one_million_entities():
+    """configs[4] scale: n = 2^20 entities in ONE launch, table built on the device (no per-tensor host work)."""
+    from hpc_rll.rl_utils import padding as P
+    n = 1 << 20
+    rng = np.random.default_rng(5)
+    lens = torch.from_numpy(rng.integers(32, 128, n)).to(DEV)
+    flat = torch.randn(int(lens.sum().item()), device=DEV)
+    new_x, mask = P.Padding1DPacked(flat, lens, max_len=127, value=-2)
+    assert new_x.shape == (n, 127) and int(mask.eq(1).sum()) == flat.numel()
+    assert bool(new_x[mask.eq(-2)].eq(-2.0).all())
+    assert torch.equal(P.UnPadding1DPacked(new_x, lens), flat)
+    # agreement with the reference-style list API on a prefix
+    k = 4096
+    xs = list(torch.split(flat[: int(lens[:k].sum().item())], [int(v) for v in lens[:k].tolist()]))
+    lx, lm, _ = P.Padding1D(xs, value=-2)
+    w = lx.shape[1]
+    assert torch.equal(new_x[:k, :w], lx) and torch.equal(mask[:k, :w], lm)
+
+
 def test_padding_errors():
     from hpc_rll.rl_utils import padding as P
     with pytest.raises(RuntimeError):

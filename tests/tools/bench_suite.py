@@ -174,6 +174,11 @@ def suite_c5(B=4096, M=256, N=64, H=64, W=64):
     mx = int(lens.max())
     t_k = timed(lambda: U.N.call("hpc_rll_pad_forward", dev, table.data_ptr(), new_x.data_ptr(), mask.data_ptr(), n, 1, 1, mx, 0), n=5)
     report("pad1d_kernel", f"n={n} len~U[32,128)", t_k, 4 * int(lens.sum()) + 8 * n * mx)
+    n1m = 1 << 20
+    lens1m = torch.from_numpy(np.random.default_rng(1).integers(32, 128, n1m)).to(dev)
+    flat1m = torch.randn(int(lens1m.sum().item()), device=dev)
+    t_pk = timed(lambda: P.Padding1DPacked(flat1m, lens1m, max_len=127), n=3)
+    report("pad1d_packed_api", f"n={n1m} len~U[32,128) (device table, no host loop)", t_pk, 4 * flat1m.numel() + 8 * n1m * 127)
     t_api = timed(lambda: P.Padding1D(xs), n=1, rounds=2)
     rows.append(dict(op="pad1d_python_api", shape=f"n={n}", fwd_ms=t_api * 1e3, note="list-of-tensors API incl. host table build"))
     print(json.dumps(rows[-1]), flush=True)
