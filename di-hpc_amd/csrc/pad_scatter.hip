@@ -203,12 +203,12 @@ __global__ __launch_bounds__(256) void scatter_out_kernel(const float* __restric
 // 4 consecutive cells x 4 channels per thread step: four float4 gathers, a 4x4 register transpose, four float4
 // nontemporal stores (1 KiB per wave-store instead of 256 B).  Needs HW % 4 == 0, N % 4 == 0, 16-byte aligned x/out.
 template <bool ADD>
-__global__ __launch_bounds__(256) void scatter_out4_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(1024) void scatter_out4_kernel(const float* __restrict__ x,
                                                            const int32_t* __restrict__ idx,
                                                            float* __restrict__ out, int M, int N, int HW,
                                                            int n_per_block) {
     const int b = blockIdx.z;
-    const int cell = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int cell = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // blockDim.x = 256 or 1024 (16 KiB runs per plane)
     if (cell >= HW) return;
     const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
     const int32_t* __restrict__ last = head + HW;
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __
 }  // namespace
 }  // namespace hpc_rll
 
+namespace hpc_rll { int g_scatter_threads = 1024; }
 using namespace hpc_rll;
 
 extern "C" int hpc_rll_pad_forward(const int64_t* table, float* new_x, int32_t* mask, int64_t n, int m0, int m1,
@@ -485,14 +486,15 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     if (rc) return rc;
     const bool v4 = (HW % 4) == 0 && (N % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    const int cell_blocks = (int)((HW + (v4 ? 1023 : 255)) / (v4 ? 1024 : 256));
+    const int tpb = (v4 && HW >= 4096) ? g_scatter_threads : 256;   // threads per block of the 4-wide kernel
+    const int cell_blocks = (int)((HW + (v4 ? 4 * tpb - 1 : 255)) / (v4 ? 4 * tpb : 256));
     // enough workgroups to cover the chip: split the channel axis when B * cell_blocks is small
     int n_per_block = N;
     while (n_per_block > 4 && (long)B * cell_blocks * ((N + n_per_block - 1) / n_per_block) < 2048) n_per_block = (n_per_block / 2 + 3) / 4 * 4;
     const dim3 grid(cell_blocks, (N + n_per_block - 1) / n_per_block, B);
     if (v4) {
-        if (add) hipLaunchKernelGGL(scatter_out4_kernel<true>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
-        else hipLaunchKernelGGL(scatter_out4_kernel<false>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
+        if (add) hipLaunchKernelGGL(scatter_out4_kernel<true>, grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
+        else hipLaunchKernelGGL(scatter_out4_kernel<false>, grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
         return last_error();
     }
     const bool vec = (N % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
