@@ -28,6 +28,12 @@ namespace hpc_rll {
 namespace {
 
 constexpr float kNegInf = -3.0e38f;
+constexpr float kFltMax = 3.402823466e38f;
+
+// Masked actions arrive as logits = -inf.  torch.distributions.Categorical (what hpc_rll.origin uses) clamps
+// the normalised logits to the most negative finite float so that p*log p is 0 instead of 0*(-inf) = NaN; clamping
+// the raw logit on load has the same effect (its probability underflows to exactly 0).  NaN passes through.
+__device__ __forceinline__ float clamp_logit(float x) { return x < -kFltMax ? -kFltMax : x; }
 
 // ---- all-reduce butterflies over aligned groups of G lanes: DPP inside a 16-lane row, ds_bpermute above it.
 template <int CTRL> __device__ __forceinline__ float dpp(float x) {
@@ -57,12 +63,13 @@ struct RowSlice {
                 if (c < N) {
                     // logits are read exactly once: nontemporal (streaming) load
                     const vfloat4 t = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(row + c));
-                    x[e * 4 + 0] = t.x; x[e * 4 + 1] = t.y; x[e * 4 + 2] = t.z; x[e * 4 + 3] = t.w;
+                    x[e * 4 + 0] = clamp_logit(t.x); x[e * 4 + 1] = clamp_logit(t.y);
+                    x[e * 4 + 2] = clamp_logit(t.z); x[e * 4 + 3] = clamp_logit(t.w);
                 } else {
                     x[e * 4 + 0] = x[e * 4 + 1] = x[e * 4 + 2] = x[e * 4 + 3] = kNegInf;
                 }
             } else {
-                x[e] = (c < N) ? __builtin_nontemporal_load(row + c) : kNegInf;
+                x[e] = (c < N) ? clamp_logit(__builtin_nontemporal_load(row + c)) : kNegInf;
             }
         }
     }
@@ -213,21 +220,21 @@ __global__ __launch_bounds__(256) void categorical_fwd_long_kernel(const float* 
     for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
         const float* __restrict__ x = logits + row * (long)N;
         float m = kNegInf;
-        for (int c = lane; c < N; c += 64) m = fmaxf(m, x[c]);
+        for (int c = lane; c < N; c += 64) m = fmaxf(m, clamp_logit(x[c]));
         m = wave_max(m);
         float s = 0.f;
-        for (int c = lane; c < N; c += 64) s += expf(x[c] - m);
+        for (int c = lane; c < N; c += 64) s += expf(clamp_logit(x[c]) - m);
         s = wave_sum(s);
         const float lse = m + logf(s);
         float h = 0.f;
         for (int c = lane; c < N; c += 64) {
-            const float lp = x[c] - lse;
+            const float lp = clamp_logit(x[c]) - lse;
             h -= expf(lp) * lp;
         }
         h = wave_sum(h);
         if (lane == 0) {
             const long a = action[row];
-            logp_out[row] = ((a >= 0 && a < N) ? x[a] : 0.f) - lse;
+            logp_out[row] = ((a >= 0 && a < N) ? clamp_logit(x[a]) : 0.f) - lse;
             if (ent_out) ent_out[row] = h;
         }
     }
@@ -247,15 +254,15 @@ __global__ __launch_bounds__(256) void categorical_bwd_long_kernel(const float* 
     for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
         const float* __restrict__ x = logits + row * (long)N;
         float m = kNegInf;
-        for (int c = lane; c < N; c += 64) m = fmaxf(m, x[c]);
+        for (int c = lane; c < N; c += 64) m = fmaxf(m, clamp_logit(x[c]));
         m = wave_max(m);
         float s = 0.f;
-        for (int c = lane; c < N; c += 64) s += expf(x[c] - m);
+        for (int c = lane; c < N; c += 64) s += expf(clamp_logit(x[c]) - m);
         s = wave_sum(s);
         const float lse = m + logf(s);
         float h = 0.f;
         for (int c = lane; c < N; c += 64) {
-            const float lp = x[c] - lse;
+            const float lp = clamp_logit(x[c]) - lse;
             h -= expf(lp) * lp;
         }
         h = wave_sum(h);
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256) void categorical_bwd_long_kernel(const float* 
         const float k2 = (c2 != nullptr) ? u2 * c2[row] : 0.f;
         float* __restrict__ out = grad + row * (long)N;
         for (int c = lane; c < N; c += 64) {
-            const float lp = x[c] - lse;
+            const float lp = clamp_logit(x[c]) - lse;
             const float p = expf(lp);
             out[c] = k1 * (((long)c == a ? 1.f : 0.f) - p) - k2 * p * (lp + h);
         }

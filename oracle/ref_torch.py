@@ -108,9 +108,12 @@ def td_lambda_error(value, reward, weight=None, gamma: float = 0.9, lambda_: flo
 
 
 def _logp_and_entropy(logits: torch.Tensor, action: torch.Tensor):
+    """log pi(a) and entropy of Categorical(logits=...).  Masked actions (logit = -inf) have probability 0 and
+    contribute 0 to the entropy: torch.distributions.Categorical.entropy(), which hpc_rll.origin calls
+    (origin/vtrace.py:76-79, origin/ppo.py:57-61), clamps log p to the most negative finite value before p*log p."""
     logp_all = F.log_softmax(logits, dim=-1)
     logp = logp_all.gather(-1, action.unsqueeze(-1)).squeeze(-1)
-    ent = -(logp_all.exp() * logp_all).sum(-1)
+    ent = -(logp_all.exp() * logp_all.clamp(min=torch.finfo(logp_all.dtype).min)).sum(-1)
     return logp, ent
 
 

@@ -134,7 +134,9 @@ def gen_td_lambda():
 # ---------------------------------------------------------------- V-trace
 def gen_vtrace():
     out = {}
-    cases = [(19, 7, 11, 0.99, 0.95, 1.0, 1.0, 1.0, 0, 1), (12, 5, 33, 0.9, 0.8, 0.7, 1.3, 2.0, 1, 2), (3, 70, 4, 0.99, 1.0, 1.0, 1.0, 1.0, 1, 3)]
+    # last case: action masking, ~25% of the NOT-taken actions carry logit = -inf in both policies
+    cases = [(19, 7, 11, 0.99, 0.95, 1.0, 1.0, 1.0, 0, 1), (12, 5, 33, 0.9, 0.8, 0.7, 1.3, 2.0, 1, 2), (3, 70, 4, 0.99, 1.0, 1.0, 1.0, 1.0, 1, 3),
+             (6, 9, 12, 0.99, 0.95, 1.0, 1.0, 1.0, 1, 4)]
     out["cases"] = np.array(cases, dtype=np.float64)
     coef = (1.0, 0.5, -0.01)
     out["coef"] = np.array(coef)
@@ -142,6 +144,11 @@ def gen_vtrace():
         rng = np.random.default_rng(200 + seed)
         to, bo = rn(rng, T, B, N), rn(rng, T, B, N)
         a = rng.integers(0, N, (T, B)).astype(np.int64)
+        if seed == 4:
+            masked = rng.random((T, B, N)) < 0.25
+            np.put_along_axis(masked, a[..., None], False, axis=-1)
+            to[masked] = -np.inf
+            bo[masked] = -np.inf
         v, r = rn(rng, T + 1, B), rn(rng, T, B)
         w = rng.random((T, B)).astype(np.float32) if has_w else None
         tto, tv = T_(to, True), T_(v, True)
@@ -193,7 +200,8 @@ def gen_upgo():
 def gen_ppo():
     out = {}
     # B, N, clip, use_value_clip, dual_clip(0=None), has_w, seed
-    cases = [(37, 13, 0.2, 1, 0.0, 0, 1), (64, 5, 0.1, 0, 3.0, 1, 2), (5, 130, 0.3, 1, 1.5, 1, 3)]
+    # last case: action masking (-inf logits on ~25% of the not-taken actions)
+    cases = [(37, 13, 0.2, 1, 0.0, 0, 1), (64, 5, 0.1, 0, 3.0, 1, 2), (5, 130, 0.3, 1, 1.5, 1, 3), (40, 10, 0.2, 1, 0.0, 1, 4)]
     out["cases"] = np.array(cases, dtype=np.float64)
     coef = (1.0, 0.5, -0.01)
     out["coef"] = np.array(coef)
@@ -202,6 +210,11 @@ def gen_ppo():
         ln, lo = rn(rng, B, N), rn(rng, B, N)
         lo = (ln + 0.3 * lo).astype(np.float32)       # keep ratios near 1 so both clip branches fire
         a = rng.integers(0, N, (B,)).astype(np.int64)
+        if seed == 4:
+            masked = rng.random((B, N)) < 0.25
+            np.put_along_axis(masked, a[:, None], False, axis=-1)
+            ln[masked] = -np.inf
+            lo[masked] = -np.inf
         vn, vo, adv, ret = rn(rng, B), rn(rng, B), rn(rng, B), rn(rng, B)
         w = rng.random(B).astype(np.float32) if has_w else None
         tln, tvn = T_(ln, True), T_(vn, True)
