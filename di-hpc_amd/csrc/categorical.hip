@@ -126,12 +126,15 @@ __global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* __res
     constexpr int R = RowsPerIter<G, VEC, E>::value;
     const int gl = threadIdx.x % G;
     const int gi = threadIdx.x / G;
-    for (long base = ((long)blockIdx.x * GPB + gi) * R; base < rows; base += (long)gridDim.x * GPB * R) {
+    // row of (iteration block bb, slot k, group gi) = bb + k*GPB + gi: for a fixed k the groups of the whole workgroup
+    // read consecutive rows, i.e. one contiguous span per load instruction whatever G is
+    for (long bb = (long)blockIdx.x * GPB * R; bb < rows; bb += (long)gridDim.x * GPB * R) {
         RowSlice<G, VEC, E> r[R];
         long a[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const long row = (base + k < rows) ? base + k : rows - 1;   // clamp: uniform control flow, store is guarded
+            const long want = bb + (long)k * GPB + gi;
+            const long row = want < rows ? want : rows - 1;   // clamp: uniform control flow, store is guarded
             r[k].load(logits + row * (long)N, N, gl);
             a[k] = action[row];
         }
@@ -143,11 +146,13 @@ __global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* __res
         }
         if (gl == 0) {
 #pragma unroll
-            for (int k = 0; k < R; ++k)
-                if (base + k < rows) {
-                    logp_out[base + k] = lp[k];
-                    if (ent_out) ent_out[base + k] = h[k];
+            for (int k = 0; k < R; ++k) {
+                const long row = bb + (long)k * GPB + gi;
+                if (row < rows) {
+                    logp_out[row] = lp[k];
+                    if (ent_out) ent_out[row] = h[k];
                 }
+            }
         }
     }
 }
@@ -167,13 +172,14 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __res
     const int gi = threadIdx.x / G;
     const float u1 = g1 ? g1[0] : 1.f;
     const float u2 = (c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
-    for (long base = ((long)blockIdx.x * GPB + gi) * R; base < rows; base += (long)gridDim.x * GPB * R) {
+    for (long bb = (long)blockIdx.x * GPB * R; bb < rows; bb += (long)gridDim.x * GPB * R) {
         RowSlice<G, VEC, E> r[R];
         long a[R];
         float k1[R], k2[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const long row = (base + k < rows) ? base + k : rows - 1;
+            const long want = bb + (long)k * GPB + gi;
+            const long row = want < rows ? want : rows - 1;
             r[k].load(logits + row * (long)N, N, gl);
             a[k] = action[row];
             k1[k] = u1 * c1[row];
@@ -183,9 +189,10 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __res
         for (int k = 0; k < R; ++k) {
             float ex[E * VEC], lse, sum, lp, h;
             row_stats<G, VEC, E>(r[k], N, gl, a[k], ex, lse, sum, lp, h);
-            if (base + k >= rows) continue;
+            const long orow = bb + (long)k * GPB + gi;
+            if (orow >= rows) continue;
             const float inv = 1.f / sum;
-            float* __restrict__ out = grad + (base + k) * (long)N;
+            float* __restrict__ out = grad + orow * (long)N;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int c0 = (e * G + gl) * VEC;
@@ -207,6 +214,134 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __res
                 }
             }
         }
+    }
+}
+
+// ---- small action spaces whose rows are not 16-byte multiples (N % 4 != 0, N <= 32: Atari's 6 / 9 / 18, ...).
+// A row-per-group mapping would issue 4-byte loads at odd offsets (measured 1.1-1.9 TB/s).  Instead a workgroup
+// moves 256 consecutive rows as ONE flat, 16-byte aligned stream through LDS (coalesced float4 both ways), and each
+// thread owns one row in LDS (stride N words: conflict free for odd N, 2-way for N = 2 mod 4).
+constexpr int kSmallRows = 256;
+constexpr int kSmallMaxN = 32;
+template <bool BWD>
+__global__ __launch_bounds__(256) void categorical_small_kernel(const float* __restrict__ logits,
+                                                                const int64_t* __restrict__ action,
+                                                                float* __restrict__ logp_out,
+                                                                float* __restrict__ ent_out,
+                                                                const float* __restrict__ c1,
+                                                                const float* __restrict__ g1,
+                                                                const float* __restrict__ c2,
+                                                                const float* __restrict__ g2,
+                                                                float* __restrict__ grad, long rows, int N) {
+    __shared__ __attribute__((aligned(16))) float tile[kSmallRows * kSmallMaxN];
+    const float u1 = (BWD && g1) ? g1[0] : 1.f;
+    const float u2 = (BWD && c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
+    for (long row0 = (long)blockIdx.x * kSmallRows; row0 < rows; row0 += (long)gridDim.x * kSmallRows) {
+        const int nr = (int)((rows - row0 < kSmallRows) ? rows - row0 : kSmallRows);
+        const int total = nr * N;
+        const float* __restrict__ src = logits + row0 * (long)N;   // row0 % 256 == 0 -> 16-byte aligned
+        for (int i = threadIdx.x * 4; i + 3 < total; i += 1024)
+            *reinterpret_cast<vfloat4*>(tile + i) = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(src + i));
+        for (int i = (total & ~3) + threadIdx.x; i < total; i += 256) tile[i] = src[i];
+        __syncthreads();
+        if ((int)threadIdx.x < nr) {
+            float* __restrict__ x = tile + threadIdx.x * N;
+            const long row = row0 + threadIdx.x;
+            const long a = action[row];
+            float m = kNegInf;
+            for (int i = 0; i < N; ++i) m = fmaxf(m, clamp_logit(x[i]));
+            float sum = 0.f;
+            for (int i = 0; i < N; ++i) sum += __expf(clamp_logit(x[i]) - m);
+            const float lse = m + __logf(sum);
+            float h = 0.f;
+            for (int i = 0; i < N; ++i) {
+                const float lp = clamp_logit(x[i]) - lse;
+                h -= __expf(lp) * lp;
+            }
+            if (!BWD) {
+                logp_out[row] = ((a >= 0 && a < N) ? clamp_logit(x[a]) : 0.f) - lse;
+                if (ent_out) ent_out[row] = h;
+            } else {
+                const float k1 = u1 * c1[row];
+                const float k2 = (c2 != nullptr) ? u2 * c2[row] : 0.f;
+                for (int i = 0; i < N; ++i) {
+                    const float lp = clamp_logit(x[i]) - lse;
+                    const float p = __expf(lp);
+                    x[i] = k1 * (((long)i == a ? 1.f : 0.f) - p) - k2 * p * (lp + h);
+                }
+            }
+        }
+        if (BWD) {
+            __syncthreads();
+            float* __restrict__ dst = grad + row0 * (long)N;
+            for (int i = threadIdx.x * 4; i + 3 < total; i += 1024)
+                __builtin_nontemporal_store(*reinterpret_cast<const vfloat4*>(tile + i), reinterpret_cast<vfloat4*>(dst + i));
+            for (int i = (total & ~3) + threadIdx.x; i < total; i += 256) dst[i] = tile[i];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- long rows (N beyond the register path, up to 16384): one workgroup per row, the row is read from HBM ONCE into
+// LDS with coalesced loads and the three passes (max, sum-exp, entropy / gradient) run out of LDS.
+template <bool BWD>
+__global__ __launch_bounds__(256) void categorical_ldsrow_kernel(const float* __restrict__ logits,
+                                                                 const int64_t* __restrict__ action,
+                                                                 float* __restrict__ logp_out,
+                                                                 float* __restrict__ ent_out,
+                                                                 const float* __restrict__ c1,
+                                                                 const float* __restrict__ g1,
+                                                                 const float* __restrict__ c2,
+                                                                 const float* __restrict__ g2,
+                                                                 float* __restrict__ grad, long rows, int N) {
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float u1 = (BWD && g1) ? g1[0] : 1.f;
+    const float u2 = (BWD && c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
+    auto block_reduce = [&](float v, bool is_max) -> float {
+        v = is_max ? wave_max(v) : wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* __restrict__ x = logits + row * (long)N;
+        float m = kNegInf;
+        for (int c = threadIdx.x; c < N; c += 256) {
+            const float v = clamp_logit(__builtin_nontemporal_load(x + c));
+            rowbuf[c] = v;
+            m = fmaxf(m, v);
+        }
+        m = block_reduce(m, true);
+        float s = 0.f;
+        for (int c = threadIdx.x; c < N; c += 256) s += __expf(rowbuf[c] - m);
+        s = block_reduce(s, false);
+        const float lse = m + __logf(s);
+        float h = 0.f;
+        for (int c = threadIdx.x; c < N; c += 256) {
+            const float lp = rowbuf[c] - lse;
+            h -= __expf(lp) * lp;
+        }
+        h = block_reduce(h, false);
+        const long a = action[row];
+        if (!BWD) {
+            if (threadIdx.x == 0) {
+                logp_out[row] = ((a >= 0 && a < N) ? rowbuf[a] : 0.f) - lse;
+                if (ent_out) ent_out[row] = h;
+            }
+        } else {
+            const float k1 = u1 * c1[row];
+            const float k2 = (c2 != nullptr) ? u2 * c2[row] : 0.f;
+            float* __restrict__ out = grad + row * (long)N;
+            for (int c = threadIdx.x; c < N; c += 256) {
+                const float lp = rowbuf[c] - lse;
+                const float p = __expf(lp);
+                __builtin_nontemporal_store(k1 * (((long)c == a ? 1.f : 0.f) - p) - k2 * p * (lp + h), out + c);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -342,8 +477,19 @@ int categorical_forward(const float* logits, const int64_t* action, float* logp,
     if (rows < 0 || N <= 0) return HPC_RLL_EINVAL;
     if (rows == 0) return HPC_RLL_OK;
     if (!logits || !action || !logp) return HPC_RLL_EINVAL;
+    if ((N % 4) != 0 && N <= kSmallMaxN && al16(logits)) {
+        hipLaunchKernelGGL(categorical_small_kernel<false>, dim3(grid_for(rows, kSmallRows)), dim3(256), 0, st, logits,
+                           action, logp, ent, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, rows, N);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? HPC_RLL_OK : (int)e;
+    }
     const RowCfg cfg = row_cfg(N, al16(logits));
-    if (cfg.e > 8 || !launch_fwd(cfg, st, logits, action, logp, ent, rows, N)) {
+    if (cfg.e > 8 && N <= 16384) {
+        hipLaunchKernelGGL(categorical_ldsrow_kernel<false>, dim3(grid_for(rows, 1)), dim3(256), (size_t)N * sizeof(float),
+                           st, logits, action, logp, ent, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, rows, N);
+    } else if (cfg.e > 8 || !launch_fwd(cfg, st, logits, action, logp, ent, rows, N)) {
         hipLaunchKernelGGL(categorical_fwd_long_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, st, logits, action,
                            logp, ent, rows, N);
     }
@@ -356,8 +502,17 @@ int categorical_backward(const float* logits, const int64_t* action, const float
     if (rows < 0 || N <= 0) return HPC_RLL_EINVAL;
     if (rows == 0) return HPC_RLL_OK;
     if (!logits || !action || !c1 || !grad) return HPC_RLL_EINVAL;
+    if ((N % 4) != 0 && N <= kSmallMaxN && al16(logits) && al16(grad)) {
+        hipLaunchKernelGGL(categorical_small_kernel<true>, dim3(grid_for(rows, kSmallRows)), dim3(256), 0, st, logits,
+                           action, (float*)nullptr, (float*)nullptr, c1, g1, c2, g2, grad, rows, N);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? HPC_RLL_OK : (int)e;
+    }
     const RowCfg cfg = row_cfg(N, al16(logits) && al16(grad));
-    if (cfg.e > 8 || !launch_bwd(cfg, st, logits, action, c1, g1, c2, g2, grad, rows, N)) {
+    if (cfg.e > 8 && N <= 16384) {
+        hipLaunchKernelGGL(categorical_ldsrow_kernel<true>, dim3(grid_for(rows, 1)), dim3(256), (size_t)N * sizeof(float),
+                           st, logits, action, (float*)nullptr, (float*)nullptr, c1, g1, c2, g2, grad, rows, N);
+    } else if (cfg.e > 8 || !launch_bwd(cfg, st, logits, action, c1, g1, c2, g2, grad, rows, N)) {
         hipLaunchKernelGGL(categorical_bwd_long_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, st, logits, action,
                            c1, g1, c2, g2, grad, rows, N);
     }

@@ -86,7 +86,8 @@ def test_vtrace_golden(golden):
         assert rel_err(g[f"c{i}_grad_value"], v.grad.cpu().numpy()) < GTOL
 
 
-@pytest.mark.parametrize("T,B,N", [(128, 128, 128), (64, 300, 6), (16, 70, 1000), (9, 33, 2500), (256, 1024, 18), (3, 5, 1)])
+@pytest.mark.parametrize("T,B,N", [(128, 128, 128), (64, 300, 6), (16, 70, 1000), (9, 33, 2500), (256, 1024, 18), (3, 5, 1),
+                                   (5, 7, 9), (40, 100, 4), (3, 11, 5001), (2, 3, 20000), (31, 50, 30), (7, 9, 2)])
 def test_vtrace_oracle(T, B, N):
     from hpc_rll.rl_utils.vtrace import VTrace
     rng = np.random.default_rng(T * 7 + N)
