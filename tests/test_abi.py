@@ -61,3 +61,21 @@ def test_cpu_tensor_is_rejected_loudly():
     v, r, a = torch.zeros(3, 2), torch.zeros(2, 2), torch.zeros(2, 2)
     with pytest.raises(RuntimeError):
         hpc_rl_utils.GaeForward([v, r], [a], 0.99, 0.97)
+
+
+def test_argument_errors_are_status_codes_not_crashes():
+    """Invalid arguments are rejected with a negative status BEFORE any HIP call is made (so this runs without a GPU)."""
+    from hpc_rll import _native
+    L = _native.lib
+    assert L.hpc_rll_gae_forward(None, None, None, None, 4, 4, 0.99, None) == -1            # null pointers
+    assert L.hpc_rll_gae_forward(None, None, None, None, -1, 4, 0.99, None) == -1           # negative size
+    assert L.hpc_rll_gae_backward(None, None, None, None, 4, -2, 0.99, None) == -1
+    assert L.hpc_rll_td_lambda_forward(None, None, None, 3, None, None, None, 4, 4, 0.9, 0.8, 1.0, None) == -1  # bad mode
+    assert L.hpc_rll_vtrace_forward(None, None, None, None, None, None, None, None, 4, 4, 0, 0.9, 0.9, 1., 1., 1., 1., None) == -1
+    assert L.hpc_rll_lstm_forward(None, None, None, None, None, None, None, None, None, None, None, None,
+                                  4, 4, 4, 4096, 1, 0.0, 0, None) == -3                     # H beyond the register path
+    assert L.hpc_rll_pad_forward(None, None, None, 4, 8, 1, 1, 0, None) == -1
+    assert L.hpc_rll_tune_set(99, 1) == -1
+    assert b"invalid argument" in L.hpc_rll_status_string(-1)
+    assert L.hpc_rll_partials_floats(100) >= 100
+    assert L.hpc_rll_vtrace_workspace_floats(10, 20) >= 6 * 200
