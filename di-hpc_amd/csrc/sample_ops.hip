@@ -77,9 +77,13 @@ struct PpoOp {
         float dv = -(r - vn);            // d(0.5 v)/d value_new on the unclipped branch
         if (use_value_clip) {
             const float vo = value_old[i];
-            const float vc = vo + fminf(fmaxf(vn - vo, -clip), clip);
+            const float dvo = vn - vo;
+            const bool saturated = dvo > clip || dvo < -clip;   // d vclip / d value_new = 0 only when the clamp is active
+            const float vc = vo + fminf(fmaxf(dvo, -clip), clip);
             const float v2 = (r - vc) * (r - vc);
-            if (v2 > v) { v = v2; dv = (vc == vn) ? -(r - vn) : 0.f; }
+            // NB: with an inactive clamp vo + (vn - vo) can differ from vn by an ulp in fp32, so v2 may exceed v
+            // although mathematically equal; the gradient must then still flow (found by tests/test_fuzz_gpu.py)
+            if (v2 > v) { v = v2; dv = saturated ? 0.f : -(r - vc); }
         }
         acc[1] = fmaf(v, w, acc[1]);
         gv_unit[i] = dv * w * scale;

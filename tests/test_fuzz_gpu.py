@@ -1,0 +1,217 @@
+"""Randomised differential test: every op on ~25 random small shapes each (seeded, so the run is reproducible), HIP vs
+the fp64 oracle.  Catches tile-edge / raggedness bugs that hand-picked shapes miss (B not a multiple of the column
+tile, T not a multiple of the chunk span, N straddling the row-kernel variants, ...)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+NCASE = 25
+
+
+def G(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def D(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).double()
+    return t.requires_grad_(True) if grad else t
+
+
+def shapes(rng, *ranges):
+    out = []
+    for _ in range(NCASE):
+        out.append(tuple(int(np.exp(rng.uniform(np.log(lo), np.log(hi + 1)))) for lo, hi in ranges))
+    return out
+
+
+def f32(rng, *s):
+    return rng.standard_normal(s).astype(np.float32)
+
+
+def test_fuzz_gae():
+    from hpc_rll.rl_utils.gae import GAE
+    rng = np.random.default_rng(1)
+    for T, B in shapes(rng, (1, 300), (1, 3000)):
+        gam, lam = float(rng.uniform(0.8, 1.0)), float(rng.uniform(0.0, 1.0))
+        v, r, ga = f32(rng, T + 1, B), f32(rng, T, B), f32(rng, T, B)
+        ref = R.gae(D(v), D(r), gam, lam)
+        gv, gr = R.gae_backward(D(ga), gam, lam)
+        dv, dr = G(v, True), G(r, True)
+        adv = GAE(T, B)(dv, dr, gam, lam)
+        adv.backward(G(ga))
+        assert rel_err(ref.numpy(), adv.detach().cpu().numpy()) < 1e-5, (T, B, gam, lam)
+        assert rel_err(gv.numpy(), dv.grad.cpu().numpy()) < 2e-5, (T, B, gam, lam)
+        assert rel_err(gr.numpy(), dr.grad.cpu().numpy()) < 2e-5, (T, B, gam, lam)
+
+
+def test_fuzz_td_lambda():
+    from hpc_rll.rl_utils.td import TDLambda
+    rng = np.random.default_rng(2)
+    for T, B in shapes(rng, (1, 200), (1, 2000)):
+        v, r = f32(rng, T + 1, B), f32(rng, T, B)
+        mode = int(rng.integers(0, 3))
+        w = None if mode == 0 else rng.random((B,) if mode == 1 else (T, B)).astype(np.float32)
+        v64 = D(v, True)
+        l64 = R.td_lambda_error(v64, D(r), None if w is None else D(w), 0.93, 0.85)
+        l64.backward()
+        dv = G(v, True)
+        loss = TDLambda(T, B)(dv, G(r), None if w is None else G(w), 0.93, 0.85)
+        loss.backward()
+        assert rel_err(l64.item(), loss.item()) < 1e-5, (T, B, mode)
+        assert rel_err(v64.grad.numpy(), dv.grad.cpu().numpy()) < 2e-5, (T, B, mode)
+
+
+def test_fuzz_vtrace_upgo():
+    from hpc_rll.rl_utils.upgo import UPGO
+    from hpc_rll.rl_utils.vtrace import VTrace
+    rng = np.random.default_rng(3)
+    for T, B, N in shapes(rng, (1, 60), (1, 200), (1, 300)):
+        to, bo = f32(rng, T, B, N), f32(rng, T, B, N)
+        a = rng.integers(0, N, (T, B)).astype(np.int64)
+        v, r, w = f32(rng, T + 1, B), f32(rng, T, B), rng.random((T, B)).astype(np.float32)
+        clips = [float(c) for c in rng.uniform(0.5, 2.0, 3)]
+        to64, v64 = D(to, True), D(v, True)
+        l64 = R.vtrace_error(to64, D(bo), torch.from_numpy(a), v64, D(r), D(w), 0.99, 0.9, *clips)
+        sum(l64).backward()
+        dto, dv = G(to, True), G(v, True)
+        ls = VTrace(T, B, N)(dto, G(bo), G(a), dv, G(r), G(w), 0.99, 0.9, *clips)
+        sum(ls).backward()
+        assert rel_err([x.item() for x in l64], [x.item() for x in ls]) < 1e-5, (T, B, N)
+        assert rel_err(to64.grad.numpy(), dto.grad.cpu().numpy()) < 2e-5, (T, B, N)
+        assert rel_err(v64.grad.numpy(), dv.grad.cpu().numpy()) < 2e-5, (T, B, N)
+        # UPGO on the same tensors; skip shapes with a knife-edge lambda comparison (fp32 vs fp64 could disagree)
+        margin = np.abs((r[1:] + v[2:]) - v[1:-1]).min() if T > 1 else 1.0
+        if margin > 1e-5:
+            rho = rng.random((T, B)).astype(np.float32)
+            to64 = D(to, True)
+            l64 = R.upgo_loss(to64, D(rho), torch.from_numpy(a), D(r), D(v))
+            l64.backward()
+            dto = G(to, True)
+            loss = UPGO(T, B, N)(dto, G(rho), G(a), G(r), G(v))
+            loss.backward()
+            assert rel_err(l64.item(), loss.item()) < 1e-5, (T, B, N)
+            assert rel_err(to64.grad.numpy(), dto.grad.cpu().numpy()) < 2e-5, (T, B, N)
+
+
+def test_fuzz_ppo():
+    from hpc_rll.rl_utils.ppo import PPO
+    rng = np.random.default_rng(4)
+    for B, N in shapes(rng, (1, 3000), (1, 400)):
+        ln = f32(rng, B, N)
+        lo = (ln + 0.3 * f32(rng, B, N)).astype(np.float32)
+        a = rng.integers(0, N, (B,)).astype(np.int64)
+        vn, vo, adv, ret = f32(rng, B), f32(rng, B), f32(rng, B), f32(rng, B)
+        dual = [None, 2.0][int(rng.integers(0, 2))]
+        uvc = bool(rng.integers(0, 2))
+        ln64, vn64 = D(ln, True), D(vn, True)
+        l64, i64 = R.ppo_error(ln64, D(lo), torch.from_numpy(a), vn64, D(vo), D(adv), D(ret), None, 0.2, uvc, dual)
+        sum(l64).backward()
+        dln, dvn = G(ln, True), G(vn, True)
+        ls, info = PPO(B, N)(dln, G(lo), G(a), dvn, G(vo), G(adv), G(ret), None, 0.2, uvc, dual)
+        sum(ls).backward()
+        assert rel_err([x.item() for x in l64], [x.item() for x in ls]) < 1e-5, (B, N)
+        assert rel_err(ln64.grad.numpy(), dln.grad.cpu().numpy()) < 2e-5, (B, N)
+        assert rel_err(vn64.grad.numpy(), dvn.grad.cpu().numpy()) < 2e-5, (B, N)
+
+
+def test_fuzz_td_family():
+    from hpc_rll.rl_utils.td import QNStepTD, QNStepTDRescale, IQNNStepTDError, QRDQNNStepTDError
+    rng = np.random.default_rng(5)
+    for T, B, N, tau in shapes(rng, (1, 8), (1, 300), (1, 40), (1, 80)):
+        a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+        r, done, w = f32(rng, T, B), (rng.random(B) < 0.3).astype(np.float32), rng.random(B).astype(np.float32)
+        q, nq = f32(rng, B, N), f32(rng, B, N)
+        for resc, cls in ((False, QNStepTD), (True, QNStepTDRescale)):
+            q64 = D(q, True)
+            l64, p64 = R.q_nstep_td_error(q64, D(nq), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(w), 0.97, resc)
+            l64.backward()
+            dq = G(q, True)
+            loss, per = cls(T, B, N)(dq, G(nq), G(a), G(na), G(r), G(done), G(w), 0.97)
+            loss.backward()
+            assert rel_err(l64.item(), loss.item()) < 2e-5, (T, B, N, resc)
+            assert rel_err(p64.detach().numpy(), per.cpu().numpy()) < 2e-5
+            assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+        taup = max(1, tau // 2 + 1)
+        q3, nq3 = f32(rng, tau, B, N), f32(rng, taup, B, N)
+        rq = rng.random((tau, B)).astype(np.float32)
+        q64 = D(q3, True)
+        l64, p64 = R.iqn_nstep_td_error(q64, D(nq3), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(rq), D(w), 0.97, 0.8)
+        l64.backward()
+        dq = G(q3, True)
+        loss, per = IQNNStepTDError(tau, taup, T, B, N)(dq, G(nq3), G(a), G(na), G(r), G(done), G(rq), 0.97, 0.8, G(w))
+        loss.backward()
+        assert rel_err(l64.item(), loss.item()) < 2e-5, ("iqn", tau, taup, T, B, N)
+        assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+        q4, nq4 = f32(rng, B, N, tau), f32(rng, B, N, tau)
+        q64 = D(q4, True)
+        l64, p64 = R.qrdqn_nstep_td_error(q64, D(nq4), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), tau, D(w), 0.97)
+        l64.backward()
+        dq = G(q4, True)
+        loss, per = QRDQNNStepTDError(tau, T, B, N)(dq, G(nq4), G(a), G(na), G(r), G(done), 0.97, G(w))
+        loss.backward()
+        assert rel_err(l64.item(), loss.item()) < 2e-5, ("qrdqn", tau, T, B, N)
+        assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+
+
+def test_fuzz_scatter_and_padding():
+    from hpc_rll.rl_utils import padding as P
+    from hpc_rll.torch_utils.network.scatter_connection import ScatterConnection
+    rng = np.random.default_rng(6)
+    for B, M, N, H, W in shapes(rng, (1, 20), (1, 120), (1, 70), (1, 40), (1, 40)):
+        x = f32(rng, B, M, N)
+        loc = np.stack([rng.integers(0, H, (B, M)), rng.integers(0, W, (B, M))], -1).astype(np.int64)
+        go = f32(rng, B, N, H, W)
+        for st in ("cover", "add"):
+            xo = torch.from_numpy(x).requires_grad_(True)
+            oo = R.scatter_connection(xo, torch.from_numpy(loc), H, W, st)
+            oo.backward(torch.from_numpy(go))
+            xd = G(x, True)
+            od = ScatterConnection(B, M, N, H, W, st)(xd, G(loc))
+            od.backward(G(go))
+            assert torch.equal(od.detach().cpu(), oo.detach()), (B, M, N, H, W, st)
+            assert torch.equal(xd.grad.cpu(), xo.grad), (B, M, N, H, W, st)
+    for rank in (1, 2, 3):
+        for _ in range(8):
+            n = int(rng.integers(1, 40))
+            xs = [torch.from_numpy(f32(rng, *[int(rng.integers(1, 12)) for _ in range(rank)])).to(DEV) for _ in range(n)]
+            pad = {1: P.Padding1D, 2: P.Padding2D, 3: P.Padding3D}[rank]
+            unpad = {1: P.UnPadding1D, 2: P.UnPadding2D, 3: P.UnPadding3D}[rank]
+            value = int(rng.integers(-3, 4))
+            new_x, mask, shp = pad(xs, value=value)
+            ox, om, _ = R.pad([t.cpu() for t in xs], value)
+            assert torch.equal(new_x.cpu(), ox) and torch.equal(mask.cpu(), om.to(torch.int32))
+            assert all(torch.equal(a, b) for a, b in zip(xs, unpad(new_x, shp)))
+
+
+def test_fuzz_lstm():
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    rng = np.random.default_rng(7)
+    for S, B, I, H, L in shapes(rng, (1, 6), (1, 70), (1, 40), (1, 70), (1, 3))[:12]:
+        torch.manual_seed(S * 100 + B)
+        m = LSTM(S, B, I, H, L).to(DEV)
+        with torch.no_grad():
+            m.ln_gamma.add_(0.1 * torch.randn_like(m.ln_gamma))
+            m.ln_beta.add_(0.1 * torch.randn_like(m.ln_beta))
+        x, h0, c0 = f32(rng, S, B, I), f32(rng, L, B, H), f32(rng, L, B, H)
+        dx = G(x, True)
+        y, (hn, cn) = m(dx, (G(h0), G(c0)))
+        (y.sum() + hn.sum() * 0.5 - cn.sum()).backward()
+        G4 = 4 * H
+        off, wx = 0, []
+        for l in range(L):
+            k = (I if l == 0 else H) * G4
+            wx.append(m.wx.detach().cpu().double()[off:off + k].reshape(-1, G4))
+            off += k
+        wh = [m.wh.detach().cpu().double()[l * H * G4:(l + 1) * H * G4].reshape(H, G4) for l in range(L)]
+        ox = D(x, True)
+        oy, oh, oc = R.lstm(ox, D(h0), D(c0), wx, wh, m.bias.detach().cpu().double().reshape(L, G4),
+                            m.ln_gamma.detach().cpu().double(), m.ln_beta.detach().cpu().double())
+        (oy.sum() + oh.sum() * 0.5 - oc.sum()).backward()
+        assert rel_err(oy.detach().numpy(), y.detach().cpu().numpy()) < 2e-5, (S, B, I, H, L)
+        assert rel_err(ox.grad.numpy(), dx.grad.cpu().numpy()) < 2e-4, (S, B, I, H, L)
