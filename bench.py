@@ -8,6 +8,8 @@ followed by ``adv.backward(grad_adv)`` through the drop-in ``hpc_rll.rl_utils.ga
 kernels behind the C ABI).  Inputs are resident in HBM before the timed region.  The batch axis shards
 across ranks with NO data-path collective (every trajectory is independent), so per-GPU
 work is fixed as N grows: weak scaling; ``value`` = (N * T * B) * K / max-over-ranks wall time.
+``--scaling strong`` splits a fixed global batch instead (SURVEY.md 8d asks for both readings) and ``--graph``
+replays the step from a captured hipGraph -- the launch-latency regime strong scaling ends up in.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline     -- dominant kernel's algorithmic bytes per launch / its average launch duration measured
@@ -74,6 +76,10 @@ def main():
     ap.add_argument("--T", type=int, default=T_DEFAULT)
     ap.add_argument("--B", type=int, default=B_DEFAULT, help="batch per GPU")
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): B per GPU fixed; strong: --B is the GLOBAL batch, split over the ranks")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one fwd+bwd step in a hipGraph and replay it (the latency regime: small B per GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,6 +101,9 @@ def main():
     from hpc_rll.rl_utils.gae import GAE
 
     T, B, gamma, lam = args.T, args.B, 0.99, 0.97
+    if args.scaling == "strong":
+        assert B % world == 0, "strong scaling: the global batch must divide by the number of ranks"
+        B //= world
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     value = torch.randn(T + 1, B, device=dev, generator=g).requires_grad_(True)
     reward = torch.randn(T, B, device=dev, generator=g).requires_grad_(True)
@@ -111,6 +120,20 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.graph:   # same kernels, same order; only the host-side launch path changes (one hipGraphLaunch per step)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        value.grad = None
+        reward.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gae(value, reward, gamma, lam).backward(grad_adv)
+        step = graph.replay  # noqa: F811
 
     for _ in range(args.warmup):
         step()
@@ -169,13 +192,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"GAE fwd+bwd, T={T}, B={B} per GPU, fp32 (BASELINE.json configs[1])",
                        "T": T, "B_per_gpu": B, "global_B": B * world,
-                       "parallelism": f"batch-sharded x{world}, no data-path collective"},
+                       "parallelism": f"batch-sharded x{world}, no data-path collective",
+                       "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_launch / t_dom / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bytes_launch / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_launch,

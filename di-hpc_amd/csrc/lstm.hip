@@ -281,11 +281,17 @@ inline void launch_cell_bwd(int H, int B, hipStream_t st, Args... a) {
     else hipLaunchKernelGGL(lstm_cell_bwd_kernel<8>, dim3(B), dim3(256), 0, st, a..., H);
 }
 
+}  // namespace
+}  // namespace hpc_rll
+#include "lstm_persist.hpp"
+namespace hpc_rll {
+namespace {
+
 // workspace carving --------------------------------------------------------------------------------------------
 struct LayerWs { float *xw, *hw, *gates, *c, *hseq, *stats, *xin_next; };
 struct Ws {
     LayerWs layer[16];
-    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part;
+    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg;
     size_t total;
 };
 inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
@@ -312,6 +318,7 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.dseq_a = take(widest);
     w.dseq_b = take(widest);
     w.colpart = take((size_t)kColChunks * 3 * G);
+    w.xchg = take(2 * xchg_layout(B, H).total_words);   // persistent small-batch path: {value, tag} words
     w.total = off;
     return w;
 }
@@ -344,6 +351,10 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
     const size_t SB = (size_t)S * B, G = 4 * (size_t)H, BH = (size_t)B * H;
     const Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
     size_t wx_off = 0;
+    PersistCfg pc{};
+    const bool persist = S > 0 && persist_cfg(B, H, H, &pc);
+    const XchgLayout xl = xchg_layout(B, H);
+    if (persist && hipMemsetAsync(w.xchg, 0, xl.total_words * sizeof(u64), st) != hipSuccess) return last_error();
     for (int l = 0; l < L; ++l) {
         const int in_l = l == 0 ? I : H;
         const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
@@ -354,7 +365,18 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
             GemmArgs g{xin, wx_l, lw.xw, (int)SB, (int)G, in_l, in_l, 1, (long)G, 1, (long)G, 0};
             launch_gemm(g, st);
         }
-        for (int s = 0; s < S; ++s) {
+        if (persist) {   // one kernel walks the whole sequence of this layer (lstm_persist.hpp)
+            hipLaunchKernelGGL(lstm_rowstats_kernel, dim3((unsigned)SB), dim3(256), 0, st, (const float*)lw.xw, (int)G,
+                               lw.stats);
+            PersistFwd a{lw.xw, wh_l, bias + (size_t)l * G, ln_gamma + (size_t)l * 2 * G, ln_beta + (size_t)l * 2 * G,
+                         h0 + (size_t)l * BH, c0 + (size_t)l * BH, lw.hw, lw.gates, lw.c, lw.hseq, lw.stats,
+                         (u64*)w.xchg, (u64*)w.xchg + 2 * xl.big_par, S, B, H, pc.nwg, g_lstm_xchg_rep,
+                         xl.big_par, xl.sums_par, xl.big_rep, xl.sums_rep, (uint32_t)((size_t)l * S), persist_prof()};
+            const int prc = launch_persist_fwd(pc, a, st);
+            if (prc) return prc;
+            persist_prof_report("fwd", l, S, st);
+        }
+        for (int s = 0; s < S && !persist; ++s) {
             const float* h_prev = s == 0 ? h0 + (size_t)l * BH : lw.hseq + (size_t)(s - 1) * BH;
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
             float* hw_s = lw.hw + (size_t)s * B * G;
@@ -414,6 +436,10 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
     const float* d_out = dy;   // may be null (no gradient through y)
     float* seq_bufs[2] = {w.dseq_a, w.dseq_b};
     int flip = 0;
+    PersistCfg pc{};
+    const bool persist = persist_cfg(B, H, 4 * H, &pc);
+    const XchgLayout xl = xchg_layout(B, H);
+    if (persist && hipMemsetAsync(w.xchg, 0, xl.total_words * sizeof(u64), st) != hipSuccess) return last_error();
     for (int l = L - 1; l >= 0; --l) {
         const int in_l = l == 0 ? I : H;
         const LayerWs& lw = w.layer[l];
@@ -425,7 +451,16 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         const float* dc_carry = dcn ? dcn + (size_t)l * BH : nullptr;
         int dh_parts = 1;                                   // how many split-K partials dh_carry consists of
         const int sk_dh = gemm_skinny_splitk(B, H, (int)G);
-        for (int s = S - 1; s >= 0; --s) {
+        if (persist) {   // one kernel walks the whole sequence of this layer backwards (lstm_persist.hpp)
+            PersistBwd a{d_out, dh_carry, dc_carry, lw.gates, lw.c, c0 + (size_t)l * BH, lw.xw, lw.hw, lw.stats, gamma_l,
+                         wh_l, w.dgate, w.dxw, w.dhw, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, (u64*)w.xchg,
+                         (u64*)w.xchg + 2 * xl.big_par, S, B, H, pc.nwg, g_lstm_xchg_rep, xl.big_par,
+                         xl.sums_par, xl.big_rep, xl.sums_rep, (uint32_t)((size_t)(L - 1 - l) * S), persist_prof()};
+            const int prc = launch_persist_bwd(pc, a, st);
+            if (prc) return prc;
+            persist_prof_report("bwd", l, S, st);
+        }
+        for (int s = S - 1; s >= 0 && !persist; --s) {
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
             launch_cell_bwd(H, B, st, d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dh_parts,
                             (long)BH, dc_carry,
@@ -444,9 +479,11 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         }
         int rc = last_error();
         if (rc) return rc;
-        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((BH + 255) / 256)), dim3(256), 0, st, (const float*)w.dh,
-                           dh_parts, (long)BH, dh0 + (size_t)l * BH);
-        if ((rc = copy_async(dc0 + (size_t)l * BH, w.dc, BH, st))) return rc;
+        if (!persist) {
+            hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((BH + 255) / 256)), dim3(256), 0, st,
+                               (const float*)w.dh, dh_parts, (long)BH, dh0 + (size_t)l * BH);
+            if ((rc = copy_async(dc0 + (size_t)l * BH, w.dc, BH, st))) return rc;
+        }
         // dWh (H,G) = [h0 ; hseq[0..S-2]]^T @ dHW
         {
             GemmArgs g0{h0 + (size_t)l * BH, w.dhw, dwh + (size_t)l * H * G, H, (int)G, B, 1, (long)H, (long)G, 1,

@@ -64,6 +64,14 @@ def _cpu_worker(rank, world, port, q):
     D.all_reduce_losses_(info, None, sharded=True, mean_slots=(3, 4))
     gathered = D.all_gather_batch(sh["reward"], 1)                 # (T, B/R) shards -> (T, B) on every rank
     assert torch.equal(gathered, d["reward"])
+    # bucketed gradient all-reduce (LSTM weight gradients): several buckets, mixed shapes, one None grad
+    ps = [torch.nn.Parameter(torch.zeros(s)) for s in [(3, 4), (5,), (2, 2, 2), (7,)]]
+    for i, p in enumerate(ps[:3]):
+        p.grad = torch.full(p.shape, float(rank + 1) * (i + 1))
+    D.all_reduce_grads_(ps, None, bucket_bytes=64)
+    assert all(torch.equal(p.grad, torch.full(p.shape, 3.0 * (i + 1))) for i, p in enumerate(ps[:3])) and ps[3].grad is None
+    D.all_reduce_grads_(ps, None, average=True)
+    assert all(torch.equal(p.grad, torch.full(p.shape, 3.0 * (i + 1))) for i, p in enumerate(ps[:3]))
     q.put((rank, loss.item(), v.grad.numpy(), three.numpy(), info.numpy()))
     dist.destroy_process_group()
 
@@ -123,7 +131,18 @@ def _gpu_worker(rank, world, port, q):
     l3 = VTrace(T, B // world, N, sharded=True)(to, sh["behaviour"], sh["action"], v, sh["reward"])
     (l1 + sum(l3)).sum().backward()
     adv = GAE(T, B // world)(sh["value"], sh["reward"])          # no collective
-    q.put((rank, l1.item(), [x.item() for x in l3], v.grad.cpu().numpy(), to.grad.cpu().numpy(), adv.cpu().numpy()))
+    # batch-sharded LSTM: activations stay local, the weight gradients are summed in one bucketed all-reduce
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    S, LB, I, H, L = 6, 8, 10, 12, 2
+    torch.manual_seed(11)
+    m = LSTM(S, LB // world, I, H, L).to(dev)
+    x = torch.randn(S, LB, I, generator=torch.Generator().manual_seed(5))
+    xs = D.shard_batch(x, 1, rank, world).to(dev).requires_grad_(True)
+    y, _ = m(xs, None)
+    y.sum().backward()
+    D.all_reduce_grads_(list(m.parameters()), None)
+    lstm = [p.grad.cpu().numpy() for p in m.parameters()] + [xs.grad.cpu().numpy()]
+    q.put((rank, l1.item(), [x.item() for x in l3], v.grad.cpu().numpy(), to.grad.cpu().numpy(), adv.cpu().numpy(), lstm))
     dist.destroy_process_group()
 
 
@@ -150,8 +169,20 @@ def test_gpu_two_ranks_match_single_process():
     l3 = VTrace(T, B, N)(to, d["behaviour"], d["action"], v, d["reward"])
     (l1 + sum(l3)).sum().backward()
     adv = GAE(T, B)(d["value"], d["reward"]).cpu().numpy()
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    S, LB, I, H, L = 6, 8, 10, 12, 2
+    torch.manual_seed(11)
+    m = LSTM(S, LB, I, H, L).to(dev)
+    x = torch.randn(S, LB, I, generator=torch.Generator().manual_seed(5)).to(dev).requires_grad_(True)
+    y, _ = m(x, None)
+    y.sum().backward()
+    full = [p.grad.cpu().numpy() for p in m.parameters()]
     k = B // world
-    for rank, r1, r3, gv, gt, radv in res:
+    for rank, r1, r3, gv, gt, radv, lstm in res:
+        for a, b in zip(full, lstm[:-1]):                       # summed weight gradients == full-batch gradients
+            assert rel_err(a, b) < 1e-5
+        kb = LB // world
+        assert rel_err(x.grad.cpu().numpy()[:, rank * kb:(rank + 1) * kb], lstm[-1]) < 1e-5
         assert rel_err(l1.item(), r1) < 1e-6
         assert rel_err([x.item() for x in l3], r3) < 1e-6
         assert rel_err(v.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gv) < 1e-6

@@ -180,3 +180,57 @@ def test_lstm_dropout():
     yg, _ = m(xg, None)
     yg.sum().backward()
     assert torch.isfinite(xg.grad).all() and xg.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("S,B,I,H,L", [(64, 3, 1792, 384, 3), (9, 8, 40, 1024, 2), (7, 5, 12, 1000, 2), (5, 1, 7, 65, 1),
+                                       (12, 2, 16, 257, 2), (4, 7, 5, 3, 3), (3, 4, 8, 512, 1)])
+def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
+    """B <= 8 runs the persistent per-layer kernels (lstm_persist.hpp); hpc_rll_tune_set(3, 0) forces the step-kernel
+    path (GEMM + cell kernel per step).  Same math, different summation order in the recurrent products, and fp32
+    rounding is amplified along the S*L chain of LayerNorms, so the two paths are compared through the fp64 oracle:
+    the persistent path must be as close to it as the step path is (factor 2), or within the base tolerance."""
+    import hpc_rll._native as N
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(S * 131 + H)
+    m = LSTM(S, B, I, H, L).to(DEV)
+    with torch.no_grad():
+        m.ln_gamma.add_(0.1 * torch.randn_like(m.ln_gamma))
+        m.ln_beta.add_(0.1 * torch.randn_like(m.ln_beta))
+        m.bias.add_(0.1 * torch.randn_like(m.bias))
+    x = torch.randn(S, B, I, device=DEV)
+    h0, c0 = torch.randn(L, B, H, device=DEV), torch.randn(L, B, H, device=DEV)
+    gy, gh, gc = torch.randn(S, B, H, device=DEV), torch.randn(L, B, H, device=DEV), torch.randn(L, B, H, device=DEV)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        xs, hs, cs = (t.clone().requires_grad_(True) for t in (x, h0, c0))
+        y, (hn, cn) = m(xs, (hs, cs))
+        ((y * gy).sum() + (hn * gh).sum() + (cn * gc).sum()).backward()
+        return [t.detach().double().cpu().numpy() for t in (y, hn, cn, xs.grad, hs.grad, cs.grad, m.wx.grad,
+                                                            m.wh.grad, m.bias.grad, m.ln_gamma.grad, m.ln_beta.grad)]
+
+    try:
+        N.check(N.lib.hpc_rll_tune_set(3, 0), "tune_set")
+        step = run()
+    finally:
+        N.check(N.lib.hpc_rll_tune_set(3, 1), "tune_set")
+    pers = run()
+    dims = [I] + [H] * L
+    offs = np.cumsum([0] + [d * 4 * H for d in dims])
+    leaf = lambda t: t.detach().double().cpu().requires_grad_(True)  # noqa: E731
+    ox, oh, oc = leaf(x), leaf(h0), leaf(c0)
+    wxf = m.wx.detach().double().cpu()
+    owx = [wxf[offs[l]:offs[l + 1]].reshape(dims[l], 4 * H).clone().requires_grad_(True) for l in range(L)]
+    owh = [w.clone().requires_grad_(True) for w in m.wh.detach().double().cpu().reshape(L, H, 4 * H)]
+    ob, og, obe = leaf(m.bias.reshape(L, 4 * H)), leaf(m.ln_gamma), leaf(m.ln_beta)
+    oy, ohn, ocn = R.lstm(ox, oh, oc, owx, owh, ob, og, obe)
+    ((oy * gy.double().cpu()).sum() + (ohn * gh.double().cpu()).sum() + (ocn * gc.double().cpu()).sum()).backward()
+    orc = [oy, ohn, ocn, ox.grad, oh.grad, oc.grad, torch.cat([w.grad.reshape(-1) for w in owx]),
+           torch.cat([w.grad.reshape(-1) for w in owh]), ob.grad.reshape(-1), og.grad, obe.grad]
+    names = "y hn cn dx dh0 dc0 dwx dwh dbias dgamma dbeta".split()
+    for k, a, b, o in zip(names, step, pers, orc):
+        o = o.detach().numpy().reshape(a.shape)
+        assert np.isfinite(b).all(), k
+        base = 1e-5 if k in ("y", "hn", "cn") else 2e-4
+        assert rel_err(o, b) < max(base, 2.0 * rel_err(o, a)), (k, rel_err(o, b), rel_err(o, a))
