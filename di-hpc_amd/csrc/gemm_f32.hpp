@@ -37,7 +37,7 @@ struct GemmArgs {
     long b_sk, b_sn;   // B(k,n) = B[k*b_sk + n*b_sn]
     long ldc;
     int accumulate;    // C += A*B instead of C = A*B
-    int splitk = 1;    // > 1 (skinny path only): gridDim.z slices of K, slice z writes its PARTIAL product to
+    int splitk = 1;    // > 1: gridDim.z slices of K (gemm_splitk), slice z writes its PARTIAL product to
     long c_split = 0;  //      C + z*c_split; the consumer adds the slices in a fixed order (deterministic)
 };
 
@@ -245,13 +245,40 @@ inline void launch_gemm_tile(const GemmArgs& g, int am, int bm, hipStream_t st) 
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, kGeneric, kGeneric>), grid, dim3(256), 0, st, g);
 }
 
-// Number of K slices worth using for a skinny (M <= 32) product so that ~48+ workgroups share the weight stream
-// (a handful of workgroups walking a long K serially is latency bound: 12 k-tiles ~ 10 us).  1 for everything else.
-inline int gemm_skinny_splitk(int M, int N, int K) {
-    if (M > 32) return 1;
-    const int ntiles = (N + 127) / 128, ktiles = (K + 31) / 32;
+// Tile shape launch_gemm picks for an (M, N) problem.
+struct GemmTile { int bm, bn; };
+inline GemmTile gemm_tile_of(int M, int N) {
+    // Enough workgroups to keep >= 2 resident per CU (256 CUs): a lone 128x128 workgroup per CU cannot overlap its
+    // own staging with its MFMAs.
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const long t64 = (long)((M + 127) / 128) * ((N + 63) / 64);
+    if (M <= 32) return {32, 128};   // skinny: the 4 waves side by side along N
+    if (t128 >= 512) return {128, 128};
+    if (t64 >= 512 || M > 64) return {128, 64};
+    return {64, 64};
+}
+
+// Number of K slices worth using when the output tiles alone cannot fill the 256 CUs (the per-step recurrent
+// products of the LSTM at B <~ 1024: a handful of workgroups walking a long K serially is latency bound -- measured
+// 98 us per step for dHW(64x2048) @ Wh^T on 8 workgroups).  Slices write partial products; the consumer sums them in
+// a fixed order.  Every slice keeps >= 2 k-tiles of 32.
+inline int gemm_splitk(int M, int N, int K) {
+    const GemmTile t = gemm_tile_of(M, N);
+    const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+    const int ktiles = (K + 31) / 32;
     int s = 1;
-    while (s < 16 && ntiles * s < 48 && ktiles / (s * 2) >= 2) s *= 2;
+    while (s < 16 && tiles * s < 256 && ktiles / (s * 2) >= 2) s *= 2;
+    return s;
+}
+
+// The same for the large once-per-layer products with a long K (the weight gradients, K = S*B): fill the chip with
+// ~2 workgroups per CU but keep >= 16 k-tiles per slice; the partial products are summed by a reduction kernel.
+inline int gemm_splitk_big(int M, int N, int K) {
+    const GemmTile t = gemm_tile_of(M, N);
+    const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+    const int ktiles = (K + 31) / 32;
+    int s = 1;
+    while (s < 16 && tiles * s < 512 && ktiles / (s * 2) >= 16) s *= 2;
     return s;
 }
 
@@ -259,19 +286,16 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return;
     const int am = gemm_mode(g.A, g.a_sm, g.a_sk, g.M, g.K);
     const int bm = gemm_mode(g.B, g.b_sn, g.b_sk, g.N, g.K);
-    // Enough workgroups to keep >= 2 resident per CU (256 CUs): a lone 128x128 workgroup per CU cannot overlap its
-    // own staging with its MFMAs.
-    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    const long t64 = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
     extern int g_gemm_bk;   // tuning knob (hpc_rll_tune_set key 1): 16 / 32, 0 = by layout
     // measured at the LSTM shapes: NN runs better with BK = 16 (4-5 workgroups resident per CU: 108 vs 94 TFLOP/s on
     // the recurrent GEMM), TN (K = S*B) with BK = 32 (103 vs 79), NT is indifferent
     const int bk = g_gemm_bk ? g_gemm_bk : ((am == kContigK && bm == kContigMN) ? 16 : 32);
-    if (g.M <= 32) launch_gemm_tile<32, 128, 32, 1, 1>(g, am, bm, st);   // skinny: the 4 waves side by side along N
-    else if (t128 >= 512) {
+    const GemmTile t = gemm_tile_of(g.M, g.N);
+    if (t.bm == 32) launch_gemm_tile<32, 128, 32, 1, 1>(g, am, bm, st);
+    else if (t.bm == 128 && t.bn == 128) {
         if (bk == 16) launch_gemm_tile<128, 128, 16, 2, 2>(g, am, bm, st);
         else launch_gemm_tile<128, 128, 32, 2, 2>(g, am, bm, st);
-    } else if (t64 >= 512 || g.M > 64) {
+    } else if (t.bm == 128) {
         if (bk == 16) launch_gemm_tile<128, 64, 16, 2, 1>(g, am, bm, st);
         else launch_gemm_tile<128, 64, 32, 2, 1>(g, am, bm, st);
     } else launch_gemm_tile<64, 64, 32, 1, 1>(g, am, bm, st);

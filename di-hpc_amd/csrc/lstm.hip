@@ -72,15 +72,61 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             x[q][g] = (j < H) ? xr[g * H + j] : 0.f;
-            float hv = 0.f;
-            if (j < H) {
-                hv = hr[g * H + j];
-                for (int z = 1; z < nsplit; ++z) hv += hr[(size_t)z * part_stride + g * H + j];   // fixed order
-                if (nsplit > 1) hw_out[(size_t)b * G + g * H + j] = hv;
+            h[q][g] = (j < H) ? hr[g * H + j] : 0.f;
+        }
+    }
+    // split-K partials: summed in slice order (deterministic).  The slice loop is outermost and takes ZC slices
+    // per round so that 4*ZC*JPT loads are in flight together (element by element this was ~10 us of dependent round
+    // trips at nsplit = 8).
+    constexpr int ZC = JPT <= 2 ? 4 : JPT <= 4 ? 2 : 1;   // slices per round (register budget)
+    for (int z = 1; z < nsplit; z += ZC) {
+        float p[ZC][JPT][4];
+#pragma unroll
+        for (int zz = 0; zz < ZC; ++zz)
+#pragma unroll
+            for (int q = 0; q < JPT; ++q) {
+                const int j = threadIdx.x + q * 256;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    p[zz][q][g] = (j < H && z + zz < nsplit) ? hr[(size_t)(z + zz) * part_stride + g * H + j] : 0.f;
             }
-            h[q][g] = hv;
+#pragma unroll
+        for (int zz = 0; zz < ZC; ++zz)
+#pragma unroll
+            for (int q = 0; q < JPT; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (z + zz < nsplit) h[q][g] += p[zz][q][g];
+    }
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) {
+        const int j = threadIdx.x + q * 256;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (nsplit > 1 && j < H) hw_out[(size_t)b * G + g * H + j] = h[q][g];
             s[0] += x[q][g];
             s[1] += h[q][g];
+        }
+    }
+    // parameters and c_prev do not depend on the reductions: fetch them now so their latency hides behind the two
+    // block sums (at small B this kernel is a chain of memory round trips, not arithmetic)
+    constexpr bool kPrefetch = JPT <= 2;
+    float pgx[kPrefetch ? JPT : 1][4], pgh[kPrefetch ? JPT : 1][4], pbs[kPrefetch ? JPT : 1][4], pc[kPrefetch ? JPT : 1];
+    float pbx[kPrefetch ? JPT : 1][4], pbh[kPrefetch ? JPT : 1][4];
+    if (kPrefetch) {
+#pragma unroll
+        for (int q = 0; q < JPT; ++q) {
+            const int j = threadIdx.x + q * 256;
+            pc[q] = (j < H) ? c_prev[(size_t)b * H + j] : 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = g * H + j;
+                pgx[q][g] = (j < H) ? gamma[col] : 0.f;
+                pgh[q][g] = (j < H) ? gamma[G + col] : 0.f;
+                pbs[q][g] = (j < H) ? bias[col] : 0.f;
+                pbx[q][g] = (j < H) ? beta[col] : 0.f;
+                pbh[q][g] = (j < H) ? beta[G + col] : 0.f;
+            }
         }
     }
     block_allsum<2>(s, red);
@@ -112,14 +158,18 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = g * H + j;
-                a[g] = (x[q][g] - mx) * rx * gamma[col] + beta[col] + (h[q][g] - mh) * rh * gamma[G + col] +
-                       beta[G + col] + bias[col];
+                const float gxv = kPrefetch ? pgx[kPrefetch ? q : 0][g] : gamma[col];
+                const float ghv = kPrefetch ? pgh[kPrefetch ? q : 0][g] : gamma[G + col];
+                const float bv = kPrefetch ? pbs[kPrefetch ? q : 0][g] : bias[col];
+                const float bxv = kPrefetch ? pbx[kPrefetch ? q : 0][g] : beta[col];
+                const float bhv = kPrefetch ? pbh[kPrefetch ? q : 0][g] : beta[G + col];
+                a[g] = (x[q][g] - mx) * rx * gxv + bxv + (h[q][g] - mh) * rh * ghv + bhv + bv;
             }
             const float ig = 1.f / (1.f + expf(-a[0]));
             const float fg = 1.f / (1.f + expf(-a[1]));
             const float og = 1.f / (1.f + expf(-a[2]));
             const float ug = tanhf(a[3]);
-            const float c = fg * c_prev[(size_t)b * H + j] + ig * ug;
+            const float c = fg * (kPrefetch ? pc[kPrefetch ? q : 0] : c_prev[(size_t)b * H + j]) + ig * ug;
             float* gr = gates + (size_t)b * G;
             gr[j] = ig; gr[H + j] = fg; gr[2 * H + j] = og; gr[3 * H + j] = ug;
             c_out[(size_t)b * H + j] = c;
@@ -145,6 +195,29 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
     const float mx = st[0], rx = st[1], mh = st[2], rh = st[3];
     float da[JPT][4], xh[JPT][4], hh[JPT][4];   // gate adjoint, normalised x-branch, normalised h-branch
     float r[4] = {0.f, 0.f, 0.f, 0.f};          // sum dy_g (x), sum dy_g*xhat (x), same for h
+    float dh_tot[JPT];                          // dh = dh_a + sum of the split-K partials, in slice order
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) {
+        const int j = threadIdx.x + q * 256;
+        dh_tot[q] = (dh_a && j < H) ? dh_a[(size_t)b * H + j] : 0.f;
+    }
+    if (dh_b) {
+        for (int z = 0; z < nsplit; z += 4) {   // four slices (4*JPT loads) in flight per round
+            float p[4][JPT];
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+                for (int q = 0; q < JPT; ++q) {
+                    const int j = threadIdx.x + q * 256;
+                    p[zz][q] = (j < H && z + zz < nsplit) ? dh_b[(size_t)(z + zz) * part_stride + (size_t)b * H + j] : 0.f;
+                }
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+                for (int q = 0; q < JPT; ++q)
+                    if (z + zz < nsplit) dh_tot[q] += p[zz][q];
+        }
+    }
 #pragma unroll
     for (int q = 0; q < JPT; ++q) {
         const int j = threadIdx.x + q * 256;
@@ -152,9 +225,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
             const size_t o = (size_t)b * H + j;
             const float* gr = gates + (size_t)b * G;
             const float ig = gr[j], fg = gr[H + j], og = gr[2 * H + j], ug = gr[3 * H + j];
-            float dh = dh_a ? dh_a[o] : 0.f;
-            if (dh_b)
-                for (int z = 0; z < nsplit; ++z) dh += dh_b[(size_t)z * part_stride + o];
+            const float dh = dh_tot[q];
             const float tc = tanhf(c_new[o]);
             const float dc = (dc_in ? dc_in[o] : 0.f) + dh * og * (1.f - tc * tc);
             da[q][0] = dc * ug * ig * (1.f - ig);
@@ -291,7 +362,7 @@ namespace {
 struct LayerWs { float *xw, *hw, *gates, *c, *hseq, *stats, *xin_next; };
 struct Ws {
     LayerWs layer[16];
-    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg;
+    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg, *wpart;
     size_t total;
 };
 inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
@@ -311,14 +382,25 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.dgate = take(SB * G);
     w.dxw = take(SB * G);
     w.dhw = take(SB * G);
-    w.dh = take((size_t)16 * B * H);            // up to 16 split-K partials of dh_prev
-    w.hw_part = take((size_t)16 * B * G);       // up to 16 split-K partials of h @ Wh
+    w.dh = take((size_t)gemm_splitk(B, H, (int)G) * B * H);        // split-K partials of dh_prev = dHW @ Wh^T
+    w.hw_part = take((size_t)gemm_splitk(B, (int)G, H) * B * G);   // split-K partials of h @ Wh
     w.dc = take((size_t)B * H);
     const size_t widest = SB * (size_t)(I > H ? I : H);
     w.dseq_a = take(widest);
     w.dseq_b = take(widest);
     w.colpart = take((size_t)kColChunks * 3 * G);
     w.xchg = take(2 * xchg_layout(B, H).total_words);   // persistent small-batch path: {value, tag} words
+    {   // split-K partials of the weight gradients (dWh: 1 + sk parts, dWx: sk parts), largest layer
+        size_t need = 0;
+        const int skh = S > 1 ? gemm_splitk_big(H, (int)G, (int)((S - 1) * (size_t)B)) : 1;
+        if (skh > 1) need = (size_t)(skh + 1) * H * G;
+        for (int l = 0; l < L; ++l) {
+            const int in_l = l == 0 ? I : H;
+            const int skx = gemm_splitk_big(in_l, (int)G, (int)SB);
+            if (skx > 1 && (size_t)skx * in_l * G > need) need = (size_t)skx * in_l * G;
+        }
+        w.wpart = take(need);
+    }
     w.total = off;
     return w;
 }
@@ -380,7 +462,7 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
             const float* h_prev = s == 0 ? h0 + (size_t)l * BH : lw.hseq + (size_t)(s - 1) * BH;
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
             float* hw_s = lw.hw + (size_t)s * B * G;
-            const int sk = gemm_skinny_splitk(B, (int)G, H);
+            const int sk = gemm_splitk(B, (int)G, H);
             GemmArgs g{h_prev, wh_l, sk > 1 ? w.hw_part : hw_s, B, (int)G, H, H, 1, (long)G, 1, (long)G, 0, sk,
                        (long)((size_t)B * G)};
             launch_gemm(g, st);
@@ -450,7 +532,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         const float* dh_carry = dhn ? dhn + (size_t)l * BH : nullptr;
         const float* dc_carry = dcn ? dcn + (size_t)l * BH : nullptr;
         int dh_parts = 1;                                   // how many split-K partials dh_carry consists of
-        const int sk_dh = gemm_skinny_splitk(B, H, (int)G);
+        const int sk_dh = gemm_splitk(B, H, (int)G);
         if (persist) {   // one kernel walks the whole sequence of this layer backwards (lstm_persist.hpp)
             PersistBwd a{d_out, dh_carry, dc_carry, lw.gates, lw.c, c0 + (size_t)l * BH, lw.xw, lw.hw, lw.stats, gamma_l,
                          wh_l, w.dgate, w.dxw, w.dhw, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, (u64*)w.xchg,
@@ -484,21 +566,34 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
                                (const float*)w.dh, dh_parts, (long)BH, dh0 + (size_t)l * BH);
             if ((rc = copy_async(dc0 + (size_t)l * BH, w.dc, BH, st))) return rc;
         }
-        // dWh (H,G) = [h0 ; hseq[0..S-2]]^T @ dHW
+        // dWh (H,G) = [h0 ; hseq[0..S-2]]^T @ dHW ; dWx (in,G) = xin^T @ dXW.  K = S*B is long and the output tiles
+        // alone may not fill the chip: slices of K go to partial buffers, summed in slice order (deterministic).
         {
-            GemmArgs g0{h0 + (size_t)l * BH, w.dhw, dwh + (size_t)l * H * G, H, (int)G, B, 1, (long)H, (long)G, 1,
+            const size_t HG = (size_t)H * G;
+            const int skh = S > 1 ? gemm_splitk_big(H, (int)G, (int)((S - 1) * (size_t)B)) : 1;
+            float* dwh_l = dwh + (size_t)l * HG;
+            GemmArgs g0{h0 + (size_t)l * BH, w.dhw, skh > 1 ? w.wpart : dwh_l, H, (int)G, B, 1, (long)H, (long)G, 1,
                         (long)G, 0};
             launch_gemm(g0, st);
             if (S > 1) {
-                GemmArgs g1{lw.hseq, w.dhw + (size_t)B * G, dwh + (size_t)l * H * G, H, (int)G, (int)((S - 1) * (size_t)B),
-                            1, (long)H, (long)G, 1, (long)G, 1};
+                GemmArgs g1{lw.hseq, w.dhw + (size_t)B * G, skh > 1 ? w.wpart + HG : dwh_l, H, (int)G,
+                            (int)((S - 1) * (size_t)B), 1, (long)H, (long)G, 1, (long)G, skh > 1 ? 0 : 1, skh,
+                            (long)HG};
                 launch_gemm(g1, st);
             }
+            if (skh > 1)
+                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((HG + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, skh + 1, (long)HG, dwh_l);
         }
-        // dWx (in,G) = xin^T @ dXW
         {
-            GemmArgs g{xin, w.dxw, dwx + wx_offs[l], in_l, (int)G, (int)SB, 1, (long)in_l, (long)G, 1, (long)G, 0};
+            const size_t IG = (size_t)in_l * G;
+            const int skx = gemm_splitk_big(in_l, (int)G, (int)SB);
+            GemmArgs g{xin, w.dxw, skx > 1 ? w.wpart : dwx + wx_offs[l], in_l, (int)G, (int)SB, 1, (long)in_l, (long)G, 1,
+                       (long)G, 0, skx, (long)IG};
             launch_gemm(g, st);
+            if (skx > 1)
+                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((IG + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, skx, (long)IG, dwx + wx_offs[l]);
         }
         // d xin (S*B, in) = dXW @ Wx^T : B(k=g, n=i) = Wx[i*G + g]
         float* dxin = l == 0 ? dx : seq_bufs[flip];
