@@ -39,6 +39,7 @@ struct GemmArgs {
     int accumulate;    // C += A*B instead of C = A*B
     int splitk = 1;    // > 1: gridDim.z slices of K (gemm_splitk), slice z writes its PARTIAL product to
     long c_split = 0;  //      C + z*c_split; the consumer adds the slices in a fixed order (deterministic)
+    int big = 0;       // 1: a long-K product that brings its own split-K (gemm_splitk_big): 128x128 tiles
 };
 
 enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2 };
@@ -137,8 +138,16 @@ struct TileStage {
 };
 
 // BM x BN x BK block tile, 256 threads.  WM x WN = MFMA blocks per wave; waves arranged (BM/(32*WM)) x (BN/(32*WN)).
+// Resident workgroups per CU the LDS footprint allows (160 KB per CU); the register allocation is steered to match
+// (launch_bounds' second argument = waves per SIMD): at 136 registers the 128x128x16 tile ran 3 workgroups per CU, so
+// a 1024-tile product (the C4 recurrent GEMM) ran as 768 + a 256-workgroup tail at one workgroup per CU.
+template <int BM, int BN, int BK> struct GemmOcc {
+    static constexpr int lds = 2 * BK * (BM + BN) * 4;
+    static constexpr int value = lds <= 36 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : 2;
+};
+
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int WAVES_M = BM / (32 * WM);
     static_assert(WAVES_M * (BN / (32 * WN)) == 4, "4 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
@@ -267,18 +276,32 @@ inline int gemm_splitk(int M, int N, int K) {
     const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
     const int ktiles = (K + 31) / 32;
     int s = 1;
-    while (s < 16 && tiles * s < 256 && ktiles / (s * 2) >= 2) s *= 2;
-    return s;
+    while (s < 16 && tiles * s < 256 && ktiles / (s * 2) >= 2) s *= 2;    // latency regime: fill the CUs at all
+    while (s < 16 && tiles * s < 768 && ktiles / (s * 2) >= 32) s *= 2;   // throughput regime: 3-4 workgroups per CU
+    return s;                                                             // while the slices stay long (C4 dh: 2)
 }
 
 // The same for the large once-per-layer products with a long K (the weight gradients, K = S*B): fill the chip with
 // ~2 workgroups per CU but keep >= 16 k-tiles per slice; the partial products are summed by a reduction kernel.
+inline GemmTile gemm_tile_big(int M, int N, int K) {
+    extern int g_gemm_big_tile128;   // tuning knobs (hpc_rll_tune_set keys 7, 6)
+    extern int g_gemm_big_target;
+    if (g_gemm_big_tile128 && M > 64 && N > 64) {   // 128x128 only if its split-K can still reach the target
+        const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+        const int ktiles = (K + 31) / 32;
+        int s = 1;
+        while (s < 16 && ktiles / (s * 2) >= 16) s *= 2;
+        if (tiles * s >= g_gemm_big_target) return {128, 128};
+    }
+    return gemm_tile_of(M, N);
+}
 inline int gemm_splitk_big(int M, int N, int K) {
-    const GemmTile t = gemm_tile_of(M, N);
+    const GemmTile t = gemm_tile_big(M, N, K);
     const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
     const int ktiles = (K + 31) / 32;
+    extern int g_gemm_big_target;   // tuning knob (hpc_rll_tune_set key 6)
     int s = 1;
-    while (s < 16 && tiles * s < 512 && ktiles / (s * 2) >= 16) s *= 2;
+    while (s < 16 && tiles * s < g_gemm_big_target && ktiles / (s * 2) >= 16) s *= 2;
     return s;
 }
 
@@ -288,9 +311,11 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     const int bm = gemm_mode(g.B, g.b_sn, g.b_sk, g.N, g.K);
     extern int g_gemm_bk;   // tuning knob (hpc_rll_tune_set key 1): 16 / 32, 0 = by layout
     // measured at the LSTM shapes: NN runs better with BK = 16 (4-5 workgroups resident per CU: 108 vs 94 TFLOP/s on
-    // the recurrent GEMM), TN (K = S*B) with BK = 32 (103 vs 79), NT is indifferent
-    const int bk = g_gemm_bk ? g_gemm_bk : ((am == kContigK && bm == kContigMN) ? 16 : 32);
-    const GemmTile t = gemm_tile_of(g.M, g.N);
+    // the recurrent GEMM), NT is indifferent; the long-K weight-gradient products (TN, `big`) run 128x128x16 tiles
+    // with their own split-K (4 workgroups per CU in one round: C4 backward 179 -> 171 ms vs 128x64x32)
+    const GemmTile t = g.big ? gemm_tile_big(g.M, g.N, g.K) : gemm_tile_of(g.M, g.N);
+    const int bk = g_gemm_bk ? g_gemm_bk
+                             : (((am == kContigK && bm == kContigMN) || (g.big && t.bm == 128 && t.bn == 128)) ? 16 : 32);
     if (t.bm == 32) launch_gemm_tile<32, 128, 32, 1, 1>(g, am, bm, st);
     else if (t.bm == 128 && t.bn == 128) {
         if (bk == 16) launch_gemm_tile<128, 128, 16, 2, 2>(g, am, bm, st);

@@ -26,6 +26,8 @@
 
 namespace hpc_rll {
 int g_gemm_bk = 0;
+int g_gemm_big_tile128 = 1;
+int g_gemm_big_target = 768;   // workgroups the split-K of the weight-gradient GEMMs aims for
 namespace {
 
 constexpr float kLnEps = 1e-5f;
@@ -578,7 +580,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             if (S > 1) {
                 GemmArgs g1{lw.hseq, w.dhw + (size_t)B * G, skh > 1 ? w.wpart + HG : dwh_l, H, (int)G,
                             (int)((S - 1) * (size_t)B), 1, (long)H, (long)G, 1, (long)G, skh > 1 ? 0 : 1, skh,
-                            (long)HG};
+                            (long)HG, 1};
                 launch_gemm(g1, st);
             }
             if (skh > 1)
@@ -589,7 +591,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             const size_t IG = (size_t)in_l * G;
             const int skx = gemm_splitk_big(in_l, (int)G, (int)SB);
             GemmArgs g{xin, w.dxw, skx > 1 ? w.wpart : dwx + wx_offs[l], in_l, (int)G, (int)SB, 1, (long)in_l, (long)G, 1,
-                       (long)G, 0, skx, (long)IG};
+                       (long)G, 0, skx, (long)IG, 1};
             launch_gemm(g, st);
             if (skx > 1)
                 hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((IG + 255) / 256)), dim3(256), 0, st,
