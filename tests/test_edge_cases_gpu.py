@@ -77,3 +77,45 @@ def test_side_stream_and_graph_capture():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(adv, ref)
+
+
+def test_hip_graph_capture_replay():
+    """Launch-bound loops are meant to be replayed from a hipGraph (bench.py --graph): every entry point only
+    enqueues work on the caller's stream (no host synchronisation, no allocation behind torch's back), so a captured
+    step replays bit-identically -- GAE forward+backward through autograd, and the LSTM forward on both of its paths
+    (B=3: persistent per-layer kernels with their exchange-buffer memset; B=12: GEMM + cell kernel per step)."""
+    from hpc_rll.rl_utils.gae import GAE
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    dev = torch.device("cuda:0")
+    T, B = 64, 200
+    v = torch.randn(T + 1, B, device=dev, requires_grad=True)
+    r = torch.randn(T, B, device=dev)
+    ga = torch.randn(T, B, device=dev)
+    gae = GAE(T, B)
+    lstms = [(LSTM(10, b, 24, 48, 2).to(dev), torch.randn(10, b, 24, device=dev)) for b in (3, 12)]
+
+    def step():
+        v.grad = None
+        gae(v, r).backward(ga)
+        return [m(x, None)[0] for m, x in lstms]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            eager = step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager = [t.clone() for t in eager]
+    eager_grad = v.grad.clone()
+    v.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gae(v, r).backward(ga)
+        outs = [m(x, None)[0] for m, x in lstms]
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(v.grad, eager_grad)
+    for a, b in zip(outs, eager):
+        assert torch.equal(a, b)

@@ -156,9 +156,10 @@ def test_lstm_reference_usage_pattern():
     assert torch.equal(out[-1], h[-1])
 
 
-def test_lstm_dropout():
+@pytest.mark.parametrize("B", [16, 4])          # step-kernel path / persistent path
+def test_lstm_dropout(B):
     from hpc_rll.torch_utils.network.rnn import LSTM
-    S, B, I, H, L = 8, 16, 32, 64, 3
+    S, I, H, L = 8, 32, 64, 3
     torch.manual_seed(1)
     m = LSTM(S, B, I, H, L, dropout=0.5).to(DEV)
     x = torch.randn(S, B, I, device=DEV)
