@@ -400,6 +400,10 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
             const int in_l = l == 0 ? I : H;
             const int skx = gemm_splitk_big(in_l, (int)G, (int)SB);
             if (skx > 1 && (size_t)skx * in_l * G > need) need = (size_t)skx * in_l * G;
+            // under-filled x-branch / d(xin) products at small S*B (latency regime): partials + one summation pass
+            const int skf = gemm_splitk((int)SB, (int)G, in_l), skd = gemm_splitk((int)SB, in_l, (int)G);
+            if (skf > 1 && (size_t)skf * SB * G > need) need = (size_t)skf * SB * G;
+            if (skd > 1 && (size_t)skd * SB * in_l > need) need = (size_t)skd * SB * in_l;
         }
         w.wpart = take(need);
     }
@@ -446,8 +450,13 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
         const float* wh_l = wh + (size_t)l * H * G;
         const LayerWs& lw = w.layer[l];
         if (S > 0) {
-            GemmArgs g{xin, wx_l, lw.xw, (int)SB, (int)G, in_l, in_l, 1, (long)G, 1, (long)G, 0};
+            const int skf = gemm_splitk((int)SB, (int)G, in_l);
+            GemmArgs g{xin, wx_l, skf > 1 ? w.wpart : lw.xw, (int)SB, (int)G, in_l, in_l, 1, (long)G, 1, (long)G, 0, skf,
+                       (long)(SB * G)};
             launch_gemm(g, st);
+            if (skf > 1)
+                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((SB * G + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, skf, (long)(SB * G), lw.xw);
         }
         if (persist) {   // one kernel walks the whole sequence of this layer (lstm_persist.hpp)
             hipLaunchKernelGGL(lstm_rowstats_kernel, dim3((unsigned)SB), dim3(256), 0, st, (const float*)lw.xw, (int)G,
@@ -600,8 +609,13 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         // d xin (S*B, in) = dXW @ Wx^T : B(k=g, n=i) = Wx[i*G + g]
         float* dxin = l == 0 ? dx : seq_bufs[flip];
         {
-            GemmArgs g{w.dxw, wx_l, dxin, (int)SB, in_l, (int)G, (long)G, 1, 1, (long)G, (long)in_l, 0};
+            const int skd = gemm_splitk((int)SB, in_l, (int)G);
+            GemmArgs g{w.dxw, wx_l, skd > 1 ? w.wpart : dxin, (int)SB, in_l, (int)G, (long)G, 1, 1, (long)G, (long)in_l,
+                       0, skd, (long)(SB * in_l)};
             launch_gemm(g, st);
+            if (skd > 1)
+                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((SB * in_l + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, skd, (long)(SB * in_l), dxin);
         }
         {
             const int chunks = (int)(SB < (size_t)kColChunks * 8 ? (SB + 7) / 8 : kColChunks);
