@@ -522,7 +522,7 @@ int categorical_backward(const float* logits, const int64_t* action, const float
 
 }  // namespace hpc_rll
 
-namespace hpc_rll { extern int g_gemm_bk; extern int g_scatter_threads; extern int g_lstm_persist; extern int g_lstm_xchg_rep; extern int g_lstm_jw; extern int g_gemm_big_target; extern int g_gemm_big_tile128; }
+namespace hpc_rll { extern int g_gemm_bk; extern int g_scatter_threads; extern int g_lstm_persist; extern int g_lstm_xchg_rep; extern int g_lstm_jw; extern int g_gemm_big_target; extern int g_gemm_big_tile128; extern int g_lstm_wave; }
 extern "C" int hpc_rll_tune_set(int key, int value) {
     if (key == 0 && value >= 1 && value <= 64) { hpc_rll::g_blocks_per_cu = value; return HPC_RLL_OK; }
     if (key == 1 && (value == 0 || value == 16 || value == 32)) { hpc_rll::g_gemm_bk = value; return HPC_RLL_OK; }
@@ -532,6 +532,7 @@ extern "C" int hpc_rll_tune_set(int key, int value) {
     if (key == 5 && (value == 0 || value == 2 || value == 4)) { hpc_rll::g_lstm_jw = value; return HPC_RLL_OK; }
     if (key == 6 && value >= 1 && value <= 4096) { hpc_rll::g_gemm_big_target = value; return HPC_RLL_OK; }
     if (key == 7 && (value == 0 || value == 1)) { hpc_rll::g_gemm_big_tile128 = value; return HPC_RLL_OK; }
+    if (key == 8 && (value == 0 || value == 1)) { hpc_rll::g_lstm_wave = value; return HPC_RLL_OK; }
     return HPC_RLL_EINVAL;
 }
 

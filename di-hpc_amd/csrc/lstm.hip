@@ -357,6 +357,7 @@ inline void launch_cell_bwd(int H, int B, hipStream_t st, Args... a) {
 }  // namespace
 }  // namespace hpc_rll
 #include "lstm_persist.hpp"
+#include "lstm_wave.hpp"
 namespace hpc_rll {
 namespace {
 
@@ -391,7 +392,12 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.dseq_a = take(widest);
     w.dseq_b = take(widest);
     w.colpart = take((size_t)kColChunks * 3 * G);
-    w.xchg = take(2 * xchg_layout(B, H).total_words);   // persistent small-batch path: {value, tag} words
+    {   // persistent small-batch paths: {value, tag} exchange words (per-layer kernels / layer wavefront)
+        size_t words = xchg_layout(B, H).total_words;
+        WaveCfg wc{};
+        if (wave_shape_ok(S, B, H, L, 256, &wc) && wc.hx_words + wc.sx_words > words) words = wc.hx_words + wc.sx_words;
+        w.xchg = take(2 * words);
+    }
     {   // split-K partials of the weight gradients (dWh: 1 + sk parts, dWx: sk parts), largest layer
         size_t need = 0;
         const int skh = S > 1 ? gemm_splitk_big(H, (int)G, (int)((S - 1) * (size_t)B)) : 1;
@@ -439,6 +445,43 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
     const size_t SB = (size_t)S * B, G = 4 * (size_t)H, BH = (size_t)B * H;
     const Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
     size_t wx_off = 0;
+    WaveCfg wc{};
+    if (S > 0 && wave_fwd_ok(S, B, H, L, &wc)) {   // all layers in one launch, as a wavefront (lstm_wave.hpp)
+        const LayerWs& l0 = w.layer[0];
+        {
+            const int skf = gemm_splitk((int)SB, (int)G, I);
+            GemmArgs g{x, wx, skf > 1 ? w.wpart : l0.xw, (int)SB, (int)G, I, I, 1, (long)G, 1, (long)G, 0, skf,
+                       (long)(SB * G)};
+            launch_gemm(g, st);
+            if (skf > 1)
+                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((SB * G + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, skf, (long)(SB * G), l0.xw);
+        }
+        hipLaunchKernelGGL(lstm_rowstats_kernel, dim3((unsigned)SB), dim3(256), 0, st, (const float*)l0.xw, (int)G,
+                           l0.stats);
+        if (hipMemsetAsync(w.xchg, 0, (wc.hx_words + wc.sx_words) * sizeof(u64), st) != hipSuccess) return last_error();
+        const uint32_t thr = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967295.0) : 0u;
+        WaveFwd a{l0.xw, wx, wh, bias, ln_gamma, ln_beta, h0, c0, l0.xw, l0.hw, l0.gates, l0.c, l0.hseq, l0.stats,
+                  (size_t)(w.layer[1].xw - l0.xw), (u64*)w.xchg, (u64*)w.xchg + wc.hx_words, S, B, I, H, L, wc.nwg, seed,
+                  thr, dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f};
+        int rc = launch_wave_fwd(wc, a, st);
+        if (rc) return rc;
+        for (int l = 0; l < L; ++l) {
+            const LayerWs& lw = w.layer[l];
+            if ((rc = copy_async(hn + (size_t)l * BH, lw.hseq + (size_t)(S - 1) * BH, BH, st))) return rc;
+            if ((rc = copy_async(cn + (size_t)l * BH, lw.c + (size_t)(S - 1) * BH, BH, st))) return rc;
+            if (dropout_p > 0.f && l < L - 1) {   // the dropped-out sequence the backward GEMMs read
+                const long n = (long)(SB * H);
+                long blocks = (n + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)lw.hseq,
+                                   lw.xin_next, n, seed + 0x1000003ull * (uint64_t)(l + 1), thr,
+                                   1.f / (1.f - dropout_p));
+            }
+        }
+        if ((rc = copy_async(y, w.layer[L - 1].hseq, SB * H, st))) return rc;
+        return last_error();
+    }
     PersistCfg pc{};
     const bool persist = S > 0 && persist_cfg(B, H, H, &pc);
     const XchgLayout xl = xchg_layout(B, H);

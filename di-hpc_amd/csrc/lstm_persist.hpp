@@ -78,6 +78,7 @@ __device__ __forceinline__ void xchg_get(const u64* base, const int (&idx)[NL], 
             return;
         }
         if (++spins > kSpinLimit) __builtin_trap();
+        __builtin_amdgcn_s_sleep(8);   // failed poll: back off (~0.2 us) so that co-resident waves get the memory queue
     }
 }
 

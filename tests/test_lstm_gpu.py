@@ -175,6 +175,14 @@ def test_lstm_dropout(B):
     torch.manual_seed(5)
     y2, _ = m(x, None)
     assert torch.equal(y1, y2)                         # same seed -> same mask
+    import hpc_rll._native as N
+    try:                                               # every path draws the same stateless-hash mask
+        N.check(N.lib.hpc_rll_tune_set(3, 0), "tune_set")
+        torch.manual_seed(5)
+        y3, _ = m(x, None)
+    finally:
+        N.check(N.lib.hpc_rll_tune_set(3, 1), "tune_set")
+    assert rel_err(y3.detach().cpu().numpy(), y1.detach().cpu().numpy()) < 1e-5
     assert not torch.equal(y1, y0) and torch.isfinite(y1).all()
     xg = x.clone().requires_grad_(True)
     torch.manual_seed(5)
