@@ -365,7 +365,7 @@ namespace {
 struct LayerWs { float *xw, *hw, *gates, *c, *hseq, *stats, *xin_next; };
 struct Ws {
     LayerWs layer[16];
-    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg, *wpart;
+    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg, *wpart, *dwave;
     size_t total;
 };
 inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
@@ -396,7 +396,10 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
         size_t words = xchg_layout(B, H).total_words;
         WaveCfg wc{};
         if (wave_shape_ok(S, B, H, L, 256, &wc) && wc.hx_words + wc.sx_words > words) words = wc.hx_words + wc.sx_words;
+        const bool wb = wave_bwd_shape_ok(S, B, H, L, 256, &wc);
+        if (wb && 2 * wc.hx_words + wc.sx_words > words) words = 2 * wc.hx_words + wc.sx_words;
         w.xchg = take(2 * words);
+        w.dwave = take(wb ? (size_t)L * 3 * SB * G : 0);   // per-layer dgate/dXW/dHW (all layers are live at once)
     }
     {   // split-K partials of the weight gradients (dWh: 1 + sk parts, dWx: sk parts), largest layer
         size_t need = 0;
@@ -576,6 +579,80 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
     const bool persist = persist_cfg(B, H, 4 * H, &pc);
     const XchgLayout xl = xchg_layout(B, H);
     if (persist && hipMemsetAsync(w.xchg, 0, xl.total_words * sizeof(u64), st) != hipSuccess) return last_error();
+    // weight / parameter gradients of layer l from its gate-gradient buffers, and (if `dxin`) d(layer input)
+    auto layer_grads = [&](int l, const float* p_dgate, const float* p_dxw, const float* p_dhw, float* dxin) {
+        const int in_l = l == 0 ? I : H;
+        const LayerWs& lw = w.layer[l];
+        const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
+        const float* wx_l = wx + wx_offs[l];
+        // dWh (H,G) = [h0 ; hseq[0..S-2]]^T @ dHW ; dWx (in,G) = xin^T @ dXW.  K = S*B is long and the output tiles
+        // alone may not fill the chip: slices of K go to partial buffers, summed in slice order (deterministic).
+        {
+            const size_t HG = (size_t)H * G;
+            const int skh = S > 1 ? gemm_splitk_big(H, (int)G, (int)((S - 1) * (size_t)B)) : 1;
+            float* dwh_l = dwh + (size_t)l * HG;
+            GemmArgs g0{h0 + (size_t)l * BH, p_dhw, skh > 1 ? w.wpart : dwh_l, H, (int)G, B, 1, (long)H, (long)G, 1,
+                        (long)G, 0};
+            launch_gemm(g0, st);
+            if (S > 1) {
+                GemmArgs g1{lw.hseq, p_dhw + (size_t)B * G, skh > 1 ? w.wpart + HG : dwh_l, H, (int)G,
+                            (int)((S - 1) * (size_t)B), 1, (long)H, (long)G, 1, (long)G, skh > 1 ? 0 : 1, skh,
+                            (long)HG, 1};
+                launch_gemm(g1, st);
+            }
+            if (skh > 1)
+                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((HG + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, skh + 1, (long)HG, dwh_l);
+        }
+        {
+            const size_t IG = (size_t)in_l * G;
+            const int skx = gemm_splitk_big(in_l, (int)G, (int)SB);
+            GemmArgs g{xin, p_dxw, skx > 1 ? w.wpart : dwx + wx_offs[l], in_l, (int)G, (int)SB, 1, (long)in_l, (long)G, 1,
+                       (long)G, 0, skx, (long)IG, 1};
+            launch_gemm(g, st);
+            if (skx > 1)
+                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((IG + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, skx, (long)IG, dwx + wx_offs[l]);
+        }
+        // d xin (S*B, in) = dXW @ Wx^T : B(k=g, n=i) = Wx[i*G + g]
+        if (dxin) {
+            const int skd = gemm_splitk((int)SB, in_l, (int)G);
+            GemmArgs g{p_dxw, wx_l, skd > 1 ? w.wpart : dxin, (int)SB, in_l, (int)G, (long)G, 1, 1, (long)G, (long)in_l,
+                       0, skd, (long)(SB * in_l)};
+            launch_gemm(g, st);
+            if (skd > 1)
+                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((SB * in_l + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, skd, (long)(SB * in_l), dxin);
+        }
+        {
+            const int chunks = (int)(SB < (size_t)kColChunks * 8 ? (SB + 7) / 8 : kColChunks);
+            hipLaunchKernelGGL(lstm_colreduce_kernel, dim3((unsigned)((G + 63) / 64), chunks), dim3(256), 0, st,
+                               (const float*)p_dgate, (const float*)lw.xw, (const float*)lw.hw,
+                               (const float*)lw.stats, (long)SB, (int)G, w.colpart);
+            hipLaunchKernelGGL(lstm_colfinal_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st,
+                               (const float*)w.colpart, chunks, (int)G, dbias + (size_t)l * G,
+                               dln_gamma + (size_t)l * 2 * G, dln_beta + (size_t)l * 2 * G);
+        }
+    };
+    WaveCfg wb{};
+    if (wave_bwd_shape_ok(S, B, H, L, persist_cu_count(), &wb) && w.dwave) {   // all layers in one launch (lstm_wave.hpp)
+        const size_t words = 2 * wb.hx_words + wb.sx_words;
+        if (hipMemsetAsync(w.xchg, 0, words * sizeof(u64), st) != hipSuccess) return last_error();
+        const LayerWs& l0 = w.layer[0];
+        const size_t SBG = SB * G;
+        const uint32_t thr = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967295.0) : 0u;
+        WaveBwd a{dy, dhn, dcn, l0.gates, l0.c, l0.xw, l0.hw, l0.stats, (size_t)(w.layer[1].xw - l0.xw), c0, ln_gamma, wx, wh,
+                  w.dwave, w.dwave + SBG, w.dwave + 2 * SBG, 3 * SBG, dh0, dc0, (u64*)w.xchg, (u64*)w.xchg + wb.hx_words,
+                  (u64*)w.xchg + 2 * wb.hx_words, S, B, I, H, L, wb.nwg, seed, thr,
+                  dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f};
+        int rc = launch_wave_bwd(wb, a, st);
+        if (rc) return rc;
+        for (int l = L - 1; l >= 0; --l) {
+            const float* base = w.dwave + (size_t)l * 3 * SBG;
+            layer_grads(l, base, base + SBG, base + 2 * SBG, l == 0 ? dx : nullptr);
+        }
+        return last_error();
+    }
     for (int l = L - 1; l >= 0; --l) {
         const int in_l = l == 0 ? I : H;
         const LayerWs& lw = w.layer[l];
@@ -620,55 +697,8 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
                                (const float*)w.dh, dh_parts, (long)BH, dh0 + (size_t)l * BH);
             if ((rc = copy_async(dc0 + (size_t)l * BH, w.dc, BH, st))) return rc;
         }
-        // dWh (H,G) = [h0 ; hseq[0..S-2]]^T @ dHW ; dWx (in,G) = xin^T @ dXW.  K = S*B is long and the output tiles
-        // alone may not fill the chip: slices of K go to partial buffers, summed in slice order (deterministic).
-        {
-            const size_t HG = (size_t)H * G;
-            const int skh = S > 1 ? gemm_splitk_big(H, (int)G, (int)((S - 1) * (size_t)B)) : 1;
-            float* dwh_l = dwh + (size_t)l * HG;
-            GemmArgs g0{h0 + (size_t)l * BH, w.dhw, skh > 1 ? w.wpart : dwh_l, H, (int)G, B, 1, (long)H, (long)G, 1,
-                        (long)G, 0};
-            launch_gemm(g0, st);
-            if (S > 1) {
-                GemmArgs g1{lw.hseq, w.dhw + (size_t)B * G, skh > 1 ? w.wpart + HG : dwh_l, H, (int)G,
-                            (int)((S - 1) * (size_t)B), 1, (long)H, (long)G, 1, (long)G, skh > 1 ? 0 : 1, skh,
-                            (long)HG, 1};
-                launch_gemm(g1, st);
-            }
-            if (skh > 1)
-                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((HG + 255) / 256)), dim3(256), 0, st,
-                                   (const float*)w.wpart, skh + 1, (long)HG, dwh_l);
-        }
-        {
-            const size_t IG = (size_t)in_l * G;
-            const int skx = gemm_splitk_big(in_l, (int)G, (int)SB);
-            GemmArgs g{xin, w.dxw, skx > 1 ? w.wpart : dwx + wx_offs[l], in_l, (int)G, (int)SB, 1, (long)in_l, (long)G, 1,
-                       (long)G, 0, skx, (long)IG, 1};
-            launch_gemm(g, st);
-            if (skx > 1)
-                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((IG + 255) / 256)), dim3(256), 0, st,
-                                   (const float*)w.wpart, skx, (long)IG, dwx + wx_offs[l]);
-        }
-        // d xin (S*B, in) = dXW @ Wx^T : B(k=g, n=i) = Wx[i*G + g]
         float* dxin = l == 0 ? dx : seq_bufs[flip];
-        {
-            const int skd = gemm_splitk((int)SB, in_l, (int)G);
-            GemmArgs g{w.dxw, wx_l, skd > 1 ? w.wpart : dxin, (int)SB, in_l, (int)G, (long)G, 1, 1, (long)G, (long)in_l,
-                       0, skd, (long)(SB * in_l)};
-            launch_gemm(g, st);
-            if (skd > 1)
-                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((SB * in_l + 255) / 256)), dim3(256), 0, st,
-                                   (const float*)w.wpart, skd, (long)(SB * in_l), dxin);
-        }
-        {
-            const int chunks = (int)(SB < (size_t)kColChunks * 8 ? (SB + 7) / 8 : kColChunks);
-            hipLaunchKernelGGL(lstm_colreduce_kernel, dim3((unsigned)((G + 63) / 64), chunks), dim3(256), 0, st,
-                               (const float*)w.dgate, (const float*)lw.xw, (const float*)lw.hw,
-                               (const float*)lw.stats, (long)SB, (int)G, w.colpart);
-            hipLaunchKernelGGL(lstm_colfinal_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st,
-                               (const float*)w.colpart, chunks, (int)G, dbias + (size_t)l * G,
-                               dln_gamma + (size_t)l * 2 * G, dln_beta + (size_t)l * 2 * G);
-        }
+        layer_grads(l, w.dgate, w.dxw, w.dhw, dxin);
         if (l > 0) {
             if (dropout_p > 0.f) {   // backward of the dropout between layer l-1 and l: same mask, same scale
                 const long n = (long)(SB * H);

@@ -340,3 +340,324 @@ inline bool wave_fwd_ok(int S, int B, int H, int L, WaveCfg* out) {
 
 }  // namespace
 }  // namespace hpc_rll
+
+// ===================================================================================================== backward
+// Layer l walks s = S-1 .. 0 while layer l-1 is one step behind.  Besides its own dHW_l[s+1] (for dh_prev through
+// Wh^T) it gathers the upper layer's dXW_{l+1}[s] and multiplies it with the rows of Wx_{l+1} that belong to its own
+// hidden units: that is the gradient arriving through the layer output, so no d(xin) GEMM is needed between layers.
+// Every (layer, step) has its own tagged slots for dHW, dXW and the four LayerNorm-adjoint sums.
+namespace hpc_rll {
+namespace {
+
+struct WaveBwd {
+    const float *dy /* (S,B,H) or null */, *dhn, *dcn /* (L,B,H) or null */;
+    const float *gates, *c, *xw, *hw, *stats;   // layer 0 pointers of the saved tensors; layer l at + l*layer_stride
+    size_t layer_stride;
+    const float *c0, *gamma, *wx, *wh;
+    float *dgate, *dxw, *dhw;                   // layer 0 of the per-layer gradient buffers; layer l at + l*grad_stride
+    size_t grad_stride;
+    float *dh0, *dc0;
+    u64 *xhw, *xxw, *xsum;                      // [L][S][B*4H], [L][S][B*4H], [L][S][4*B*nwg] tagged words
+    int S, B, I, H, L, nwg;
+    uint64_t seed;
+    uint32_t drop_threshold;
+    float drop_scale;
+};
+
+template <int NB, int JW>
+__global__ __launch_bounds__(256) void lstm_wave_bwd_kernel(WaveBwd a) {
+    extern __shared__ float smem[];
+    constexpr int GL = RowGroup<NB>::GL, NI = RowGroup<NB>::NI;
+    const int H = a.H, G = 4 * H, B = a.B, nwg = a.nwg, S = a.S, L = a.L;
+    const int l = blockIdx.y;
+    const bool top = l == L - 1;        // d_out = dy; otherwise from the upper layer's dXW
+    float* Wt = smem;                   // [JW][G]  rows of Wh_l of the owned units
+    float* Wxt = Wt + JW * G;           // [JW][G]  rows of Wx_{l+1} of the owned units (not for the top layer)
+    float* dl = Wxt + JW * G;           // [NB][G]  dHW_l[s+1]
+    float* du = dl + NB * G;            // [NB][G]  dXW_{l+1}[s]
+    float* rp = du + NB * G;            // [NB][JW][4]
+    float* rtot = rp + NB * JW * 4;     // [NB][4]
+    float* gp = rtot + NB * 4;          // [4][2][NB*JW] per-wave partials of the two products
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = blockIdx.x * JW;
+    const int nvalid = (H - j0) < JW ? (H - j0) : JW;
+    const size_t BH = (size_t)B * H, BG = (size_t)B * G;
+    const float* wh_l = a.wh + (size_t)l * H * G;
+    const float* wx_up = top ? nullptr : a.wx + (size_t)a.I * G + (size_t)l * H * G;   // Wx of layer l+1: (H, 4H)
+    for (int e = tid; e < JW * G; e += 256) {
+        const int jj = e / G, cc = e - jj * G;
+        const bool ok = jj < nvalid;
+        Wt[e] = ok ? wh_l[(size_t)(j0 + jj) * G + cc] : 0.f;
+        Wxt[e] = (ok && !top) ? wx_up[(size_t)(j0 + jj) * G + cc] : 0.f;
+    }
+    for (int e = tid; e < NB * G; e += 256) dl[e] = du[e] = 0.f;
+    const float* gates_l = a.gates + l * a.layer_stride;
+    const float* c_l = a.c + l * a.layer_stride;
+    const float* xw_l = a.xw + l * a.layer_stride;
+    const float* hw_l = a.hw + l * a.layer_stride;
+    const float* stats_l = a.stats + l * a.layer_stride;
+    float* dgate_l = a.dgate + l * a.grad_stride;
+    float* dxw_l = a.dxw + l * a.grad_stride;
+    float* dhw_l = a.dhw + l * a.grad_stride;
+    const float* gamma_l = a.gamma + (size_t)l * 2 * G;
+
+    const int cb = tid / JW, cjj = tid % JW, cj = j0 + cjj;
+    const bool cell = tid < NB * JW && cb < B && cjj < nvalid;
+    float gx[4] = {0.f, 0.f, 0.f, 0.f}, gh[4] = {0.f, 0.f, 0.f, 0.f};
+    float dh_carry = 0.f, dc_carry = 0.f;
+    if (cell) {
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            gx[gg] = gamma_l[gg * H + cj];
+            gh[gg] = gamma_l[G + gg * H + cj];
+        }
+        if (a.dhn) dh_carry = a.dhn[(size_t)l * BH + (size_t)cb * H + cj];
+        if (a.dcn) dc_carry = a.dcn[(size_t)l * BH + (size_t)cb * H + cj];
+    }
+    const float inv_g = 1.f / (float)G;
+    const int rb = tid / GL, rpart = tid % GL;
+    const bool rgrp = rb < B;
+    u64* const xhw_l = a.xhw + (size_t)l * S * BG;
+    u64* const xxw_l = a.xxw + (size_t)l * S * BG;
+    const u64* const xxw_up = top ? nullptr : a.xxw + (size_t)(l + 1) * S * BG;
+    u64* const xsum_l = a.xsum + (size_t)l * S * (size_t)(4 * B * nwg);
+    const uint64_t dseed = a.seed + 0x1000003ull * (uint64_t)(l + 1);   // dropout applied to this layer's output
+    __syncthreads();
+
+    // step index s runs S-1 .. 0, then one extra pass (s = -1) that only turns dHW_l[0] into dh0
+    for (int s = S - 1; s >= -1; --s) {
+        const uint32_t tag = (uint32_t)(S - 1 - s) + 1u;   // tag of the words published at step s
+        // saved tensors of this step: independent of the exchange, so issued before the poll (their HBM latency
+        // overlaps the wait instead of following it)
+        float sg[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        float sst[4] = {0.f, 0.f, 0.f, 0.f}, c_new = 0.f, c_prev = 0.f, dyv = 0.f;
+        if (cell && s >= 0) {
+            const size_t row = (size_t)s * B + cb;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                sg[gg] = gates_l[row * G + gg * H + cj];
+                sx[gg] = xw_l[row * G + gg * H + cj];
+                sh[gg] = hw_l[row * G + gg * H + cj];
+                sst[gg] = stats_l[row * 4 + gg];
+            }
+            c_new = c_l[row * H + cj];
+            c_prev = s == 0 ? a.c0[(size_t)l * BH + (size_t)cb * H + cj] : c_l[(row - B) * H + cj];
+            if (top && a.dy) dyv = a.dy[row * H + cj];
+        }
+        // ---- one poll round: dHW_l[s+1] (published at the previous step, tag-1) and dXW_{l+1}[s] (tag, upper layer)
+        const int n1 = s < S - 1 ? B * G : 0, n2 = (!top && s >= 0) ? B * G : 0;
+        if (n1 + n2 > 0) {
+            const u64* src1 = xhw_l + (size_t)(s + 1 < S ? s + 1 : 0) * BG;
+            const u64* src2 = n2 ? xxw_up + (size_t)s * BG : nullptr;
+            constexpr int CHB = 16;   // words per thread and poll round (40 = one round at the test shape: +-2 %)
+            for (int e0 = tid; e0 < n1 + n2; e0 += 256 * CHB) {
+                long spins = 0;
+                u64 w[CHB];
+                unsigned long long valid = 0;
+#pragma unroll
+                for (int i = 0; i < CHB; ++i)
+                    if (e0 + 256 * i < n1 + n2) valid |= 1ull << i;
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < CHB; ++i) {
+                        const int e = e0 + 256 * i;
+                        if ((valid >> i) & 1ull) {
+                            const bool first = e < n1;
+                            w[i] = __hip_atomic_load(first ? src1 + e : src2 + (e - n1), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && ((uint32_t)(w[i] >> 32) == (first ? tag - 1u : tag));
+                        }
+                    }
+                    if (ok) break;
+                    if (++spins > kSpinLimit) __builtin_trap();
+                    __builtin_amdgcn_s_sleep(8);
+                }
+#pragma unroll
+                for (int i = 0; i < CHB; ++i) {
+                    const int e = e0 + 256 * i;
+                    if ((valid >> i) & 1ull) {
+                        const float v = __uint_as_float((uint32_t)w[i]);
+                        if (e < n1) dl[e] = v;
+                        else du[e - n1] = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- the two products for the owned units: all 256 threads split the 4H columns
+        {
+            float acc[NB][JW], accu[NB][JW];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int jj = 0; jj < JW; ++jj) acc[b][jj] = accu[b][jj] = 0.f;
+            if (n1 + n2 > 0) {
+#pragma unroll 2
+                for (int cc = tid; cc < G; cc += 256) {
+                    float w1[JW], w2[JW];
+#pragma unroll
+                    for (int jj = 0; jj < JW; ++jj) {
+                        w1[jj] = Wt[jj * G + cc];
+                        w2[jj] = Wxt[jj * G + cc];
+                    }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const float d1 = dl[b * G + cc], d2 = du[b * G + cc];
+#pragma unroll
+                        for (int jj = 0; jj < JW; ++jj) {
+                            acc[b][jj] = fmaf(d1, w1[jj], acc[b][jj]);
+                            accu[b][jj] = fmaf(d2, w2[jj], accu[b][jj]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int jj = 0; jj < JW; ++jj) {
+                    const float t1 = wave_sum_last(acc[b][jj]);
+                    const float t2 = wave_sum_last(accu[b][jj]);
+                    if (lane == 63) {
+                        gp[(wv * 2) * NB * JW + b * JW + jj] = t1;
+                        gp[(wv * 2 + 1) * NB * JW + b * JW + jj] = t2;
+                    }
+                }
+        }
+        __syncthreads();
+        float dout = 0.f;
+        if (cell) {
+            const int o = cb * JW + cjj, st = NB * JW;
+            if (n1) dh_carry = (gp[o] + gp[2 * st + o]) + (gp[4 * st + o] + gp[6 * st + o]);
+            if (n2) {
+                dout = (gp[st + o] + gp[3 * st + o]) + (gp[5 * st + o] + gp[7 * st + o]);
+                if (a.drop_threshold)
+                    dout = (mix_hash(dseed, ((uint64_t)s * B + cb) * H + cj) > a.drop_threshold) ? dout * a.drop_scale
+                                                                                                   : 0.f;
+            }
+        }
+        if (s < 0) break;
+        // ---- gate adjoints of the owned units and their LayerNorm-adjoint partial sums
+        float da[4] = {0.f, 0.f, 0.f, 0.f}, xh[4] = {0.f, 0.f, 0.f, 0.f}, hh[4] = {0.f, 0.f, 0.f, 0.f};
+        float rx = 0.f, rh = 0.f;
+        if (cell) {
+            if (top) dout = dyv;
+            const float ig = sg[0], fg = sg[1], og = sg[2], ug = sg[3];
+            const float dh = dout + dh_carry;
+            const float tc = tanhf(c_new);
+            const float dc = dc_carry + dh * og * (1.f - tc * tc);
+            da[0] = dc * ug * ig * (1.f - ig);
+            da[1] = dc * c_prev * fg * (1.f - fg);
+            da[2] = dh * tc * og * (1.f - og);
+            da[3] = dc * ig * (1.f - ug * ug);
+            dc_carry = dc * fg;
+            rx = sst[1];
+            rh = sst[3];
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                xh[gg] = (sx[gg] - sst[0]) * sst[1];
+                hh[gg] = (sh[gg] - sst[2]) * sst[3];
+                const float dyx = da[gg] * gx[gg], dyh = da[gg] * gh[gg];
+                r[0] += dyx; r[1] += dyx * xh[gg];
+                r[2] += dyh; r[3] += dyh * hh[gg];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rp[(cb * JW + cjj) * 4 + q] = r[q];
+        }
+        __syncthreads();
+        u64* const sdst = xsum_l + (size_t)s * (size_t)(4 * B * nwg);
+        if (tid < 4 * B) {
+            const int b = tid >> 2, q = tid & 3;
+            float t = 0.f;
+            for (int jj = 0; jj < nvalid; ++jj) t += rp[(b * JW + jj) * 4 + q];
+            xchg_put(sdst + (size_t)(b * 4 + q) * nwg + blockIdx.x, t, tag);
+        }
+        {
+            int idx[4 * NI];
+            unsigned valid = 0;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int w = rpart + GL * i;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    idx[q * NI + i] = (rb * 4 + q) * nwg + w;
+                    if (rgrp && w < nwg) valid |= 1u << (q * NI + i);
+                }
+            }
+            float v[4 * NI];
+            xchg_get<4 * NI>(sdst, idx, valid, tag, v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) t += ((valid >> (q * NI + i)) & 1u) ? v[q * NI + i] : 0.f;
+                t = group_sum_last<GL>(t);
+                if (rgrp && rpart == GL - 1) rtot[rb * 4 + q] = t * inv_g;
+            }
+        }
+        __syncthreads();
+        // ---- dXW, dHW of the owned columns: publish (dHW for this layer, dXW for the layer below), store
+        if (cell) {
+            const float r0 = rtot[cb * 4], r1 = rtot[cb * 4 + 1], r2 = rtot[cb * 4 + 2], r3 = rtot[cb * 4 + 3];
+            const size_t row = (size_t)s * B + cb;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int col = gg * H + cj;
+                const float dyx = da[gg] * gx[gg], dyh = da[gg] * gh[gg];
+                const float dhw = rh * (dyh - r2 - hh[gg] * r3);
+                const float dxw = rx * (dyx - r0 - xh[gg] * r1);
+                xchg_put(xhw_l + (size_t)s * BG + (size_t)cb * G + col, dhw, tag);
+                if (l > 0) xchg_put(xxw_l + (size_t)s * BG + (size_t)cb * G + col, dxw, tag);
+                dhw_l[row * G + col] = dhw;
+                dxw_l[row * G + col] = dxw;
+                dgate_l[row * G + col] = da[gg];
+            }
+        }
+    }
+    if (cell) {
+        a.dh0[(size_t)l * BH + (size_t)cb * H + cj] = dh_carry;
+        a.dc0[(size_t)l * BH + (size_t)cb * H + cj] = dc_carry;
+    }
+}
+
+template <int NB, int JW>
+inline int launch_wave_bwd_t(const WaveCfg& c, const WaveBwd& a, hipStream_t st) {
+    auto k = lstm_wave_bwd_kernel<NB, JW>;
+    if (c.lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3(c.nwg, a.L), dim3(256), c.lds, st, a);
+    return 0;
+}
+inline int launch_wave_bwd(const WaveCfg& c, const WaveBwd& a, hipStream_t st) {
+#define HPC_RLL_WAVE_RUN(JW_)                                               \
+    if (c.jw == JW_) {                                                      \
+        if (c.nb == 1) return launch_wave_bwd_t<1, JW_>(c, a, st);          \
+        if (c.nb == 2) return launch_wave_bwd_t<2, JW_>(c, a, st);          \
+        return launch_wave_bwd_t<4, JW_>(c, a, st);                         \
+    }
+    HPC_RLL_WAVE_RUN(1) HPC_RLL_WAVE_RUN(2) HPC_RLL_WAVE_RUN(4) HPC_RLL_WAVE_RUN(6) HPC_RLL_WAVE_RUN(8)
+#undef HPC_RLL_WAVE_RUN
+    return HPC_RLL_EUNSUPPORTED;
+}
+
+// backward eligibility: the forward rule plus the backward's LDS footprint and exchange storage
+inline bool wave_bwd_shape_ok(int S, int B, int H, int L, int cus, WaveCfg* out) {
+    WaveCfg c;
+    if (!wave_shape_ok(S, B, H, L, cus, &c)) return false;
+    // two layers of a wide LSTM: the doubled gather (dHW_l and dXW_{l+1}, 2*B*4H words per step) costs more than
+    // halving the number of dependent steps saves (measured L=2, H=512: 2.0 ms per-layer vs 2.2 ms wavefront)
+    if (L < 3 && H > 256) return false;
+    const size_t G = 4 * (size_t)H;
+    c.lds = ((size_t)2 * c.jw * G + (size_t)2 * c.nb * G + (size_t)c.nb * c.jw * 12 + 4 * c.nb + 64) * sizeof(float);
+    c.hx_words = (size_t)L * S * B * G;        // dHW slots (and as many dXW slots)
+    c.sx_words = (size_t)L * S * 4 * B * H;    // sums slots, sized for jw = 1
+    if (2 * c.hx_words + c.sx_words > kWaveMaxWords || c.lds > 144 * 1024) return false;
+    *out = c;
+    return true;
+}
+
+}  // namespace
+}  // namespace hpc_rll
