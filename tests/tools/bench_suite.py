@@ -171,6 +171,9 @@ def suite_c5(B=4096, M=256, N=64, H=64, W=64):
     new_x, mask, shapes = P.Padding1D(xs)
     import hpc_rl_utils as U
     table = U._device_table([[t.data_ptr(), 1, 1, t.shape[0]] for t in xs], dev)
+    t_un = timed(lambda: P.UnPadding1D(new_x, shapes), n=1, rounds=2)
+    rows.append(dict(op="unpad1d_python_api", shape=f"n={n}", fwd_ms=t_un * 1e3, note="list-of-tensors API incl. host table build"))
+    print(json.dumps(rows[-1]), flush=True)
     mx = int(lens.max())
     t_k = timed(lambda: U.N.call("hpc_rll_pad_forward", dev, table.data_ptr(), new_x.data_ptr(), mask.data_ptr(), n, 1, 1, mx, 0), n=5)
     report("pad1d_kernel", f"n={n} len~U[32,128)", t_k, 4 * int(lens.sum()) + 8 * n * mx)
