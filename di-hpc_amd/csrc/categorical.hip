@@ -33,7 +33,7 @@ constexpr float kFltMax = 3.402823466e38f;
 // Masked actions arrive as logits = -inf.  torch.distributions.Categorical (what hpc_rll.origin uses) clamps
 // the normalised logits to the most negative finite float so that p*log p is 0 instead of 0*(-inf) = NaN; clamping
 // the raw logit on load has the same effect (its probability underflows to exactly 0).  NaN passes through.
-__device__ __forceinline__ float clamp_logit(float x) { return x < -kFltMax ? -kFltMax : x; }
+__device__ __forceinline__ float clamp_logit(float x) { return fmaxf(x, -kFltMax); }   // -inf (masked) -> finite
 
 // ---- all-reduce butterflies over aligned groups of G lanes: DPP inside a 16-lane row, ds_bpermute above it.
 template <int CTRL> __device__ __forceinline__ float dpp(float x) {
@@ -66,52 +66,136 @@ struct RowSlice {
                     x[e * 4 + 0] = clamp_logit(t.x); x[e * 4 + 1] = clamp_logit(t.y);
                     x[e * 4 + 2] = clamp_logit(t.z); x[e * 4 + 3] = clamp_logit(t.w);
                 } else {
-                    x[e * 4 + 0] = x[e * 4 + 1] = x[e * 4 + 2] = x[e * 4 + 3] = kNegInf;
+                    x[e * 4 + 0] = x[e * 4 + 1] = x[e * 4 + 2] = x[e * 4 + 3] = -kFltMax;   // padding (finite: merges stay NaN-free)
                 }
             } else {
-                x[e] = (c < N) ? clamp_logit(__builtin_nontemporal_load(row + c)) : kNegInf;
+                x[e] = (c < N) ? clamp_logit(__builtin_nontemporal_load(row + c)) : -kFltMax;
             }
         }
     }
 };
 
-// Softmax statistics of the row held by a G-lane group.  On return ex[i] = exp(x_i - max) (0 for padding).
+// ---- Softmax statistics of the row held by a G-lane group.
+// Instruction count matters here: at N = 128 the first version issued ~130 VALU instructions per row pair and the
+// forward kernel was VALU-bound (PMC: SQ_ACTIVE_INST_VALU = 0.47 ms of a 0.52 ms kernel, 4.2 TB/s) although a pure
+// read streams at 7.0 TB/s (tests/tools/micro/readbw.hip).  Hence:
+//   * entropy from the same pass as the partition sum: H = log s - (sum e_i d_i) / s with d_i = x_i - m, e_i = exp d_i
+//     (no second loop over the row, no per-element division);
+//   * the action compare in 32 bits against an index that is -1 when out of range;
+//   * padding checks only when the row does not fill the group exactly (uniform branch);
+//   * forward: NO cross-row all-reduce.  Each 16-lane DPP row reduces (max, s, t, x_a) relative to its OWN maximum
+//     with DPP butterflies only; rows are then merged pairwise with the log-sum-exp merge rule through row_bcast
+//     moves (VALU, no ds_bpermute), leaving the result in the LAST lane of the group, which writes the outputs;
+//   * backward needs p_i in every lane: three all-reduces (max, s, t) instead of four.
+template <int G, class Op> __device__ __forceinline__ float row_all(float x) {   // all-reduce over min(G,16) lanes
+    if (G >= 2) x = Op::f(x, dpp<0xB1>(x));
+    if (G >= 4) x = Op::f(x, dpp<0x4E>(x));
+    if (G >= 8) x = Op::f(x, dpp<0x141>(x));
+    if (G >= 16) x = Op::f(x, dpp<0x140>(x));
+    return x;
+}
+// rows 1,3 <- lane 15 of rows 0,2 (CTRL 0x142, mask 0xA); rows 2,3 <- lane 31 (CTRL 0x143, mask 0xC); others keep x
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float row_fetch(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
+struct RowAcc { float m, s, t, xa; };
+// merge the statistics of two disjoint parts of a row (each relative to its own maximum)
+__device__ __forceinline__ RowAcc merge(const RowAcc& a, const RowAcc& b) {
+    RowAcc r;
+    r.m = fmaxf(a.m, b.m);
+    const float da = a.m - r.m, db = b.m - r.m;
+    const float wa = __expf(da), wb = __expf(db);
+    r.s = a.s * wa + b.s * wb;
+    r.t = wa * fmaf(da, a.s, a.t) + wb * fmaf(db, b.s, b.t);
+    r.xa = a.xa + b.xa;
+    return r;
+}
+
 template <int G, int VEC, int E>
-__device__ __forceinline__ void row_stats(const RowSlice<G, VEC, E>& r, int N, int gl, long action,
-                                          float (&ex)[E * VEC], float& lse, float& sum, float& logp_a, float& ent) {
-    float m = kNegInf;
+__device__ __forceinline__ RowAcc lane_stats(const RowSlice<G, VEC, E>& r, int N, int gl, int ai, bool full,
+                                             float (&ex)[E * VEC], float m) {
+    RowAcc a;
+    a.m = m;
+    a.s = 0.f; a.t = 0.f; a.xa = 0.f;
+    if (full) {
 #pragma unroll
-    for (int i = 0; i < E * VEC; ++i) m = fmaxf(m, r.x[i]);
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int i = e * VEC + k;
+                const float d = r.x[i] - m;
+                ex[i] = __expf(d);
+                a.s += ex[i];
+                a.t = fmaf(ex[i], d, a.t);
+                a.xa += ((e * G + gl) * VEC + k == ai) ? r.x[i] : 0.f;
+            }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int i = e * VEC + k;
+                const int c = (e * G + gl) * VEC + k;
+                const float d = r.x[i] - m;
+                ex[i] = (c < N) ? __expf(d) : 0.f;
+                a.s += ex[i];
+                a.t = (c < N) ? fmaf(ex[i], d, a.t) : a.t;
+                a.xa += (c == ai) ? r.x[i] : 0.f;
+            }
+    }
+    return a;
+}
+
+// forward: log p(action) and entropy, valid in the LAST lane of the group
+template <int G, int VEC, int E>
+__device__ __forceinline__ void row_stats_fwd(const RowSlice<G, VEC, E>& r, int N, int gl, int ai, bool full,
+                                              float& logp_a, float& ent) {
+    float m = r.x[0];
+#pragma unroll
+    for (int i = 1; i < E * VEC; ++i) m = fmaxf(m, r.x[i]);
+    m = row_all<G, MaxOp>(m);
+    float ex[E * VEC];
+    RowAcc a = lane_stats<G, VEC, E>(r, N, gl, ai, full, ex, m);
+    a.s = row_all<G, SumOp>(a.s);
+    a.t = row_all<G, SumOp>(a.t);
+    a.xa = row_all<G, SumOp>(a.xa);
+    if (G >= 32) {   // rows 1 and 3 merge the row before them
+        RowAcc b;
+        b.m = row_fetch<0x142, 0xA>(a.m); b.s = row_fetch<0x142, 0xA>(a.s);
+        b.t = row_fetch<0x142, 0xA>(a.t); b.xa = row_fetch<0x142, 0xA>(a.xa);
+        const bool odd = (threadIdx.x & 16) != 0;
+        const RowAcc mm = merge(a, b);
+        a.m = odd ? mm.m : a.m; a.s = odd ? mm.s : a.s; a.t = odd ? mm.t : a.t; a.xa = odd ? mm.xa : a.xa;
+    }
+    if (G >= 64) {   // row 3 merges lanes 0..31 (held by lane 31)
+        RowAcc b;
+        b.m = row_fetch<0x143, 0xC>(a.m); b.s = row_fetch<0x143, 0xC>(a.s);
+        b.t = row_fetch<0x143, 0xC>(a.t); b.xa = row_fetch<0x143, 0xC>(a.xa);
+        const bool hi = (threadIdx.x & 32) != 0;
+        const RowAcc mm = merge(a, b);
+        a.m = hi ? mm.m : a.m; a.s = hi ? mm.s : a.s; a.t = hi ? mm.t : a.t; a.xa = hi ? mm.xa : a.xa;
+    }
+    const float ls = __logf(a.s);
+    logp_a = a.xa - (a.m + ls);
+    ent = ls - a.t * __builtin_amdgcn_rcpf(a.s);
+}
+
+// backward: ex[i] = exp(x_i - max) and the row scalars in EVERY lane of the group
+template <int G, int VEC, int E>
+__device__ __forceinline__ void row_stats(const RowSlice<G, VEC, E>& r, int N, int gl, int ai, bool full,
+                                          float (&ex)[E * VEC], float& lse, float& inv_sum, float& ent) {
+    float m = r.x[0];
+#pragma unroll
+    for (int i = 1; i < E * VEC; ++i) m = fmaxf(m, r.x[i]);
     m = group_all<G, MaxOp>(m);
-    float s = 0.f, xa = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const int i = e * VEC + k;
-            const int c = (e * G + gl) * VEC + k;
-            ex[i] = (c < N) ? __expf(r.x[i] - m) : 0.f;
-            s += ex[i];
-            xa += ((long)c == action) ? r.x[i] : 0.f;
-        }
-    s = group_all<G, SumOp>(s);
-    xa = group_all<G, SumOp>(xa);
+    const RowAcc a = lane_stats<G, VEC, E>(r, N, gl, ai, full, ex, m);
+    const float s = group_all<G, SumOp>(a.s);
+    const float t = group_all<G, SumOp>(a.t);
     const float ls = __logf(s);
+    inv_sum = __builtin_amdgcn_rcpf(s);
     lse = m + ls;
-    sum = s;
-    logp_a = xa - lse;
-    // entropy = -sum p_i log p_i,  p_i = ex_i / s,  log p_i = x_i - lse
-    float h = 0.f;
-    const float inv = 1.f / s;
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const int i = e * VEC + k;
-            const int c = (e * G + gl) * VEC + k;
-            if (c < N) h -= (ex[i] * inv) * (r.x[i] - lse);
-        }
-    ent = group_all<G, SumOp>(h);
+    ent = ls - t * inv_sum;
 }
 
 // R rows per group per iteration: R independent load + reduction chains in flight.
@@ -126,6 +210,7 @@ __global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* __res
     constexpr int R = RowsPerIter<G, VEC, E>::value;
     const int gl = threadIdx.x % G;
     const int gi = threadIdx.x / G;
+    const bool full = N == G * VEC * E;   // uniform: no padding lanes
     // row of (iteration block bb, slot k, group gi) = bb + k*GPB + gi: for a fixed k the groups of the whole workgroup
     // read consecutive rows, i.e. one contiguous span per load instruction whatever G is
     for (long bb = (long)blockIdx.x * GPB * R; bb < rows; bb += (long)gridDim.x * GPB * R) {
@@ -141,10 +226,10 @@ __global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* __res
         float lp[R], h[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            float ex[E * VEC], lse, sum;
-            row_stats<G, VEC, E>(r[k], N, gl, a[k], ex, lse, sum, lp[k], h[k]);
+            const int ai = (a[k] >= 0 && a[k] < (long)N) ? (int)a[k] : -1;
+            row_stats_fwd<G, VEC, E>(r[k], N, gl, ai, full, lp[k], h[k]);
         }
-        if (gl == 0) {
+        if (gl == G - 1) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const long row = bb + (long)k * GPB + gi;
@@ -172,6 +257,7 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __res
     const int gi = threadIdx.x / G;
     const float u1 = g1 ? g1[0] : 1.f;
     const float u2 = (c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
+    const bool full = N == G * VEC * E;
     for (long bb = (long)blockIdx.x * GPB * R; bb < rows; bb += (long)gridDim.x * GPB * R) {
         RowSlice<G, VEC, E> r[R];
         long a[R];
@@ -187,11 +273,11 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __res
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            float ex[E * VEC], lse, sum, lp, h;
-            row_stats<G, VEC, E>(r[k], N, gl, a[k], ex, lse, sum, lp, h);
+            float ex[E * VEC], lse, inv, h;
+            const int ai = (a[k] >= 0 && a[k] < (long)N) ? (int)a[k] : -1;
+            row_stats<G, VEC, E>(r[k], N, gl, ai, full, ex, lse, inv, h);
             const long orow = bb + (long)k * GPB + gi;
             if (orow >= rows) continue;
-            const float inv = 1.f / sum;
             float* __restrict__ out = grad + orow * (long)N;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -201,7 +287,7 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __res
                 for (int q = 0; q < VEC; ++q) {
                     const int i = e * VEC + q;
                     const float p = ex[i] * inv;
-                    const float onehot = ((long)(c0 + q) == a[k]) ? 1.f : 0.f;
+                    const float onehot = (c0 + q == ai) ? 1.f : 0.f;
                     o[q] = k1[k] * (onehot - p) - k2[k] * p * ((r[k].x[i] - lse) + h);
                 }
                 if (c0 < N) {
@@ -430,8 +516,12 @@ inline RowCfg row_cfg(int N, bool can_vec4) {
     RowCfg c;
     c.vec = (can_vec4 && (N % 4) == 0) ? 4 : 1;
     const int pieces = (N + c.vec - 1) / c.vec;
+    // A row is held by at most 16 lanes (one DPP row) whenever 8 pieces per lane suffice: the per-row reductions are
+    // then four DPP steps with no cross-row merge, and their cost is amortised over more elements per lane (the
+    // kernels are VALU-bound, not bandwidth-bound, at one float4 per lane).  Longer rows take the whole wave.
+    const int gmax = pieces <= 16 * 8 ? 16 : 64;   // (8 lanes per row measured no better at N = 64..128, worse at 256)
     c.g = 1;
-    while (c.g < 64 && c.g < pieces) c.g <<= 1;
+    while (c.g < gmax && c.g < pieces) c.g <<= 1;
     const int e = (pieces + c.g - 1) / c.g;
     c.e = 1;
     while (c.e < e) c.e <<= 1;
@@ -448,13 +538,13 @@ inline RowCfg row_cfg(int N, bool can_vec4) {
 #define HPC_RLL_ROW_DISPATCH(KERNEL, ...)                                                                  \
     HPC_RLL_ROW_CASE(1, 1, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(2, 1, 1, KERNEL, __VA_ARGS__)          \
     HPC_RLL_ROW_CASE(4, 1, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(8, 1, 1, KERNEL, __VA_ARGS__)          \
-    HPC_RLL_ROW_CASE(16, 1, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(32, 1, 1, KERNEL, __VA_ARGS__)        \
-    HPC_RLL_ROW_CASE(64, 1, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(64, 1, 2, KERNEL, __VA_ARGS__)        \
+    HPC_RLL_ROW_CASE(16, 1, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(16, 1, 2, KERNEL, __VA_ARGS__)        \
+    HPC_RLL_ROW_CASE(16, 1, 4, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(16, 1, 8, KERNEL, __VA_ARGS__)        \
     HPC_RLL_ROW_CASE(64, 1, 4, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(64, 1, 8, KERNEL, __VA_ARGS__)        \
     HPC_RLL_ROW_CASE(1, 4, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(2, 4, 1, KERNEL, __VA_ARGS__)          \
     HPC_RLL_ROW_CASE(4, 4, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(8, 4, 1, KERNEL, __VA_ARGS__)          \
-    HPC_RLL_ROW_CASE(16, 4, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(32, 4, 1, KERNEL, __VA_ARGS__)        \
-    HPC_RLL_ROW_CASE(64, 4, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(64, 4, 2, KERNEL, __VA_ARGS__)        \
+    HPC_RLL_ROW_CASE(16, 4, 1, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(16, 4, 2, KERNEL, __VA_ARGS__)        \
+    HPC_RLL_ROW_CASE(16, 4, 4, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(16, 4, 8, KERNEL, __VA_ARGS__)        \
     HPC_RLL_ROW_CASE(64, 4, 4, KERNEL, __VA_ARGS__) HPC_RLL_ROW_CASE(64, 4, 8, KERNEL, __VA_ARGS__)        \
     return false;
 
