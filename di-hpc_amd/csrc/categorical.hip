@@ -112,13 +112,40 @@ __device__ __forceinline__ RowAcc merge(const RowAcc& a, const RowAcc& b) {
     return r;
 }
 
-template <int G, int VEC, int E>
+template <int G, int VEC, int E, bool PACK>
 __device__ __forceinline__ RowAcc lane_stats(const RowSlice<G, VEC, E>& r, int N, int gl, int ai, bool full,
                                              float (&ex)[E * VEC], float m) {
     RowAcc a;
     a.m = m;
     a.s = 0.f; a.t = 0.f; a.xa = 0.f;
-    if (full) {
+    if (PACK && full && VEC == 4) {   // forward only: measured -4 % there, +7 % in the backward kernel
+        // packed fp32 (v_pk_add/mul/fma_f32: two elements per instruction) for everything but exp and the compare
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 m2 = {m, m};
+        const f2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+        f2 s2 = {0.f, 0.f}, t2 = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int k = 0; k < VEC; k += 2) {
+                const int i = e * VEC + k;
+                const f2 x2 = {r.x[i], r.x[i + 1]};
+                const f2 d2 = x2 - m2;
+                const f2 a2 = d2 * l2e;
+                f2 e2;
+                e2.x = __builtin_amdgcn_exp2f(a2.x);
+                e2.y = __builtin_amdgcn_exp2f(a2.y);
+                ex[i] = e2.x;
+                ex[i + 1] = e2.y;
+                s2 += e2;
+                t2 = __builtin_elementwise_fma(e2, d2, t2);
+                const int c = (e * G + gl) * VEC + k;
+                a.xa += (c == ai) ? r.x[i] : 0.f;
+                a.xa += (c + 1 == ai) ? r.x[i + 1] : 0.f;
+            }
+        a.s = s2.x + s2.y;
+        a.t = t2.x + t2.y;
+    } else if (full) {
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
@@ -156,7 +183,7 @@ __device__ __forceinline__ void row_stats_fwd(const RowSlice<G, VEC, E>& r, int 
     for (int i = 1; i < E * VEC; ++i) m = fmaxf(m, r.x[i]);
     m = row_all<G, MaxOp>(m);
     float ex[E * VEC];
-    RowAcc a = lane_stats<G, VEC, E>(r, N, gl, ai, full, ex, m);
+    RowAcc a = lane_stats<G, VEC, E, true>(r, N, gl, ai, full, ex, m);
     a.s = row_all<G, SumOp>(a.s);
     a.t = row_all<G, SumOp>(a.t);
     a.xa = row_all<G, SumOp>(a.xa);
@@ -189,7 +216,7 @@ __device__ __forceinline__ void row_stats(const RowSlice<G, VEC, E>& r, int N, i
 #pragma unroll
     for (int i = 1; i < E * VEC; ++i) m = fmaxf(m, r.x[i]);
     m = group_all<G, MaxOp>(m);
-    const RowAcc a = lane_stats<G, VEC, E>(r, N, gl, ai, full, ex, m);
+    const RowAcc a = lane_stats<G, VEC, E, false>(r, N, gl, ai, full, ex, m);
     const float s = group_all<G, SumOp>(a.s);
     const float t = group_all<G, SumOp>(a.t);
     const float ls = __logf(s);
