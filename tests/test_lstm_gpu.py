@@ -184,11 +184,24 @@ def test_lstm_dropout(B):
         N.check(N.lib.hpc_rll_tune_set(3, 1), "tune_set")
     assert rel_err(y3.detach().cpu().numpy(), y1.detach().cpu().numpy()) < 1e-5
     assert not torch.equal(y1, y0) and torch.isfinite(y1).all()
-    xg = x.clone().requires_grad_(True)
-    torch.manual_seed(5)
-    yg, _ = m(xg, None)
-    yg.sum().backward()
-    assert torch.isfinite(xg.grad).all() and xg.grad.abs().sum() > 0
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        torch.manual_seed(5)
+        yg, _ = m(xg, None)
+        (yg * torch.linspace(0.5, 1.5, yg.numel(), device=DEV).view_as(yg)).sum().backward()
+        return [xg.grad.cpu().numpy()] + [p.grad.cpu().numpy() for p in m.parameters()]
+
+    g1 = grads()
+    assert np.isfinite(g1[0]).all() and np.abs(g1[0]).sum() > 0
+    try:                                               # backward applies the same masks on every path
+        N.check(N.lib.hpc_rll_tune_set(3, 0), "tune_set")
+        g0 = grads()
+    finally:
+        N.check(N.lib.hpc_rll_tune_set(3, 1), "tune_set")
+    for a, b in zip(g0, g1):
+        assert rel_err(a, b) < 2e-4
 
 
 @pytest.mark.parametrize("S,B,I,H,L", [(64, 3, 1792, 384, 3), (9, 8, 40, 1024, 2), (7, 5, 12, 1000, 2), (5, 1, 7, 65, 1),
