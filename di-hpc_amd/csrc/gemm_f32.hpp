@@ -40,6 +40,7 @@ struct GemmArgs {
     int splitk = 1;    // > 1: gridDim.z slices of K (gemm_splitk), slice z writes its PARTIAL product to
     long c_split = 0;  //      C + z*c_split; the consumer adds the slices in a fixed order (deterministic)
     int big = 0;       // 1: a long-K product that brings its own split-K (gemm_splitk_big): 128x128 tiles
+    int xcd_swizzle = 0;   // set by launch_gemm_tile
 };
 
 enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2 };
@@ -157,7 +158,25 @@ __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_ke
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8), each with its own 4 MB L2.
+    // Give XCD x the x-th contiguous eighth of the tile sequence, and walk that sequence in groups of 8 tile rows
+    // (column-major inside a group), so that the ~128 workgroups resident on one XCD cover a compact 8 x 16 block of
+    // tiles and share their A rows / B columns through that L2.
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (g.xcd_swizzle) {
+        const int nbx = gridDim.x, nby = gridDim.y, total = nbx * nby;
+        const int id = blockIdx.y * nbx + blockIdx.x;
+        const int per = total >> 3;                       // host sets xcd_swizzle only when total % 8 == 0
+        const int t = (id & 7) * per + (id >> 3);
+        constexpr int GROUP_M = 8;
+        const int in_group = GROUP_M * nbx;
+        const int grp = t / in_group, first_m = grp * GROUP_M;
+        const int gsz = (nby - first_m) < GROUP_M ? (nby - first_m) : GROUP_M;
+        const int r = t - grp * in_group;
+        tile_m = first_m + r % gsz;
+        tile_n = r / gsz;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     TileStage<BM, BK, AMODE> sa;
     TileStage<BN, BK, BMODE> sb;
@@ -240,8 +259,11 @@ inline int gemm_mode(const float* p, long sx, long sk, int XD, int KD) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
-inline void launch_gemm_tile(const GemmArgs& g, int am, int bm, hipStream_t st) {
-    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
+inline void launch_gemm_tile(const GemmArgs& g_in, int am, int bm, hipStream_t st) {
+    const dim3 grid((g_in.N + BN - 1) / BN, (g_in.M + BM - 1) / BM, g_in.splitk > 1 ? g_in.splitk : 1);
+    extern int g_gemm_xcd;   // tuning knob (hpc_rll_tune_set key 10)
+    GemmArgs g = g_in;
+    g.xcd_swizzle = (g_gemm_xcd && ((long)grid.x * grid.y) % 8 == 0 && grid.y >= 8) ? 1 : 0;
 #define HPC_RLL_GEMM_CASE(AM, BMD)                                                                          \
     if (am == AM && bm == BMD) {                                                                            \
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, AM, BMD>), grid, dim3(256), 0, st, g);          \

@@ -26,6 +26,7 @@
 
 namespace hpc_rll {
 int g_gemm_bk = 0;
+int g_gemm_xcd = 1;
 int g_gemm_big_tile128 = 1;
 int g_gemm_big_target = 768;   // workgroups the split-K of the weight-gradient GEMMs aims for
 namespace {

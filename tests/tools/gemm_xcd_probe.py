@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""fp32 MFMA GEMM: XCD-aware tile order on/off (tune key 10) at the C4 LSTM shapes; interleaved rounds."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+import torch  # noqa: E402
+import hpc_torch_utils_network as U  # noqa: E402
+dev = torch.device("cuda:0")
+
+
+def t(fn, n=5):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+
+shapes = [("NN rec", 4096, 4096, 1024, "nn"), ("NT dh", 4096, 1024, 4096, "nt"), ("NN xw", 65536, 4096, 1024, "nn"),
+          ("TN dW", 1024, 4096, 65536, "tn"), ("NT dx", 65536, 1024, 4096, "nt"), ("NN sq", 4096, 4096, 4096, "nn")]
+for name, M, N, K, lay in shapes:
+    a = torch.randn(M, K, device=dev)
+    b = torch.randn(K, N, device=dev)
+    A = a if lay != "tn" else a.t().contiguous().t()
+    Bm = b if lay != "nt" else b.t().contiguous().t()
+    c = torch.empty(M, N, device=dev)
+    best = {}
+    outs = {}
+    for rnd in range(3):
+        for x in (1, 0):
+            assert U.N.lib.hpc_rll_tune_set(10, x) == 0
+            dt = t(lambda: U.gemm_f32(A, Bm, out=c))
+            best[x] = min(best.get(x, 1e9), dt)
+            outs[x] = c.clone()
+    assert torch.equal(outs[0], outs[1])
+    print(f"{name:7s} M={M} N={N} K={K}: xcd-aware {2.0*M*N*K/best[1]/1e12:6.1f} TF   plain {2.0*M*N*K/best[0]/1e12:6.1f} TF", flush=True)
+    del a, b, c, A, Bm
+U.N.lib.hpc_rll_tune_set(10, 1)
