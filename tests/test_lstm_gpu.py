@@ -238,7 +238,12 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
         step = run()
     finally:
         N.check(N.lib.hpc_rll_tune_set(3, 1), "tune_set")
-    pers = run()
+    pers = run()                                       # layer wavefront where eligible, else per-layer kernels
+    try:
+        N.check(N.lib.hpc_rll_tune_set(8, 0), "tune_set")
+        pers_layer = run()                             # per-layer persistent kernels
+    finally:
+        N.check(N.lib.hpc_rll_tune_set(8, 1), "tune_set")
     dims = [I] + [H] * L
     offs = np.cumsum([0] + [d * 4 * H for d in dims])
     leaf = lambda t: t.detach().double().cpu().requires_grad_(True)  # noqa: E731
@@ -252,8 +257,9 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
     orc = [oy, ohn, ocn, ox.grad, oh.grad, oc.grad, torch.cat([w.grad.reshape(-1) for w in owx]),
            torch.cat([w.grad.reshape(-1) for w in owh]), ob.grad.reshape(-1), og.grad, obe.grad]
     names = "y hn cn dx dh0 dc0 dwx dwh dbias dgamma dbeta".split()
-    for k, a, b, o in zip(names, step, pers, orc):
+    for k, a, b, b2, o in zip(names, step, pers, pers_layer, orc):
         o = o.detach().numpy().reshape(a.shape)
-        assert np.isfinite(b).all(), k
         base = 1e-5 if k in ("y", "hn", "cn") else 2e-4
-        assert rel_err(o, b) < max(base, 2.0 * rel_err(o, a)), (k, rel_err(o, b), rel_err(o, a))
+        for got in (b, b2):
+            assert np.isfinite(got).all(), k
+            assert rel_err(o, got) < max(base, 2.0 * rel_err(o, a)), (k, rel_err(o, got), rel_err(o, a))
