@@ -79,3 +79,25 @@ def test_argument_errors_are_status_codes_not_crashes():
     assert b"invalid argument" in L.hpc_rll_status_string(-1)
     assert L.hpc_rll_partials_floats(100) >= 100
     assert L.hpc_rll_vtrace_workspace_floats(10, 20) >= 6 * 200
+
+
+def test_c_program_links_and_runs(tmp_path):
+    """The boundary is a plain C ABI: a C program (no Python, no torch) compiles against include/hpc_rll_hip.h, links
+    the shared library and calls the entry points that need no GPU."""
+    import shutil
+    import subprocess
+    import pytest
+    LIB = os.path.join(ROOT, "di-hpc_amd", "hpc_rll", "_lib", "libhpc_rll_hip.so")
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    lib_dir = os.path.dirname(LIB)
+    exe = str(tmp_path / "abi_smoke")
+    rocm_lib = "/opt/rocm/lib"
+    cmd = [gcc, "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_smoke.c"),
+           "-o", exe, "-L", lib_dir, "-lhpc_rll_hip", f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{rocm_lib}",
+           f"-Wl,-rpath-link,{rocm_lib}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "abi 1 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
