@@ -54,33 +54,41 @@ __global__ void gae_coef_kernel(float* __restrict__ coef, int T, float gamma, fl
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int V, int LC, int NW, bool NTL, bool NTS>
+// HALF (V = 1 only): a wave covers 32 columns instead of 64 and its two 32-lane halves own two DIFFERENT chunks of
+// the time axis ("virtual waves" 2w and 2w+1).  For narrow batches (B < 16384: fewer than 256 column tiles of 64) this
+// doubles both the number of workgroups and the steps covered per barrier (NW*2*LC): the kernel is bound by the
+// latency of its T / SPAN iterations there, not by bandwidth.
+template <int V, int LC, int NW, bool NTL, bool NTS, bool HALF = false>
 __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restrict__ value,
                                                           const float* __restrict__ reward,
                                                           float* __restrict__ adv,
                                                           const float* __restrict__ coef, int T, int B,
                                                           float gamma) {
-    constexpr int TILE = 64 * V;
+    static_assert(!HALF || V == 1, "half-wave tiles hold one column per lane");
+    constexpr int NWV = HALF ? 2 * NW : NW;       // (virtual) waves per workgroup
+    constexpr int TILE = HALF ? 32 : 64 * V;
     // one LDS object: [buf][wave][TILE] chunk-head values, then [buf][wave] chunk products
-    __shared__ float lds[2 * NW * TILE + 2 * NW];
+    __shared__ float lds[2 * NWV * TILE + 2 * NWV];
     float* const s_l0 = lds;
-    float* const s_p0 = lds + 2 * NW * TILE;
+    float* const s_p0 = lds + 2 * NWV * TILE;
 
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    const int wr = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cl = HALF ? (lane & 31) : lane;             // column lane inside the tile
+    const int w = HALF ? 2 * wr + (lane >> 5) : wr;       // (virtual) wave: lane dependent when HALF
+    const long col = (long)blockIdx.x * TILE + (long)cl * V;
     const bool col_ok = col < (long)B;  // dispatcher guarantees B % V == 0: packs never straddle B
 
     float carry[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) carry[k] = 0.f;
 
-    constexpr int SPAN = NW * LC;
+    constexpr int SPAN = NWV * LC;
     const int n_iter = (T + SPAN - 1) / SPAN;
 
     for (int it = 0; it < n_iter; ++it) {
-        // chunks are aligned to the END of the trajectory; wave NW-1 owns the latest chunk
-        const int t1 = T - (it * NW + (NW - 1 - w)) * LC;  // exclusive end, <= T, may be <= 0
+        // chunks are aligned to the END of the trajectory; wave NWV-1 owns the latest chunk
+        const int t1 = T - (it * NWV + (NWV - 1 - w)) * LC;  // exclusive end, <= T, may be <= 0
         const int t0 = t1 - LC;
         const int buf = it & 1;
 
@@ -158,23 +166,23 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restric
 
         // ---- publish this chunk's head (value at t0 with zero carry-in, and the product over the chunk)
 #pragma unroll
-        for (int k = 0; k < V; ++k) s_l0[(buf * NW + w) * TILE + lane * V + k] = L[0][k];
-        if (lane == 0) s_p0[buf * NW + w] = P[0];
+        for (int k = 0; k < V; ++k) s_l0[(buf * NWV + w) * TILE + cl * V + k] = L[0][k];
+        if (cl == 0) s_p0[buf * NWV + w] = P[0];
         __syncthreads();
 
-        // ---- resolve carries: walk the NW chunks from the latest to the earliest
+        // ---- resolve carries: walk the NWV chunks from the latest to the earliest
         float A[V], Aw[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) { A[k] = carry[k]; Aw[k] = 0.f; }
 #pragma unroll
-        for (int u = NW - 1; u >= 0; --u) {
+        for (int u = NWV - 1; u >= 0; --u) {
             if (u == w) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) Aw[k] = A[k];
             }
-            const float p0 = s_p0[buf * NW + u];
+            const float p0 = s_p0[buf * NWV + u];
 #pragma unroll
-            for (int k = 0; k < V; ++k) A[k] = fmaf(p0, A[k], s_l0[(buf * NW + u) * TILE + lane * V + k]);
+            for (int k = 0; k < V; ++k) A[k] = fmaf(p0, A[k], s_l0[(buf * NWV + u) * TILE + cl * V + k]);
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) carry[k] = A[k];
@@ -200,31 +208,35 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // backward: d_t = g_t + c_{t-1} d_{t-1} (forward in time), chunks aligned to t = 0, wave 0 earliest.
 // ------------------------------------------------------------------------------------------------
-template <int V, int LC, int NW, bool NTL, bool NTS>
+template <int V, int LC, int NW, bool NTL, bool NTS, bool HALF = false>
 __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restrict__ grad_adv,
                                                           float* __restrict__ grad_value,
                                                           float* __restrict__ grad_reward,
                                                           const float* __restrict__ coef, int T, int B,
                                                           float gamma) {
-    constexpr int TILE = 64 * V;
-    __shared__ float lds[2 * NW * TILE + 2 * NW];
+    static_assert(!HALF || V == 1, "half-wave tiles hold one column per lane");
+    constexpr int NWV = HALF ? 2 * NW : NW;
+    constexpr int TILE = HALF ? 32 : 64 * V;
+    __shared__ float lds[2 * NWV * TILE + 2 * NWV];
     float* const s_l0 = lds;
-    float* const s_p0 = lds + 2 * NW * TILE;
+    float* const s_p0 = lds + 2 * NWV * TILE;
 
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    const int wr = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cl = HALF ? (lane & 31) : lane;
+    const int w = HALF ? 2 * wr + (lane >> 5) : wr;
+    const long col = (long)blockIdx.x * TILE + (long)cl * V;
     const bool col_ok = col < (long)B;
 
     float carry[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) carry[k] = 0.f;
 
-    constexpr int SPAN = NW * LC;
+    constexpr int SPAN = NWV * LC;
     const int n_iter = (T + SPAN - 1) / SPAN;
 
     for (int it = 0; it < n_iter; ++it) {
-        const int t0 = (it * NW + w) * LC;
+        const int t0 = (it * NWV + w) * LC;
         const int buf = it & 1;
 
         float L[LC][V];
@@ -283,22 +295,22 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restric
         }
 
 #pragma unroll
-        for (int k = 0; k < V; ++k) s_l0[(buf * NW + w) * TILE + lane * V + k] = L[LC - 1][k];
-        if (lane == 0) s_p0[buf * NW + w] = Q[LC - 1];
+        for (int k = 0; k < V; ++k) s_l0[(buf * NWV + w) * TILE + cl * V + k] = L[LC - 1][k];
+        if (cl == 0) s_p0[buf * NWV + w] = Q[LC - 1];
         __syncthreads();
 
         float A[V], Aw[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) { A[k] = carry[k]; Aw[k] = 0.f; }
 #pragma unroll
-        for (int u = 0; u < NW; ++u) {
+        for (int u = 0; u < NWV; ++u) {
             if (u == w) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) Aw[k] = A[k];
             }
-            const float q0 = s_p0[buf * NW + u];
+            const float q0 = s_p0[buf * NWV + u];
 #pragma unroll
-            for (int k = 0; k < V; ++k) A[k] = fmaf(q0, A[k], s_l0[(buf * NW + u) * TILE + lane * V + k]);
+            for (int k = 0; k < V; ++k) A[k] = fmaf(q0, A[k], s_l0[(buf * NWV + u) * TILE + cl * V + k]);
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) carry[k] = A[k];
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // host side: configuration choice + dispatch
 // ------------------------------------------------------------------------------------------------
-struct Cfg { int v, lc, nw, flags; };
+struct Cfg { int v, lc, nw, flags; bool half; };
 
 inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
@@ -366,6 +378,7 @@ inline int max_vec(int B, std::initializer_list<const void*> ptrs) {
 //     when there are few column tiles (B=64 -> one workgroup walking T in 256-step strides).
 inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, int flags) {
     auto wgs_for = [&](int vv) { return (B + 64 * vv - 1) / (64 * vv); };
+    const bool all_auto = v == 0 && lc == 0 && nw == 0;
     const bool streaming = (12.0 * (double)T * (double)B) >= 300e6;
     int av, alc, anw, afl;
     if (streaming && fwd) {
@@ -397,8 +410,15 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
         const int chunks = (T + lc - 1) / lc;
         while (nw > 1 && nw > chunks) nw >>= 1;
     }
-    if (flags < 0) flags = afl;
-    return Cfg{v, lc, nw, flags & 3};
+    // narrow batches: half-wave tiles (32 columns, two time chunks per wave) when the 64-column tiling cannot give
+    // every CU a workgroup and the trajectory has enough chunks for 32 virtual waves; explicit request: flags bit 2
+    bool half = flags >= 0 && (flags & 4);
+    if (flags < 0) {
+        flags = afl;
+        half = all_auto && !streaming && v == 1 && lc == 16 && nw == 16 && wgs_for(1) < 256 && T >= 512;
+    }
+    if (half && !(v == 1 && nw == 16 && (lc == 8 || lc == 16))) half = false;
+    return Cfg{v, lc, nw, flags & 3, half};
 }
 
 template <int N> using I = std::integral_constant<int, N>;
@@ -418,10 +438,22 @@ inline void for_each_cfg(F&& f) {
 #define HPC_RLL_GAE_DISPATCH(KERNEL, ...)                                                          \
     do {                                                                                           \
         bool hit = false;                                                                          \
+        if (cfg.half) {                                                                            \
+            const dim3 grid((unsigned)((B + 31) / 32)), block(1024);                               \
+            const bool ntl = cfg.flags & 1;                                                        \
+            if (cfg.lc == 16) {                                                                    \
+                if (ntl) hipLaunchKernelGGL((KERNEL<1, 16, 16, true, true, true>), grid, block, 0, st, __VA_ARGS__);   \
+                else hipLaunchKernelGGL((KERNEL<1, 16, 16, false, true, true>), grid, block, 0, st, __VA_ARGS__);      \
+            } else {                                                                               \
+                if (ntl) hipLaunchKernelGGL((KERNEL<1, 8, 16, true, true, true>), grid, block, 0, st, __VA_ARGS__);    \
+                else hipLaunchKernelGGL((KERNEL<1, 8, 16, false, true, true>), grid, block, 0, st, __VA_ARGS__);       \
+            }                                                                                      \
+            hit = true;                                                                            \
+        }                                                                                          \
         auto go = [&](auto V_, auto LC_, auto NW_) {                                               \
             constexpr int V = decltype(V_)::value, LC = decltype(LC_)::value,                      \
                           NW = decltype(NW_)::value;                                               \
-            if (cfg.v == V && cfg.lc == LC && cfg.nw == NW) {                                      \
+            if (!hit && cfg.v == V && cfg.lc == LC && cfg.nw == NW) {                                \
                 const dim3 grid((unsigned)((B + 64 * V - 1) / (64 * V))), block(NW * 64);          \
                 switch (cfg.flags) {                                                               \
                     case 0: hipLaunchKernelGGL((KERNEL<V, LC, NW, false, false>), grid, block, 0, st, __VA_ARGS__); break; \
