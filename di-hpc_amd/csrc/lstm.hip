@@ -794,10 +794,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         return last_error();
     }
     for (int l = L - 1; l >= 0; --l) {
-        const int in_l = l == 0 ? I : H;
         const LayerWs& lw = w.layer[l];
-        const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
-        const float* wx_l = wx + wx_offs[l];
         const float* wh_l = wh + (size_t)l * H * G;
         const float* gamma_l = ln_gamma + (size_t)l * 2 * G;
         const float* dh_carry = dhn ? dhn + (size_t)l * BH : nullptr;
