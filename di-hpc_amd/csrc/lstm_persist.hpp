@@ -43,11 +43,11 @@ __device__ __forceinline__ void xchg_put(u64* p, float v, uint32_t tag) {
     __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Every workgroup reads every exchange word, and requests for the SAME 64-byte line are served one after another at
-// the memory side: with 192 readers per line one poll round took ~2.6 us although the data was already there
-// (measured: 1.0 poll rounds per gather), against 0.5-0.65 us for a single reader.  So each word is published to
-// `nrep` replicas (tune key 4, default 16) and workgroup w reads replica w % nrep: nrep x more (fire-and-forget)
-// stores, nrep x fewer readers per line.  Spreading the lines over memory channels instead made no difference.
+// Every workgroup reads every exchange word: with 192 readers per line one poll round takes ~2.6 us although the data
+// is already there (measured: 1.0 poll rounds per gather), against 0.5-0.65 us for a single reader.  Each word is
+// therefore published to `nrep` replicas (tune key 4, default 4) and workgroup w reads replica w % nrep: nrep x more
+// (fire-and-forget) stores, nrep x fewer readers per line.  Measured: 4 replicas -20 % per gather, 8 and more lose
+// again to the extra stores; spreading the lines over memory channels instead made no difference.
 constexpr int kMaxRep = 32;
 __device__ __forceinline__ void xchg_put_all(u64* base, size_t rep_words, int nrep, int i, float v, uint32_t tag) {
     for (int r = 0; r < nrep; ++r) xchg_put(base + (size_t)r * rep_words + i, v, tag);
