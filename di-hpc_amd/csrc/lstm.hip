@@ -27,6 +27,7 @@
 namespace hpc_rll {
 int g_gemm_bk = 0;
 int g_gemm_xcd = 1;
+int g_lstm_nn_bwd = 1;   // backward products against transposed weight copies (hpc_rll_tune_set key 11)
 int g_gemm_big_tile128 = 1;
 int g_gemm_big_target = 768;   // workgroups the split-K of the weight-gradient GEMMs aims for
 namespace {
@@ -431,6 +432,31 @@ __global__ __launch_bounds__(256) void lstm_colfinal_kernel(const float* __restr
     dgamma[G + col] = s[2];
 }
 
+// out (cols, rows) = in (rows, cols)^T, 32x32 tiles through LDS.  Used once per layer and backward call to turn the
+// two "NT" products of the backward pass (dHW @ Wh^T per step, dXW @ Wx^T per layer) into "NN" products: the NT form
+// needs a register transpose of BOTH operands when staging and ran at 84-91 TFLOP/s (dh) / 112 (dx) against 117 / 122
+// for NN at the same sizes; transposing a 16 MB weight once costs ~10 us.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                        int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int r = r0 + ty + k, c = c0 + tx;
+        tile[ty + k][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int c = c0 + ty + k, r = r0 + tx;
+        if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[tx][ty + k];
+    }
+}
+inline void launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, out, rows, cols);
+}
+
 // ------------------------------------------------------------------------------------------------ dropout
 __device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
@@ -505,7 +531,7 @@ namespace {
 struct LayerWs { float *xw, *hw, *gates, *c, *hseq, *stats, *xin_next; };
 struct Ws {
     LayerWs layer[16];
-    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg, *wpart, *dwave;
+    float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg, *wpart, *dwave, *whT, *wxT;
     size_t total;
 };
 inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
@@ -532,6 +558,8 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.dseq_a = take(widest);
     w.dseq_b = take(widest);
     w.colpart = take((size_t)kColChunks * 3 * G);
+    w.whT = take((size_t)H * G);                          // Wh^T of the layer being processed (backward)
+    w.wxT = take((size_t)(I > H ? I : H) * G);            // Wx^T of that layer
     {   // persistent small-batch paths: {value, tag} exchange words (per-layer kernels / layer wavefront)
         size_t words = xchg_layout(B, H).total_words;
         WaveCfg wc{};
@@ -757,9 +785,17 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         // d xin (S*B, in) = dXW @ Wx^T : B(k=g, n=i) = Wx[i*G + g]
         if (dxin) {
             const int skd = gemm_splitk((int)SB, in_l, (int)G);
-            GemmArgs g{p_dxw, wx_l, skd > 1 ? w.wpart : dxin, (int)SB, in_l, (int)G, (long)G, 1, 1, (long)G, (long)in_l,
-                       0, skd, (long)(SB * in_l)};
-            launch_gemm(g, st);
+            // NN against a transposed copy only where it was measured to win (C4: -2 %; B <= 1024: +2..5 %)
+            if (g_lstm_nn_bwd && (double)SB * in_l >= (double)(1u << 28)) {
+                launch_transpose(wx_l, w.wxT, in_l, (int)G, st);   // (in, G) -> (G, in): B(k=g, n=i) = wxT[g*in + i]
+                GemmArgs g{p_dxw, w.wxT, skd > 1 ? w.wpart : dxin, (int)SB, in_l, (int)G, (long)G, 1, (long)in_l, 1,
+                           (long)in_l, 0, skd, (long)(SB * in_l)};
+                launch_gemm(g, st);
+            } else {                                               // NT: B(k=g, n=i) = Wx[i*G + g]
+                GemmArgs g{p_dxw, wx_l, skd > 1 ? w.wpart : dxin, (int)SB, in_l, (int)G, (long)G, 1, 1, (long)G,
+                           (long)in_l, 0, skd, (long)(SB * in_l)};
+                launch_gemm(g, st);
+            }
             if (skd > 1)
                 hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((SB * in_l + 255) / 256)), dim3(256), 0, st,
                                    (const float*)w.wpart, skd, (long)(SB * in_l), dxin);
@@ -810,6 +846,8 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             if (prc) return prc;
             persist_prof_report("bwd", l, S, st);
         }
+        const bool nn_dh = g_lstm_nn_bwd != 0 && (long)B * H >= (1L << 22);   // large batches only (measured)
+        if (!persist && nn_dh) launch_transpose(wh_l, w.whT, H, (int)G, st);   // (H, G) -> (G, H): B(k=g, n=h) = whT[g*H + h]
         for (int s = S - 1; s >= 0 && !persist; --s) {
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
             launch_cell_bwd(H, B, st, d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dh_parts,
@@ -819,9 +857,9 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
                             (const float*)(lw.hw + (size_t)s * B * G), (const float*)(lw.stats + (size_t)s * B * 4),
                             gamma_l, w.dgate + (size_t)s * B * G, w.dxw + (size_t)s * B * G,
                             w.dhw + (size_t)s * B * G, w.dc);
-            // dh_prev (B,H) = dHW_s (B,G) @ Wh^T : B(k=g, n=h) = Wh[h*G + g]
-            GemmArgs g{w.dhw + (size_t)s * B * G, wh_l, w.dh, B, H, (int)G, (long)G, 1, 1, (long)G, (long)H, 0, sk_dh,
-                       (long)BH};
+            // dh_prev (B,H) = dHW_s (B,G) @ Wh^T, as an NN product against the transposed copy
+            GemmArgs g{w.dhw + (size_t)s * B * G, nn_dh ? (const float*)w.whT : wh_l, w.dh, B, H, (int)G, (long)G, 1,
+                       nn_dh ? (long)H : 1, nn_dh ? 1 : (long)G, (long)H, 0, sk_dh, (long)BH};
             launch_gemm(g, st);
             dh_carry = w.dh;
             dh_parts = sk_dh;
