@@ -27,6 +27,7 @@
 namespace hpc_rll {
 int g_gemm_bk = 0;
 int g_gemm_xcd = 1;
+int g_lstm_dh_big = 1;   // experiments (tune key 12)
 int g_lstm_nn_bwd = 1;   // backward products against transposed weight copies (hpc_rll_tune_set key 11)
 int g_gemm_big_tile128 = 1;
 int g_gemm_big_target = 768;   // workgroups the split-K of the weight-gradient GEMMs aims for
@@ -551,7 +552,10 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.dgate = take(SB * G);
     w.dxw = take(SB * G);
     w.dhw = take(SB * G);
-    w.dh = take((size_t)gemm_splitk(B, H, (int)G) * B * H);        // split-K partials of dh_prev = dHW @ Wh^T
+    {   // split-K partials of dh_prev = dHW @ Wh^T (either tiling of that product)
+        const int a = gemm_splitk(B, H, (int)G), b = gemm_splitk_big(B, H, (int)G);
+        w.dh = take((size_t)(a > b ? a : b) * B * H);
+    }
     w.hw_part = take((size_t)gemm_splitk(B, (int)G, H) * B * G);   // split-K partials of h @ Wh
     w.dc = take((size_t)B * H);
     const size_t widest = SB * (size_t)(I > H ? I : H);
@@ -836,7 +840,9 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         const float* dh_carry = dhn ? dhn + (size_t)l * BH : nullptr;
         const float* dc_carry = dcn ? dcn + (size_t)l * BH : nullptr;
         int dh_parts = 1;                                   // how many split-K partials dh_carry consists of
-        const int sk_dh = gemm_splitk(B, H, (int)G);
+        const bool nn_dh = g_lstm_nn_bwd != 0 && (long)B * H >= (1L << 22);   // large batches only (measured)
+        // NN form: 128x128x16 tiles with their own split-K (one round of ~1024 workgroups), like the forward product
+        const int sk_dh = (nn_dh && g_lstm_dh_big) ? gemm_splitk_big(B, H, (int)G) : gemm_splitk(B, H, (int)G);
         if (persist) {   // one kernel walks the whole sequence of this layer backwards (lstm_persist.hpp)
             PersistBwd a{d_out, dh_carry, dc_carry, lw.gates, lw.c, c0 + (size_t)l * BH, lw.xw, lw.hw, lw.stats, gamma_l,
                          wh_l, w.dgate, w.dxw, w.dhw, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, (u64*)w.xchg,
@@ -846,7 +852,6 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             if (prc) return prc;
             persist_prof_report("bwd", l, S, st);
         }
-        const bool nn_dh = g_lstm_nn_bwd != 0 && (long)B * H >= (1L << 22);   // large batches only (measured)
         if (!persist && nn_dh) launch_transpose(wh_l, w.whT, H, (int)G, st);   // (H, G) -> (G, H): B(k=g, n=h) = whT[g*H + h]
         for (int s = S - 1; s >= 0 && !persist; --s) {
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
@@ -859,7 +864,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
                             w.dhw + (size_t)s * B * G, w.dc);
             // dh_prev (B,H) = dHW_s (B,G) @ Wh^T, as an NN product against the transposed copy
             GemmArgs g{w.dhw + (size_t)s * B * G, nn_dh ? (const float*)w.whT : wh_l, w.dh, B, H, (int)G, (long)G, 1,
-                       nn_dh ? (long)H : 1, nn_dh ? 1 : (long)G, (long)H, 0, sk_dh, (long)BH};
+                       nn_dh ? (long)H : 1, nn_dh ? 1 : (long)G, (long)H, 0, sk_dh, (long)BH, (nn_dh && g_lstm_dh_big) ? 1 : 0};
             launch_gemm(g, st);
             dh_carry = w.dh;
             dh_parts = sk_dh;
