@@ -372,7 +372,7 @@ inline int max_vec(int B, std::initializer_list<const void*> ptrs) {
 //     NEXT kernel (+35-45 us on the following launch).  For working sets beyond the Infinity Cache the forward also
 //     loads nontemporally, which helps itself and the backward that follows it.
 //   * streaming regime (one launch moves >= 300 MB): forward 2 columns/lane from B = 65536 up, 512 workgroups x
-//     4 waves x 8 steps or >= 1024 workgroups x 8 waves x 16 steps; backward 4 columns/lane, 4 x 4 in the middle,
+//     4 waves x 8 steps or >= 1024 workgroups x 8 waves x 16 steps; backward 2 columns/lane with 4 waves x 2 steps in the middle (4 columns/lane from B = 131072),
 //     1 column/lane 8 x 8 for narrow batches, 2 columns/lane 16 x 16 for very wide ones.
 //   * cache-resident regime: 1 column per lane and up to 16 waves x 16 steps so that ~2048 waves cover the chip even
 //     when there are few column tiles (B=64 -> one workgroup walking T in 256-step strides).
@@ -390,8 +390,10 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
         afl = 3;
     } else if (streaming) {
         if (B >= 262144 && vmax >= 2) { av = 2; alc = 16; anw = 16; }
-        else if (B >= 65536 && vmax >= 4) { av = 4; alc = 4; anw = 4; }
-        else if (B >= 65536 && vmax >= 2) { av = 2; alc = 4; anw = 4; }
+        // in-process A/B at B = 65536 (tests/tools/gae_bwd_ab.py): (2,2,4) 115.5 us, (4,2,4) 116.8, (4,4,4) 120.1;
+        // at B = 131072 (alt_shapes.py) (4,2,4) is best
+        else if (B >= 131072 && vmax >= 4) { av = 4; alc = 2; anw = 4; }
+        else if (B >= 65536 && vmax >= 2) { av = 2; alc = 2; anw = 4; }
         else { av = 1; alc = 8; anw = 8; }
         afl = 2;
     } else {
