@@ -1,6 +1,6 @@
 // lstm_persist.hpp -- persistent small-batch path of the LayerNorm-LSTM (included by lstm.hip only).
 //
-// Regime: B <= 8 (the reference's own test shape is S=64, B=3, I=1792, H=384, L=3: tests/test_lstm.py:12-17).  There
+// Regime: B <= 4 (the reference's own test shape is S=64, B=3, I=1792, H=384, L=3: tests/test_lstm.py:12-17).  There
 // the per-step work is ~1 us of arithmetic but the two-launch step (skinny GEMM + cell kernel) costs ~18 us of kernel
 // latency.  Here ONE kernel per layer walks all S steps:
 //   * workgroup w owns JW hidden units -> the 4*JW gate columns of Wh, resident in LDS for the whole sequence
@@ -31,13 +31,14 @@
 
 namespace hpc_rll {
 int g_lstm_persist = 1;          // hpc_rll_tune_set key 3
+constexpr int g_lstm_persist_max_b = 4;   // largest batch the persistent kernels take
 int g_lstm_jw = 0;               // hpc_rll_tune_set key 5: minimum hidden units per workgroup (0 = auto)
 int g_lstm_xchg_rep = 4;        // hpc_rll_tune_set key 4: replicas of every exchange word (1..32)
 namespace {
 
 typedef unsigned long long u64;
 constexpr long kSpinLimit = 1L << 22;
-constexpr int kPersistMaxB = 8;
+constexpr int kPersistMaxB = 4;
 
 __device__ __forceinline__ void xchg_put(u64* p, float v, uint32_t tag) {
     __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -606,9 +607,12 @@ struct PersistCfg { int nb, jw, nwg; size_t lds; };
 
 // is the persistent path applicable?  (forward and backward use the same LDS budget: 4*JW*H weights + a row buffer)
 inline bool persist_cfg(int B, int H, int row_floats /* per batch row staged in LDS */, PersistCfg* out) {
-    if (!g_lstm_persist || B < 1 || B > kPersistMaxB || H < 1 || H > 1024) return false;
+    // measured (tests/tools/lstm_small_probe.py, L=1, S=64): B <= 4 wins at every H (H=512: 0.68/1.02 vs 0.88/1.16 ms,
+    // H=1024: 0.75/1.24 vs 1.24/1.92); at B = 8 the exchanged volume (B*H and B*4H words per workgroup and step) makes it
+    // a tie or a loss against the split-K step kernels (H=256: 0.97/1.23 vs 0.74/0.89)
+    if (!g_lstm_persist || B < 1 || B > g_lstm_persist_max_b || H < 1 || H > 1024) return false;
     PersistCfg c;
-    c.nb = B <= 1 ? 1 : B <= 2 ? 2 : B <= 4 ? 4 : 8;
+    c.nb = B <= 1 ? 1 : B <= 2 ? 2 : 4;
     c.jw = H <= 256 ? 1 : H <= 512 ? 2 : 4;
     if (g_lstm_jw == 2 || g_lstm_jw == 4) c.jw = c.jw > g_lstm_jw ? c.jw : g_lstm_jw;   // experiments: fewer, fatter workgroups
     c.nwg = (H + c.jw - 1) / c.jw;
@@ -634,18 +638,15 @@ inline int launch_persist_fwd_t(const PersistCfg& c, const PersistFwd& a, hipStr
         if (c.jw == 1) {                                                               \
             if (c.nb == 1) return FN<1, 1>(c, a, st);                                  \
             if (c.nb == 2) return FN<2, 1>(c, a, st);                                  \
-            if (c.nb == 4) return FN<4, 1>(c, a, st);                                  \
-            return FN<8, 1>(c, a, st);                                                 \
+            return FN<4, 1>(c, a, st);                                                 \
         } else if (c.jw == 2) {                                                        \
             if (c.nb == 1) return FN<1, 2>(c, a, st);                                  \
             if (c.nb == 2) return FN<2, 2>(c, a, st);                                  \
-            if (c.nb == 4) return FN<4, 2>(c, a, st);                                  \
-            return FN<8, 2>(c, a, st);                                                 \
+            return FN<4, 2>(c, a, st);                                                 \
         } else {                                                                       \
             if (c.nb == 1) return FN<1, 4>(c, a, st);                                  \
             if (c.nb == 2) return FN<2, 4>(c, a, st);                                  \
-            if (c.nb == 4) return FN<4, 4>(c, a, st);                                  \
-            return FN<8, 4>(c, a, st);                                                 \
+            return FN<4, 4>(c, a, st);                                                 \
         }                                                                              \
     } while (0)
 
@@ -673,7 +674,7 @@ struct XchgLayout { size_t big_rep, sums_rep, big_par, sums_par, total_words; };
 inline XchgLayout xchg_layout(int B, int H) {
     XchgLayout x{0, 0, 0, 0, 0};
     if (B < 1 || B > kPersistMaxB || H < 1 || H > 1024) return x;
-    const int nb = B <= 1 ? 1 : B <= 2 ? 2 : B <= 4 ? 4 : 8;
+    const int nb = B <= 1 ? 1 : B <= 2 ? 2 : 4;
     x.big_rep = ((size_t)nb * 4 * H + 15) / 16 * 16;
     x.sums_rep = (size_t)256 * nb * 4;
     x.big_par = kMaxRep * x.big_rep;

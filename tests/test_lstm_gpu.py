@@ -208,7 +208,7 @@ def test_lstm_dropout(B):
                                        (12, 2, 16, 257, 2), (4, 7, 5, 3, 3), (3, 4, 8, 512, 1), (1, 2, 6, 20, 3),
                                        (2, 1, 3, 5, 2), (33, 4, 9, 130, 4), (5, 3, 4, 512, 2)])
 def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
-    """B <= 8 runs the persistent per-layer kernels (lstm_persist.hpp); hpc_rll_tune_set(3, 0) forces the step-kernel
+    """B <= 4 runs the persistent kernels (lstm_persist.hpp / lstm_wave.hpp; the B > 4 cases here exercise the step path twice); hpc_rll_tune_set(3, 0) forces the step-kernel
     path (GEMM + cell kernel per step).  Same math, different summation order in the recurrent products, and fp32
     rounding is amplified along the S*L chain of LayerNorms, so the two paths are compared through the fp64 oracle:
     the persistent path must be as close to it as the step path is (factor 2), or within the base tolerance."""
