@@ -247,3 +247,23 @@ def test_full_size_parity_and_properties(dev, cref):
     adv2 = torch.empty_like(dr)
     U.GaeForward([dv * 2, dr * 2], [adv2], 0.99, 0.97)
     assert torch.equal(adv2, adv * 2)
+
+
+def test_c_abi_program_on_gpu(tmp_path):
+    """No Python, no torch above the boundary: tests/abi_gpu_smoke.cpp hipMallocs its buffers, calls the C ABI on its own
+    stream and checks forward and backward against a host fp64 evaluation (tolerance 1e-5, written in the program)."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    lib_dir = os.path.join(ROOT, "di-hpc_amd", "hpc_rll", "_lib")
+    exe = str(tmp_path / "abi_gpu_smoke")
+    cmd = [hipcc, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_gpu_smoke.cpp"),
+           "-o", exe, "-L", lib_dir, "-lhpc_rll_hip", f"-Wl,-rpath,{lib_dir}"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c abi gpu ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
