@@ -445,6 +445,39 @@ def _device_table(rows, dev):
     return t.pin_memory().to(dev, non_blocking=True)
 
 
+def _pad_table(inputs, rank):
+    """(n,4) int64 host table [data_ptr, d0, d1, d2] (own axes right-aligned, leading ones) and the (n,rank) shapes of a
+    list of rank-`rank` tensors.  Pure host logic (works on CPU tensors: covered by the CPU test tier).
+    t.shape builds a torch.Size per tensor (~0.9 us); numel()/size(d) return plain ints (0.12 / 0.3 us)."""
+    n = len(inputs)
+    if rank == 1:
+        shapes = np.fromiter(map(torch.Tensor.numel, inputs), dtype=np.int64, count=n).reshape(n, 1)
+    else:
+        shapes = np.stack([np.fromiter(map(operator.methodcaller("size", d), inputs), dtype=np.int64, count=n)
+                           for d in range(rank)], axis=1)
+    table = np.ones((n, 4), dtype=np.int64)
+    table[:, 0] = np.fromiter(map(torch.Tensor.data_ptr, inputs), dtype=np.int64, count=n)
+    table[:, 4 - rank:] = shapes
+    return table, shapes
+
+
+def _unpad_table(shapes, padded_shape, rank):
+    """Host table of the inverse: (n,4) int64 [flat offset, d0, d1, d2], per-tensor element counts, offsets (n+1) and the
+    (n,rank) shape array, from the flat `shapes` list; raises if a shape does not fit the padded tensor."""
+    n = len(shapes) // rank
+    sh = np.asarray(shapes, dtype=np.int64).reshape(n, rank)
+    lim = np.asarray(padded_shape, dtype=np.int64)
+    if n and ((sh < 0).any() or (sh > lim).any()):
+        bad = int(np.argmax(((sh < 0) | (sh > lim)).any(axis=1)))
+        raise RuntimeError(f"shapes: {tuple(int(v) for v in sh[bad])} does not fit the padded tensor {tuple(padded_shape)}")
+    numel = sh.prod(axis=1) if n else np.zeros(0, dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(numel)]).astype(np.int64)
+    table = np.ones((n, 4), dtype=np.int64)
+    table[:, 0] = offs[:-1]
+    table[:, 4 - rank:] = sh
+    return table, numel, offs, sh
+
+
 def _pad_forward(inputs, value, rank, max_shape=None):
     """Host side of the list-of-tensors API.  A python loop over n tensors costs ~2 us per tensor (0.25 s at n = 131k,
     against a 45 us kernel), so validation and the (pointer, shape) table are built with C-level iteration (map /
@@ -463,18 +496,10 @@ def _pad_forward(inputs, value, rank, max_shape=None):
             N.require(t, f"inputs[{i}]", device=dev)
             if t.dim() != rank:
                 raise RuntimeError(f"inputs[{i}]: rank {t.dim()}, expected {rank}")
-    # t.shape builds a torch.Size per tensor (~0.9 us); numel()/size(d) return plain ints (0.12 / 0.3 us)
-    if rank == 1:
-        shapes = np.fromiter(map(torch.Tensor.numel, inputs), dtype=np.int64, count=n).reshape(n, 1)
-    else:
-        shapes = np.stack([np.fromiter(map(operator.methodcaller("size", d), inputs), dtype=np.int64, count=n)
-                           for d in range(rank)], axis=1)
+    table, shapes = _pad_table(inputs, rank)
     if max_shape is None:
         max_shape = [int(v) for v in shapes.max(axis=0)]
     m = _dims3(max_shape)
-    table = np.ones((n, 4), dtype=np.int64)
-    table[:, 0] = np.fromiter(map(torch.Tensor.data_ptr, inputs), dtype=np.int64, count=n)
-    table[:, 4 - rank:] = shapes
     table = torch.from_numpy(table).pin_memory().to(dev, non_blocking=True)
     new_x = torch.empty([n] + list(max_shape), dtype=F32, device=dev)
     mask = torch.empty([n] + list(max_shape), dtype=torch.int32, device=dev)
@@ -537,20 +562,11 @@ def _unpad_forward(x, shapes, rank):
     if len(shapes) != n * rank:
         raise RuntimeError(f"shapes: {len(shapes)} ints, expected {n}*{rank}")
     dev = x.device
-    sh = np.asarray(shapes, dtype=np.int64).reshape(n, rank)
-    lim = np.asarray(x.shape[1:], dtype=np.int64)
-    if n and ((sh < 0).any() or (sh > lim).any()):
-        bad = int(np.argmax(((sh < 0) | (sh > lim)).any(axis=1)))
-        raise RuntimeError(f"shapes: {tuple(int(v) for v in sh[bad])} does not fit the padded tensor {tuple(x.shape[1:])}")
-    numel = sh.prod(axis=1) if n else np.zeros(0, dtype=np.int64)
-    offs = np.concatenate([[0], np.cumsum(numel)]).astype(np.int64)
+    table, numel, offs, sh = _unpad_table(shapes, tuple(x.shape[1:]), rank)
     total = int(offs[-1])
     flat = torch.empty(total, dtype=F32, device=dev)
     if n and total:
         m = _dims3(x.shape[1:])
-        table = np.ones((n, 4), dtype=np.int64)
-        table[:, 0] = offs[:-1]
-        table[:, 4 - rank:] = sh
         table = torch.from_numpy(table).pin_memory().to(dev, non_blocking=True)
         N.call("hpc_rll_unpad_forward", dev, x.data_ptr(), table.data_ptr(), flat.data_ptr(), n, total, m[0], m[1], m[2])
     if rank == 1:   # split is one C++ call; the generic path builds n views from python

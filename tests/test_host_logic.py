@@ -68,3 +68,32 @@ def test_large_list_is_fast():
     t = time.time()
     pos = _split(nl, 8)[-1]
     assert time.time() - t < 20 and pos[0] == 0 and pos[-1] == len(nl) and len(pos) == 9
+
+
+def test_pad_and_unpad_host_tables():
+    """The (pointer, shape) tables the pad / unpad kernels consume are built with C-level iteration + numpy
+    (hpc_rl_utils._pad_table / _unpad_table); pure host logic, checked here against the obvious per-tensor loops."""
+    import hpc_rl_utils as U
+    rng = np.random.default_rng(0)
+    for rank in (1, 2, 3):
+        shapes = [tuple(int(v) for v in rng.integers(1, 6, rank)) for _ in range(17)]
+        xs = [torch.zeros(*s) for s in shapes]
+        table, sh = U._pad_table(xs, rank)
+        assert table.shape == (17, 4) and sh.shape == (17, rank)
+        for i, (t, s_) in enumerate(zip(xs, shapes)):
+            assert table[i, 0] == t.data_ptr()
+            assert tuple(table[i, 1:]) == (1,) * (3 - rank) + s_
+            assert tuple(sh[i]) == s_
+        flat_shapes = [d for s_ in shapes for d in s_]
+        lim = tuple(int(v) for v in np.max(np.array(shapes), axis=0))
+        tab, numel, offs, sh2 = U._unpad_table(flat_shapes, lim, rank)
+        want = [int(np.prod(s_)) for s_ in shapes]
+        assert numel.tolist() == want and offs.tolist() == [0] + list(np.cumsum(want))
+        assert tab[:, 0].tolist() == offs[:-1].tolist()
+        assert [tuple(r[4 - rank:]) for r in tab] == shapes and np.all(tab[:, 1:4 - rank] == 1)
+        bad = list(flat_shapes)
+        bad[0] = lim[0] + 1                                      # does not fit the padded tensor
+        with pytest.raises(RuntimeError):
+            U._unpad_table(bad, lim, rank)
+    tab, numel, offs, _ = U._unpad_table([], (4,), 1)            # empty list
+    assert tab.shape == (0, 4) and offs.tolist() == [0]
