@@ -298,7 +298,8 @@ inline int gemm_splitk(int M, int N, int K) {
     const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
     const int ktiles = (K + 31) / 32;
     int s = 1;
-    while (s < 16 && tiles * s < 256 && ktiles / (s * 2) >= 2) s *= 2;    // latency regime: fill the CUs at all
+    extern int g_gemm_lat_target;   // tuning knob (hpc_rll_tune_set key 12), 256 = one workgroup per CU
+    while (s < 16 && tiles * s < g_gemm_lat_target && ktiles / (s * 2) >= 2) s *= 2;    // latency regime: fill the CUs
     while (s < 16 && tiles * s < 768 && ktiles / (s * 2) >= 32) s *= 2;   // throughput regime: 3-4 workgroups per CU
     return s;                                                             // while the slices stay long (C4 dh: 2)
 }
