@@ -299,8 +299,12 @@ inline int gemm_splitk(int M, int N, int K) {
     const int ktiles = (K + 31) / 32;
     int s = 1;
     extern int g_gemm_lat_target;   // tuning knob (hpc_rll_tune_set key 12), 256 = one workgroup per CU
-    while (s < 16 && tiles * s < g_gemm_lat_target && ktiles / (s * 2) >= 2) s *= 2;    // latency regime: fill the CUs
-    while (s < 16 && tiles * s < 768 && ktiles / (s * 2) >= 32) s *= 2;   // throughput regime: 3-4 workgroups per CU
+    // latency regime: fill the CUs (in-process sweep over mid-batch LSTM shapes: 256 workgroups up to M = 256, two per CU
+    // from M = 512: B=1024,H=512 4.62/7.37 -> 4.11/7.02 ms)
+    const long lat_target = M >= 512 ? 2L * g_gemm_lat_target : g_gemm_lat_target;
+    while (s < 16 && tiles * s < lat_target && ktiles / (s * 2) >= 2) s *= 2;
+    extern int g_gemm_thr_ktiles;   // tuning knob (hpc_rll_tune_set key 14)
+    while (s < 16 && tiles * s < 768 && ktiles / (s * 2) >= g_gemm_thr_ktiles) s *= 2;   // throughput regime: 3-4 workgroups per CU
     return s;                                                             // while the slices stay long (C4 dh: 2)
 }
 

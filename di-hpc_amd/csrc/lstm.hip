@@ -28,6 +28,7 @@ namespace hpc_rll {
 int g_gemm_bk = 0;
 int g_gemm_xcd = 1;
 int g_gemm_lat_target = 256;
+int g_gemm_thr_ktiles = 8;    // in-process sweep (B=512..2048): 8 -> forward -3..6 %, backward +-1 %; C4 unaffected
 int g_lstm_dh_big = 1;   // experiments (tune key 12)
 int g_lstm_nn_bwd = 1;   // backward products against transposed weight copies (hpc_rll_tune_set key 11)
 int g_gemm_big_tile128 = 1;
