@@ -26,6 +26,7 @@
 
 namespace hpc_rll {
 int g_gemm_bk = 0;
+int g_cell_vec4 = 3;   // smallest ceil(H/256) that takes the 16-byte forward cell kernel (tune key 15; 0 = never)
 int g_gemm_xcd = 1;
 int g_gemm_lat_target = 256;
 int g_gemm_thr_ktiles = 8;    // in-process sweep (B=512..2048): 8 -> forward -3..6 %, backward +-1 %; C4 unaffected
@@ -493,13 +494,12 @@ inline void launch_cell_fwd_scalar(int H, int B, hipStream_t st, Args... a) {
     else hipLaunchKernelGGL(lstm_cell_fwd_kernel<8>, dim3(B), dim3(256), 0, st, a..., H);
 }
 inline bool cell_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-int g_cell_vec4 = 1;   // experiments
 
 inline void launch_cell_fwd(int H, int B, hipStream_t st, const float* xw, const float* hw, int nsplit, long part_stride,
                             float* hw_out, const float* bias, const float* gamma, const float* beta, const float* c_prev,
                             float* gates, float* c_out, float* h_out, float* stats) {
     const int jpt = (H + 255) / 256;
-    if (g_cell_vec4 && jpt > 2 && (H % 4) == 0 && (part_stride % 4) == 0 && cell_al16(xw) && cell_al16(hw) &&
+    if (g_cell_vec4 && jpt >= g_cell_vec4 && (H % 4) == 0 && (part_stride % 4) == 0 && cell_al16(xw) && cell_al16(hw) &&
         cell_al16(hw_out) && cell_al16(bias) && cell_al16(gamma) && cell_al16(beta) && cell_al16(c_prev) &&
         cell_al16(gates) && cell_al16(c_out) && cell_al16(h_out)) {
         if (H <= 1024)

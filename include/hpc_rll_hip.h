@@ -96,7 +96,8 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * key 9: LDS KiB per workgroup of the scatter backward kernel (16..128).  key 10: XCD-aware GEMM tile order on/off.
  * key 11: LSTM backward products against transposed weight copies (large batches) on/off.  key 12: 128x128 tiles
  * for the dh product when it runs as NN.  key 13: workgroups the latency-regime split-K aims for (default 256).
- * key 14: k-tiles (of 32) a slice must keep in the throughput-regime split-K (default 8). */
+ * key 14: k-tiles (of 32) a slice must keep in the throughput-regime split-K (default 8).  key 15: smallest
+ * ceil(H/256) that takes the 16-byte forward cell kernel (default 3, 0 = never). */
 int hpc_rll_tune_set(int key, int value);
 
 /* TD(lambda) -- replaces TdLambdaForward/Backward (rl_utils/entry.h:68-77, src/rl_utils/td_lambda.cu:8-52).
