@@ -179,10 +179,14 @@ def test_gpu_two_ranks_match_single_process():
     full = [p.grad.cpu().numpy() for p in m.parameters()]
     k = B // world
     for rank, r1, r3, gv, gt, radv, lstm in res:
-        for a, b in zip(full, lstm[:-1]):                       # summed weight gradients == full-batch gradients
-            assert rel_err(a, b) < 1e-5
+        # Summed weight gradients == full-batch gradients.  The half batches (B=4) run the layer-wavefront kernels and
+        # the full batch (B=8) the step kernels, so the two sides differ by fp32 rounding through S*L LayerNorms over
+        # H=12 columns (tests/tools/lstm_dp_err_probe.py: 1e-5 and 4e-5 from the fp64 oracle respectively); the bound is
+        # the gradient tolerance test_lstm_oracle uses.
+        for a, b in zip(full, lstm[:-1]):
+            assert rel_err(a, b) < 2e-4
         kb = LB // world
-        assert rel_err(x.grad.cpu().numpy()[:, rank * kb:(rank + 1) * kb], lstm[-1]) < 1e-5
+        assert rel_err(x.grad.cpu().numpy()[:, rank * kb:(rank + 1) * kb], lstm[-1]) < 2e-4
         assert rel_err(l1.item(), r1) < 1e-6
         assert rel_err([x.item() for x in l3], r3) < 1e-6
         assert rel_err(v.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gv) < 1e-6
