@@ -40,7 +40,14 @@ template <int CTRL> __device__ __forceinline__ float dpp(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
 struct SumOp { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
-struct MaxOp { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+// max of two values that are never NaN here (finish() removed NaNs): med3(a, b, +inf) is ONE v_med3_f32, whereas fmaxf
+// first canonicalises an operand the compiler cannot prove quiet (every DPP move): 3 instructions per butterfly step -> 2
+// (+inf comes out of an asm so that the compiler cannot fold med3(a, b, inf) back into maxnum(a, b) + canonicalise)
+__device__ __forceinline__ float opaque_inf() { float v; asm("s_mov_b32 %0, 0x7f800000" : "=s"(v)); return v; }
+struct MaxOp { static __device__ __forceinline__ float f(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, opaque_inf()); } };
+// log of a partition sum relative to the row maximum: s is in [1, N], so the bare v_log_f32 (log2) needs neither the
+// denormal pre-scaling nor the two-word ln2 product of __logf (14 instructions per row -> 2)
+__device__ __forceinline__ float log_sum(float s) { return __builtin_amdgcn_logf(s) * 0.69314718055994530942f; }
 template <int G, class Op> __device__ __forceinline__ float group_all(float x) {
     if (G >= 2) x = Op::f(x, dpp<0xB1>(x));    // quad_perm [1,0,3,2]
     if (G >= 4) x = Op::f(x, dpp<0x4E>(x));    // quad_perm [2,3,0,1]
@@ -52,6 +59,14 @@ template <int G, class Op> __device__ __forceinline__ float group_all(float x) {
 }
 
 // Per-lane slice of one row: E pieces of VEC consecutive floats, piece e at column (e*G + gl)*VEC.
+// Two phases.  load() only ISSUES the (nontemporal: logits are read exactly once) loads: every lane loads
+// unconditionally -- padding lanes re-read column 0 -- so there is no divergent branch around a load and all E loads of
+// all R rows of an iteration are in flight before the first use.  finish() then clamps with ONE v_med3_f32 per
+// element: -inf (masked action) becomes the most negative finite float, padding (hi = -FLT_MAX there) becomes that
+// same value, a NaN logit becomes -FLT_MAX exactly as fmaxf(x, -FLT_MAX) made it.  (The first version clamped inside
+// `if (c < N)`, which compiled to a branch and s_waitcnt vmcnt(0) per load plus two v_max per element; in an in-process
+// A/B the two builds time the same to 1 % at every N (tests/tools/cat_ab_probe.py: the kernels are VALU-bound and
+// eight waves per SIMD hid the serialised loads) -- this form is kept for being branch-free and 40 instructions shorter.)
 template <int G, int VEC, int E>
 struct RowSlice {
     float x[E * VEC];
@@ -59,18 +74,22 @@ struct RowSlice {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int c = (e * G + gl) * VEC;
+            const int cc = (c < N) ? c : 0;
             if (VEC == 4) {
-                if (c < N) {
-                    // logits are read exactly once: nontemporal (streaming) load
-                    const vfloat4 t = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(row + c));
-                    x[e * 4 + 0] = clamp_logit(t.x); x[e * 4 + 1] = clamp_logit(t.y);
-                    x[e * 4 + 2] = clamp_logit(t.z); x[e * 4 + 3] = clamp_logit(t.w);
-                } else {
-                    x[e * 4 + 0] = x[e * 4 + 1] = x[e * 4 + 2] = x[e * 4 + 3] = -kFltMax;   // padding (finite: merges stay NaN-free)
-                }
+                const vfloat4 t = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(row + cc));
+                x[e * 4 + 0] = t.x; x[e * 4 + 1] = t.y; x[e * 4 + 2] = t.z; x[e * 4 + 3] = t.w;
             } else {
-                x[e] = (c < N) ? clamp_logit(__builtin_nontemporal_load(row + c)) : -kFltMax;
+                x[e] = __builtin_nontemporal_load(row + cc);
             }
+        }
+    }
+    __device__ __forceinline__ void finish(int N, int gl) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = (e * G + gl) * VEC;
+            const float hi = (c < N) ? __builtin_inff() : -kFltMax;   // padding: finite, so that merges stay NaN-free
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) x[e * VEC + k] = __builtin_amdgcn_fmed3f(x[e * VEC + k], -kFltMax, hi);
         }
     }
 };
@@ -103,7 +122,7 @@ struct RowAcc { float m, s, t, xa; };
 // merge the statistics of two disjoint parts of a row (each relative to its own maximum)
 __device__ __forceinline__ RowAcc merge(const RowAcc& a, const RowAcc& b) {
     RowAcc r;
-    r.m = fmaxf(a.m, b.m);
+    r.m = MaxOp::f(a.m, b.m);
     const float da = a.m - r.m, db = b.m - r.m;
     const float wa = __expf(da), wb = __expf(db);
     r.s = a.s * wa + b.s * wb;
@@ -140,8 +159,8 @@ __device__ __forceinline__ RowAcc lane_stats(const RowSlice<G, VEC, E>& r, int N
                 s2 += e2;
                 t2 = __builtin_elementwise_fma(e2, d2, t2);
                 const int c = (e * G + gl) * VEC + k;
-                a.xa += (c == ai) ? r.x[i] : 0.f;
-                a.xa += (c + 1 == ai) ? r.x[i + 1] : 0.f;
+                a.xa = (c == ai) ? r.x[i] : a.xa;          // at most one column matches: a select, not a masked add
+                a.xa = (c + 1 == ai) ? r.x[i + 1] : a.xa;
             }
         a.s = s2.x + s2.y;
         a.t = t2.x + t2.y;
@@ -155,7 +174,7 @@ __device__ __forceinline__ RowAcc lane_stats(const RowSlice<G, VEC, E>& r, int N
                 ex[i] = __expf(d);
                 a.s += ex[i];
                 a.t = fmaf(ex[i], d, a.t);
-                a.xa += ((e * G + gl) * VEC + k == ai) ? r.x[i] : 0.f;
+                a.xa = ((e * G + gl) * VEC + k == ai) ? r.x[i] : a.xa;
             }
     } else {
 #pragma unroll
@@ -168,7 +187,7 @@ __device__ __forceinline__ RowAcc lane_stats(const RowSlice<G, VEC, E>& r, int N
                 ex[i] = (c < N) ? __expf(d) : 0.f;
                 a.s += ex[i];
                 a.t = (c < N) ? fmaf(ex[i], d, a.t) : a.t;
-                a.xa += (c == ai) ? r.x[i] : 0.f;
+                a.xa = (c == ai) ? r.x[i] : a.xa;
             }
     }
     return a;
@@ -203,7 +222,7 @@ __device__ __forceinline__ void row_stats_fwd(const RowSlice<G, VEC, E>& r, int 
         const RowAcc mm = merge(a, b);
         a.m = hi ? mm.m : a.m; a.s = hi ? mm.s : a.s; a.t = hi ? mm.t : a.t; a.xa = hi ? mm.xa : a.xa;
     }
-    const float ls = __logf(a.s);
+    const float ls = log_sum(a.s);
     logp_a = a.xa - (a.m + ls);
     ent = ls - a.t * __builtin_amdgcn_rcpf(a.s);
 }
@@ -219,7 +238,7 @@ __device__ __forceinline__ void row_stats(const RowSlice<G, VEC, E>& r, int N, i
     const RowAcc a = lane_stats<G, VEC, E, false>(r, N, gl, ai, full, ex, m);
     const float s = group_all<G, SumOp>(a.s);
     const float t = group_all<G, SumOp>(a.t);
-    const float ls = __logf(s);
+    const float ls = log_sum(s);
     inv_sum = __builtin_amdgcn_rcpf(s);
     lse = m + ls;
     ent = ls - t * inv_sum;
@@ -241,21 +260,28 @@ __device__ __forceinline__ void categorical_fwd_body(const float* __restrict__ l
     const int gi = threadIdx.x / G;
     const bool full = N == G * VEC * E;   // uniform: no padding lanes
     // row of (iteration block bb, slot k, group gi) = bb + k*GPB + gi: for a fixed k the groups of the whole workgroup
-    // read consecutive rows, i.e. one contiguous span per load instruction whatever G is
-    for (long bb = (long)blockIdx.x * GPB * R; bb < rows; bb += (long)gridDim.x * GPB * R) {
+    // read consecutive rows, i.e. one contiguous span per load instruction whatever G is.
+    // Row addresses advance by a uniform stride (one 64-bit add per iteration): row * N as a per-row 64-bit product
+    // cost two quarter-rate v_mul_lo_u32 and a v_mad_u64_u32 per row in a VALU-bound kernel.  Rows past the end
+    // (last iteration only) re-read the last row; their stores are guarded.
+    const long stride = (long)gridDim.x * GPB * R;
+    const float* const last_row = logits + (rows - 1) * (long)N;
+    long w0 = (long)blockIdx.x * GPB * R + gi;                 // this group's row in slot 0
+    const float* p0 = logits + w0 * (long)N;
+    for (long bb = (long)blockIdx.x * GPB * R; bb < rows; bb += stride, w0 += stride, p0 += stride * N) {
         RowSlice<G, VEC, E> r[R];
         long a[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const long want = bb + (long)k * GPB + gi;
-            const long row = want < rows ? want : rows - 1;   // clamp: uniform control flow, store is guarded
-            r[k].load(logits + row * (long)N, N, gl);
-            a[k] = action[row];
+            const bool ok = w0 + (long)k * GPB < rows;
+            r[k].load(ok ? p0 + (long)k * GPB * N : last_row, N, gl);
+            a[k] = action[ok ? w0 + (long)k * GPB : rows - 1];
         }
         float lp[R], h[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int ai = (a[k] >= 0 && a[k] < (long)N) ? (int)a[k] : -1;
+            r[k].finish(N, gl);
             row_stats_fwd<G, VEC, E>(r[k], N, gl, ai, full, lp[k], h[k]);
         }
         if (gl == G - 1) {
@@ -301,15 +327,19 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __res
     const float u1 = g1 ? g1[0] : 1.f;
     const float u2 = (c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
     const bool full = N == G * VEC * E;
-    for (long bb = (long)blockIdx.x * GPB * R; bb < rows; bb += (long)gridDim.x * GPB * R) {
+    const long stride = (long)gridDim.x * GPB * R;            // uniform row stride per iteration (see the forward body)
+    const long last_off = (rows - 1) * (long)N;
+    long w0 = (long)blockIdx.x * GPB * R + gi;
+    long off0 = w0 * (long)N;                                  // element offset of this group's slot-0 row
+    for (long bb = (long)blockIdx.x * GPB * R; bb < rows; bb += stride, w0 += stride, off0 += stride * N) {
         RowSlice<G, VEC, E> r[R];
         long a[R];
         float k1[R], k2[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const long want = bb + (long)k * GPB + gi;
-            const long row = want < rows ? want : rows - 1;
-            r[k].load(logits + row * (long)N, N, gl);
+            const bool ok = w0 + (long)k * GPB < rows;
+            const long row = ok ? w0 + (long)k * GPB : rows - 1;
+            r[k].load(logits + (ok ? off0 + (long)k * GPB * N : last_off), N, gl);
             a[k] = action[row];
             k1[k] = u1 * c1[row];
             k2[k] = (c2 != nullptr) ? u2 * c2[row] : 0.f;
@@ -318,10 +348,10 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __res
         for (int k = 0; k < R; ++k) {
             float ex[E * VEC], lse, inv, h;
             const int ai = (a[k] >= 0 && a[k] < (long)N) ? (int)a[k] : -1;
+            r[k].finish(N, gl);
             row_stats<G, VEC, E>(r[k], N, gl, ai, full, ex, lse, inv, h);
-            const long orow = bb + (long)k * GPB + gi;
-            if (orow >= rows) continue;
-            float* __restrict__ out = grad + orow * (long)N;
+            if (w0 + (long)k * GPB >= rows) continue;
+            float* __restrict__ out = grad + (off0 + (long)k * GPB * N);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int c0 = (e * G + gl) * VEC;

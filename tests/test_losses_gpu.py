@@ -105,6 +105,55 @@ def test_vtrace_oracle(T, B, N):
     assert rel_err(v64.grad.numpy(), dv.grad.cpu().numpy()) < GTOL
 
 
+def _mask(rng, logits, action, frac=0.3):
+    """-inf on a random subset of the NON-chosen actions (an action mask, as DI-engine feeds it)."""
+    m = rng.random(logits.shape) < frac
+    np.put_along_axis(m, action[..., None], False, axis=-1)
+    out = logits.copy()
+    out[m] = -np.inf
+    return out
+
+
+@pytest.mark.parametrize("T,B,N", [(16, 64, 128), (8, 40, 18), (5, 33, 1000), (4, 9, 6), (3, 7, 5001)])
+def test_masked_actions_vtrace_ppo(T, B, N):
+    """Masked actions arrive as logits = -inf: probability 0, no entropy contribution, zero gradient -- what
+    torch.distributions.Categorical (hpc_rll.origin's softmax/entropy, origin/vtrace.py:76-79, origin/ppo.py:57-61)
+    does by clamping log p to the most negative finite float.  Every row shape of the categorical kernels."""
+    from hpc_rll.rl_utils.ppo import PPO
+    from hpc_rll.rl_utils.vtrace import VTrace
+    rng = np.random.default_rng(N + T)
+    a = rng.integers(0, N, (T, B)).astype(np.int64)
+    to, bo = _mask(rng, f32(rng, T, B, N), a), _mask(rng, f32(rng, T, B, N), a)
+    v, r = f32(rng, T + 1, B), f32(rng, T, B)
+    to64, v64 = D(to, True), D(v, True)
+    l64 = R.vtrace_error(to64, D(bo), torch.from_numpy(a), v64, D(r), None, 0.99, 0.95, 1.0, 1.0, 1.0)
+    sum(l64).backward()
+    dto, dv = G(to, True), G(v, True)
+    ls = VTrace(T, B, N)(dto, G(bo), G(a), dv, G(r))
+    sum(ls).backward()
+    assert all(np.isfinite(x.item()) for x in ls) and torch.isfinite(dto.grad).all()
+    assert rel_err([x.item() for x in l64], [x.item() for x in ls]) < TOL
+    assert rel_err(to64.grad.numpy(), dto.grad.cpu().numpy()) < GTOL
+    assert (dto.grad.cpu().numpy()[np.isinf(to)] == 0).all()          # masked actions get exactly zero gradient
+    assert rel_err(v64.grad.numpy(), dv.grad.cpu().numpy()) < GTOL
+
+    Bp = T * B
+    ap = a.reshape(Bp)
+    ln = to.reshape(Bp, N)
+    lo = np.where(np.isinf(ln), ln, (ln + 0.3 * f32(rng, Bp, N))).astype(np.float32)   # the same mask on both policies
+    vn, vo, adv, ret = f32(rng, Bp), f32(rng, Bp), f32(rng, Bp), f32(rng, Bp)
+    ln64, vn64 = D(ln, True), D(vn, True)
+    p64, i64 = R.ppo_error(ln64, D(lo), torch.from_numpy(ap), vn64, D(vo), D(adv), D(ret), None, 0.2, True, None)
+    sum(p64).backward()
+    dln, dvn = G(ln, True), G(vn, True)
+    pl, info = PPO(Bp, N)(dln, G(lo), G(ap), dvn, G(vo), G(adv), G(ret), None, 0.2, True, None)
+    sum(pl).backward()
+    assert rel_err([x.item() for x in p64], [x.item() for x in pl]) < TOL
+    assert rel_err(list(i64), list(info)) < 1e-4
+    assert rel_err(ln64.grad.numpy(), dln.grad.cpu().numpy()) < GTOL
+    assert (dln.grad.cpu().numpy()[np.isinf(ln)] == 0).all()
+
+
 # ------------------------------------------------------------------------------------------------ UPGO
 def test_upgo_golden(golden):
     from hpc_rll.rl_utils.upgo import UPGO
