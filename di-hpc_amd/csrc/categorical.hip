@@ -16,7 +16,9 @@
 //   * R rows are processed per group per iteration (independent reduction chains interleave, hiding the
 //     cross-lane latency), the 16-lane part of every butterfly is DPP (no LDS traffic), exp/log are the
 //     hardware v_exp_f32 / v_log_f32 forms: first version (1 row at a time, ds_bpermute butterflies, libm expf)
-//     was row-rate bound at 3.3 TB/s.
+//     was row-rate bound at 3.3 TB/s;
+//   * rows of 2048 < N <= 16384 (N % 4 == 0) are held by a whole WORKGROUP in registers (categorical_blockrow_kernel):
+//     forward 6.8 TB/s, backward 5.6-5.9 TB/s at N = 4096 / 8192 / 16384 (the LDS-row kernel they replace: 1-3 TB/s).
 //
 // Algorithmic HBM bytes: forward 4*N + 8 (+8 for the int64 action) per row; backward 4*N read + 4*N write.
 #include <hip/hip_runtime.h>
@@ -441,7 +443,106 @@ __global__ __launch_bounds__(256) void categorical_small_kernel(const float* __r
     }
 }
 
-// ---- long rows (N beyond the register path, up to 16384): one workgroup per row, the row is read from HBM ONCE into
+// ---- wide rows, 2048 < N <= 16384 with N % 4 == 0: one WORKGROUP per row, the row lives in registers (E float4 per
+// thread, all loads in flight at once), statistics in one pass exactly like the G-lane kernels (max, then s = sum e_i and
+// t = sum e_i d_i from the same exp), two barriers per row through double-buffered LDS words.  Replaces the LDS-row
+// kernel on these shapes (4-byte loads, three passes and two exps per element: 1.8 TB/s at N = 8192).
+template <int E, bool BWD>
+__global__ __launch_bounds__(256) void categorical_blockrow_kernel(const float* __restrict__ logits,
+                                                                   const int64_t* __restrict__ action,
+                                                                   float* __restrict__ logp_out,
+                                                                   float* __restrict__ ent_out,
+                                                                   const float* __restrict__ c1,
+                                                                   const float* __restrict__ g1,
+                                                                   const float* __restrict__ c2,
+                                                                   const float* __restrict__ g2,
+                                                                   float* __restrict__ grad, long rows, int N) {
+    __shared__ float red_m[2][4], red_s[2][4], red_t[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float u1 = (BWD && g1) ? g1[0] : 1.f;
+    const float u2 = (BWD && c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
+    int buf = 0;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x, buf ^= 1) {
+        const float* __restrict__ x = logits + row * (long)N;
+        float v[E * 4];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = (e * 256 + (int)threadIdx.x) * 4;
+            const vfloat4 t = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(x + (c < N ? c : 0)));
+            v[e * 4 + 0] = t.x; v[e * 4 + 1] = t.y; v[e * 4 + 2] = t.z; v[e * 4 + 3] = t.w;
+        }
+        const long a = action[row];
+        const bool a_ok = a >= 0 && a < (long)N;
+        float xa = 0.f;
+        if (!BWD) xa = x[a_ok ? a : 0];                      // one 4-byte load, in flight with the row
+        float k1 = 0.f, k2 = 0.f;
+        if (BWD) {
+            k1 = u1 * c1[row];
+            k2 = (c2 != nullptr) ? u2 * c2[row] : 0.f;
+        }
+        float m = -kFltMax;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float hi = ((e * 256 + (int)threadIdx.x) * 4 < N) ? __builtin_inff() : -kFltMax;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[e * 4 + k] = __builtin_amdgcn_fmed3f(v[e * 4 + k], -kFltMax, hi);
+                m = fmaxf(m, v[e * 4 + k]);
+            }
+        }
+        m = group_all<64, MaxOp>(m);
+        if (lane == 0) red_m[buf][w] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red_m[buf][0], red_m[buf][1]), fmaxf(red_m[buf][2], red_m[buf][3]));
+        float s = 0.f, t = 0.f;
+#pragma unroll
+        for (int i = 0; i < E * 4; ++i) {
+            const float d = v[i] - m;
+            const float ex = __expf(d);
+            s += ex;
+            t = fmaf(ex, d, t);
+            if (BWD) v[i] = d;          // keep d; exp(d) is recomputed below only when registers are short (E = 16)
+        }
+        s = group_all<64, SumOp>(s);
+        t = group_all<64, SumOp>(t);
+        if (lane == 0) { red_s[buf][w] = s; red_t[buf][w] = t; }
+        __syncthreads();
+        s = (red_s[buf][0] + red_s[buf][1]) + (red_s[buf][2] + red_s[buf][3]);
+        t = (red_t[buf][0] + red_t[buf][1]) + (red_t[buf][2] + red_t[buf][3]);
+        const float ls = log_sum(s);
+        const float inv = __builtin_amdgcn_rcpf(s);
+        const float h = ls - t * inv;
+        if (!BWD) {
+            if (threadIdx.x == 0) {
+                logp_out[row] = (a_ok ? clamp_logit(xa) : 0.f) - (m + ls);
+                if (ent_out) ent_out[row] = h;
+            }
+        } else {
+            // grad_i = k1 (1[i==a] - p_i) - k2 p_i (log p_i + H),  log p_i = d_i - ls
+            float* __restrict__ out = grad + row * (long)N;
+            const int ai = a_ok ? (int)a : -1;
+            const float hl = h - ls;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int c = (e * 256 + (int)threadIdx.x) * 4;
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = v[e * 4 + k];
+                    const float pr = __expf(d) * inv;
+                    const float onehot = (c + k == ai) ? 1.f : 0.f;
+                    o[k] = k1 * (onehot - pr) - k2 * pr * (d + hl);
+                }
+                if (c < N) {
+                    vfloat4 q; q.x = o[0]; q.y = o[1]; q.z = o[2]; q.w = o[3];
+                    __builtin_nontemporal_store(q, reinterpret_cast<vfloat4*>(out + c));
+                }
+            }
+        }
+    }
+}
+
+// ---- long rows that cannot take 16-byte loads (N % 4 != 0 or unaligned, up to 16384): one workgroup per row, the row is read from HBM ONCE into
 // LDS with coalesced loads and the three passes (max, sum-exp, entropy / gradient) run out of LDS.
 template <bool BWD>
 __global__ __launch_bounds__(256) void categorical_ldsrow_kernel(const float* __restrict__ logits,
@@ -651,7 +752,15 @@ int categorical_forward(const float* logits, const int64_t* action, float* logp,
         return e == hipSuccess ? HPC_RLL_OK : (int)e;
     }
     const RowCfg cfg = row_cfg(N, al16(logits));
-    if (cfg.e > 8 && N <= 16384) {
+    if (cfg.e > 8 && cfg.vec == 4 && N <= 16384) {
+        const dim3 grid(grid_for(rows, 1));
+#define HPC_RLL_BLOCKROW(E_)                                                                                          \
+        hipLaunchKernelGGL((categorical_blockrow_kernel<E_, false>), grid, dim3(256), 0, st, logits, action, logp, ent,   \
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,   \
+                           (float*)nullptr, rows, N)
+        if (N <= 4096) HPC_RLL_BLOCKROW(4); else if (N <= 8192) HPC_RLL_BLOCKROW(8); else HPC_RLL_BLOCKROW(16);
+#undef HPC_RLL_BLOCKROW
+    } else if (cfg.e > 8 && N <= 16384) {
         hipLaunchKernelGGL(categorical_ldsrow_kernel<false>, dim3(grid_for(rows, 1)), dim3(256), (size_t)N * sizeof(float),
                            st, logits, action, logp, ent, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (float*)nullptr, rows, N);
@@ -675,7 +784,14 @@ int categorical_backward(const float* logits, const int64_t* action, const float
         return e == hipSuccess ? HPC_RLL_OK : (int)e;
     }
     const RowCfg cfg = row_cfg(N, al16(logits) && al16(grad));
-    if (cfg.e > 8 && N <= 16384) {
+    if (cfg.e > 8 && cfg.vec == 4 && N <= 16384) {
+        const dim3 grid(grid_for(rows, 1));
+#define HPC_RLL_BLOCKROW(E_)                                                                                          \
+        hipLaunchKernelGGL((categorical_blockrow_kernel<E_, true>), grid, dim3(256), 0, st, logits, action,              \
+                           (float*)nullptr, (float*)nullptr, c1, g1, c2, g2, grad, rows, N)
+        if (N <= 4096) HPC_RLL_BLOCKROW(4); else if (N <= 8192) HPC_RLL_BLOCKROW(8); else HPC_RLL_BLOCKROW(16);
+#undef HPC_RLL_BLOCKROW
+    } else if (cfg.e > 8 && N <= 16384) {
         hipLaunchKernelGGL(categorical_ldsrow_kernel<true>, dim3(grid_for(rows, 1)), dim3(256), (size_t)N * sizeof(float),
                            st, logits, action, (float*)nullptr, (float*)nullptr, c1, g1, c2, g2, grad, rows, N);
     } else if (cfg.e > 8 || !launch_bwd(cfg, st, logits, action, c1, g1, c2, g2, grad, rows, N)) {

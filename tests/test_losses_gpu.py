@@ -87,7 +87,8 @@ def test_vtrace_golden(golden):
 
 
 @pytest.mark.parametrize("T,B,N", [(128, 128, 128), (64, 300, 6), (16, 70, 1000), (9, 33, 2500), (256, 1024, 18), (3, 5, 1),
-                                   (5, 7, 9), (40, 100, 4), (3, 11, 5001), (2, 3, 20000), (31, 50, 30), (7, 9, 2)])
+                                   (5, 7, 9), (40, 100, 4), (3, 11, 5001), (2, 3, 20000), (31, 50, 30), (7, 9, 2),
+                                   (3, 7, 8192), (2, 5, 16384), (2, 9, 4100), (3, 4, 12000), (5, 3, 2052)])
 def test_vtrace_oracle(T, B, N):
     from hpc_rll.rl_utils.vtrace import VTrace
     rng = np.random.default_rng(T * 7 + N)
@@ -114,7 +115,8 @@ def _mask(rng, logits, action, frac=0.3):
     return out
 
 
-@pytest.mark.parametrize("T,B,N", [(16, 64, 128), (8, 40, 18), (5, 33, 1000), (4, 9, 6), (3, 7, 5001)])
+@pytest.mark.parametrize("T,B,N", [(16, 64, 128), (8, 40, 18), (5, 33, 1000), (4, 9, 6), (3, 7, 5001), (3, 5, 4096),
+                                   (2, 3, 10000)])
 def test_masked_actions_vtrace_ppo(T, B, N):
     """Masked actions arrive as logits = -inf: probability 0, no entropy contribution, zero gradient -- what
     torch.distributions.Categorical (hpc_rll.origin's softmax/entropy, origin/vtrace.py:76-79, origin/ppo.py:57-61)
