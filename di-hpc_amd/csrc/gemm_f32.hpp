@@ -66,6 +66,39 @@ struct TileStage {
     static constexpr int NS = X * BK / 256;              // scalars per thread (generic)
     gf4 v[MODE == kGeneric ? 1 : (MODE == kContigK ? NB * 4 : NV)];
     float s[MODE == kGeneric ? NS : 1];
+    const float* p;   // this thread's first element of the NEXT k-tile to prefetch (fast path)
+
+    // Fast path for tiles that lie entirely inside the operand (uniform per workgroup and k-tile): no per-lane
+    // bounds test, so no divergent branch around a load.  With the guarded form the compiler had to assume 0..NV
+    // loads in flight at every merge point and protected the zero-fill of the next operand's registers with
+    // s_waitcnt vmcnt(0) -- the A prefetch was waited for BEFORE the MFMAs of the current k-tile, i.e. the register
+    // prefetch hid nothing of the A latency.  Addresses are one per-thread pointer plus uniform (scalar) offsets,
+    // advanced once per k-tile (the guarded form recomputed 64-bit products per load).
+    __device__ __forceinline__ void init(const float* __restrict__ base, long sx, long sk, int x0, int k0) {
+        const int tid = threadIdx.x;
+        if (MODE == kContigMN) p = base + (long)(k0 + tid / (X / 4)) * sk + x0 + (tid % (X / 4)) * 4;
+        else if (MODE == kContigK) p = base + (long)(x0 + 4 * (tid / KQ)) * sx + k0 + (tid % KQ) * 4;
+        else p = base;
+    }
+    __device__ __forceinline__ void advance(long sk) { p += (MODE == kContigMN) ? BK * sk : BK; }
+    __device__ __forceinline__ void load_fast(long sx, long sk) {
+        static_assert(MODE == kGeneric || 256 % (X / 4) == 0, "k-rows per pass must be whole");
+        if (MODE == kContigMN) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (threadIdx.x + i * 256 >= X * BK / 4) break;
+                v[i] = *reinterpret_cast<const gf4*>(p + (long)(i * (256 / (X / 4))) * sk);
+            }
+        } else if (MODE == kContigK) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (threadIdx.x + i * 256 >= NBLK) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[i * 4 + r] = *reinterpret_cast<const gf4*>(p + (long)(i * 4 * (256 / KQ) + r) * sx);
+            }
+        }
+    }
 
     __device__ __forceinline__ void load(const float* __restrict__ base, long sx, long sk, int x0, int k0, int XD,
                                          int KD) {
@@ -203,12 +236,8 @@ __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_ke
     __syncthreads();
     const int am = wm * 32 * WM + (lane & 31);
     const int bn = wn * 32 * WN + (lane & 31);
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ktiles) {
-            sa.load(g.A, g.a_sm, g.a_sk, m0, kbeg + (kt + 1) * BK, g.M, KE);
-            sb.load(g.B, g.b_sn, g.b_sk, n0, kbeg + (kt + 1) * BK, g.N, KE);
-        }
+    // One k-tile of MFMAs out of LDS buffer `buf`.
+    auto mfma_tile = [&](int buf) {
         const float* __restrict__ as = As + buf * BK * BM;
         const float* __restrict__ bs = Bs + buf * BK * BN;
 #pragma unroll
@@ -225,11 +254,43 @@ __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_ke
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < ktiles) {
-            sa.store(As + (buf ^ 1) * BK * BM);
-            sb.store(Bs + (buf ^ 1) * BK * BN);
+    };
+    // Workgroups whose tiles lie entirely inside A, B and their K slice (uniform; all of them in the LSTM's large
+    // products) take a loop with branch-free prefetches, see TileStage::load_fast; the rest keep the guarded loop.
+    const bool interior = AMODE != kGeneric && BMODE != kGeneric && m0 + BM <= g.M && n0 + BN <= g.N &&
+                          (KE - kbeg) % BK == 0;
+    if (interior) {
+        sa.init(g.A, g.a_sm, g.a_sk, m0, kbeg + BK);
+        sb.init(g.B, g.b_sn, g.b_sk, n0, kbeg + BK);
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < ktiles) {
+                sa.load_fast(g.a_sm, g.a_sk);
+                sb.load_fast(g.b_sn, g.b_sk);
+                sa.advance(g.a_sk);
+                sb.advance(g.b_sk);
+            }
+            mfma_tile(buf);
+            if (kt + 1 < ktiles) {
+                sa.store(As + (buf ^ 1) * BK * BM);
+                sb.store(Bs + (buf ^ 1) * BK * BN);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < ktiles) {
+                sa.load(g.A, g.a_sm, g.a_sk, m0, kbeg + (kt + 1) * BK, g.M, KE);
+                sb.load(g.B, g.b_sn, g.b_sk, n0, kbeg + (kt + 1) * BK, g.N, KE);
+            }
+            mfma_tile(buf);
+            if (kt + 1 < ktiles) {
+                sa.store(As + (buf ^ 1) * BK * BM);
+                sb.store(Bs + (buf ^ 1) * BK * BN);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
