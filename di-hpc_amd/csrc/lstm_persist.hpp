@@ -57,21 +57,36 @@ __device__ __forceinline__ void xchg_put_all(u64* base, size_t rep_words, int nr
 
 // wait until every word idx[i] with bit i of `valid` set carries `tag`; the loads of a poll round are issued back to
 // back (one memory round trip per round, whatever NL is)
-template <int NL>
+// PAR = false: a load under `valid ? load : const` compiles to a branch per word with s_waitcnt vmcnt(0) inside, i.e.
+// the NL words of a poll are fetched one round trip after the other.  For the few-word exchanges of row sums that
+// trickle is what one wants (alternating-process A/B on one box: issuing them together made the step 15 % SLOWER --
+// every waiting thread then hammers the memory path the producers' stores need).  PAR = true issues all NL loads
+// unconditionally (an invalid slot reads word 0, result ignored) before the first check: one round trip per poll; used
+// by the forward h gather (-2.5 % at B*H = 512, neutral at 4096); the backward dgate gather measured +6 % with it.
+template <int NL, bool PAR = false>
 __device__ __forceinline__ void xchg_get(const u64* base, const int (&idx)[NL], unsigned valid, uint32_t tag,
                                          float (&out)[NL], u64* poll_count = nullptr) {
     static_assert(NL <= 32, "validity mask is 32 bits");
     long spins = 0;
     while (true) {
         u64 w[NL];
-#pragma unroll
-        for (int i = 0; i < NL; ++i)
-            w[i] = ((valid >> i) & 1u)
-                       ? __hip_atomic_load(base + idx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : ((u64)tag << 32);
         bool ok = true;
+        if (PAR) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) ok = ok && ((uint32_t)(w[i] >> 32) == tag);
+            for (int i = 0; i < NL; ++i)
+                w[i] = __hip_atomic_load(base + (((valid >> i) & 1u) ? idx[i] : 0), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) ok = ok && (!((valid >> i) & 1u) || (uint32_t)(w[i] >> 32) == tag);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                w[i] = ((valid >> i) & 1u)
+                           ? __hip_atomic_load(base + idx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : ((u64)tag << 32);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) ok = ok && ((uint32_t)(w[i] >> 32) == tag);
+        }
         if (ok) {
 #pragma unroll
             for (int i = 0; i < NL; ++i) out[i] = __uint_as_float((uint32_t)w[i]);
@@ -84,7 +99,7 @@ __device__ __forceinline__ void xchg_get(const u64* base, const int (&idx)[NL], 
 }
 
 // all 256 threads: words [0, n) of `src` -> dst[0, n) (LDS), CH words per thread and poll round
-template <int CH>
+template <int CH, bool PAR = false>
 __device__ __forceinline__ void xchg_gather(const u64* src, int n, uint32_t tag, float* dst,
                                             u64* poll_count = nullptr) {
     for (int e0 = threadIdx.x; e0 < n; e0 += 256 * CH) {
@@ -96,7 +111,7 @@ __device__ __forceinline__ void xchg_gather(const u64* src, int n, uint32_t tag,
             if (idx[i] < n) valid |= 1u << i;
         }
         float v[CH];
-        xchg_get<CH>(src, idx, valid, tag, v, poll_count);
+        xchg_get<CH, PAR>(src, idx, valid, tag, v, poll_count);
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if ((valid >> i) & 1u) dst[idx[i]] = v[i];
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(PersistFwd a) {
         const uint32_t tag = a.tag_base + (uint32_t)s + 1u;
         const int par = (int)(tag & 1u);
         if (s > 0) {   // h_{s-1}: published by its owners with tag-1
-            xchg_gather<8>(a.hx + (size_t)((tag - 1u) & 1u) * a.hx_par + myrep * a.hx_rep, B * H, tag - 1u, hs,
+            xchg_gather<8, true>(a.hx + (size_t)((tag - 1u) & 1u) * a.hx_par + myrep * a.hx_rep, B * H, tag - 1u, hs,
                            a.prof ? a.prof + 6 : nullptr);
             __syncthreads();
             flush_saved(s - 1);

@@ -33,7 +33,53 @@ struct WaveFwd {
     float drop_scale;
 };
 
-template <int NB, int JW>
+// Poll words e0 + 256*i (i < CH, those with their `valid` bit set) of the concatenation src1[0,n1) ++ src2[0,n2) until
+// every one carries its tag (tag-1 for src1, tag for src2).
+// PAR = false: each load sits under `if (valid)`, which compiles to a branch per word with s_waitcnt vmcnt(0) inside: the
+// words of a poll are fetched one round trip after the other.  PAR = true: all CH loads are issued unconditionally (an
+// out-of-range slot reads word 0 of a valid array, result ignored) before the first check: one round trip per poll.
+// Measured in alternating processes on one box (tests/tools/lstm_lib_ab.sh): the backward gather of 2*B*4H words gains
+// 6-26 % per launch from PAR (S=64,B=3,H=384,L=3: 1.63 -> 1.24 ms), the forward gather of 2*B*H words gains 6 % at
+// 9 words per thread and LOSES 3.5 % at 2 (every waiting thread then hammers the path the producers' stores need), and
+// the few-word row-sum exchanges lose 15 % (they stay on xchg_get<.., false>).
+template <int CH, bool PAR, class MaskT>
+__device__ __forceinline__ void wave_poll(const u64* src1, int n1, const u64* src2, int n2, int e0, MaskT valid,
+                                          uint32_t tag, u64 (&w)[CH]) {
+    long spins = 0;
+    const u64* const safe = n1 > 0 ? src1 : src2;
+    while (true) {
+        bool ok = true;
+        if (PAR) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int e = e0 + 256 * i;
+                const u64* pp = ((valid >> i) & 1) ? (e < n1 ? src1 + e : src2 + (e - n1)) : safe;
+                w[i] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const bool first = e0 + 256 * i < n1;
+                ok = ok && (!((valid >> i) & 1) || (uint32_t)(w[i] >> 32) == (first ? tag - 1u : tag));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int e = e0 + 256 * i;
+                if ((valid >> i) & 1) {
+                    const bool first = e < n1;
+                    w[i] = __hip_atomic_load(first ? src1 + e : src2 + (e - n1), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && ((uint32_t)(w[i] >> 32) == (first ? tag - 1u : tag));
+                }
+            }
+        }
+        if (ok) return;
+        if (++spins > kSpinLimit) __builtin_trap();
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+template <int NB, int JW, bool PARG>   // PARG: the h gather fetches a poll's words together (see wave_poll)
 __global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(WaveFwd a) {
     extern __shared__ float smem[];
     constexpr int CW = 4 * JW;
@@ -106,28 +152,12 @@ __global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(WaveFwd a) {
             const u64* src1 = hx_l + (size_t)(s > 0 ? s - 1 : 0) * BH;
             const u64* src2 = xin ? hx_lo + (size_t)s * BH : nullptr;
             for (int e0 = tid; e0 < n1 + n2; e0 += 256 * 8) {
-                long spins = 0;
                 u64 w[8];
                 unsigned valid = 0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     if (e0 + 256 * i < n1 + n2) valid |= 1u << i;
-                while (true) {
-                    bool ok = true;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int e = e0 + 256 * i;
-                        if ((valid >> i) & 1u) {
-                            const bool first = e < n1;
-                            w[i] = __hip_atomic_load(first ? src1 + e : src2 + (e - n1), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                            ok = ok && ((uint32_t)(w[i] >> 32) == (first ? tag - 1u : tag));
-                        }
-                    }
-                    if (ok) break;
-                    if (++spins > kSpinLimit) __builtin_trap();
-                    __builtin_amdgcn_s_sleep(8);
-                }
+                wave_poll<8, PARG>(src1, n1, src2, n2, e0, valid, tag, w);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int e = e0 + 256 * i;
@@ -286,15 +316,22 @@ __global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(WaveFwd a) {
 
 struct WaveCfg { int nb, jw, nwg; size_t lds; size_t hx_words, sx_words; };
 
-template <int NB, int JW>
-inline int launch_wave_fwd_t(const WaveCfg& c, const WaveFwd& a, hipStream_t st) {
-    auto k = lstm_wave_fwd_kernel<NB, JW>;
+template <int NB, int JW, bool PARG>
+inline int launch_wave_fwd_k(const WaveCfg& c, const WaveFwd& a, hipStream_t st) {
+    auto k = lstm_wave_fwd_kernel<NB, JW, PARG>;
     if (c.lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(k, dim3(c.nwg, a.L), dim3(256), c.lds, st, a);
     return 0;
+}
+// Bulk gathers (2*B*H >= 1024 words, i.e. >= 4 per thread) fetch a poll's words together, small ones one after the
+// other.  Only the JW >= 4 kernels (H > 170 at L = 3) get the second instantiation: below that the gather is small.
+template <int NB, int JW>
+inline int launch_wave_fwd_t(const WaveCfg& c, const WaveFwd& a, hipStream_t st) {
+    if (JW >= 4 && 2 * a.B * a.H >= 1024) return launch_wave_fwd_k<NB, JW, (JW >= 4)>(c, a, st);
+    return launch_wave_fwd_k<NB, JW, false>(c, a, st);
 }
 inline int launch_wave_fwd(const WaveCfg& c, const WaveFwd& a, hipStream_t st) {
 #define HPC_RLL_WAVE_RUN(JW_)                                               \
@@ -451,28 +488,12 @@ __global__ __launch_bounds__(256) void lstm_wave_bwd_kernel(WaveBwd a) {
             const u64* src2 = n2 ? xxw_up + (size_t)s * BG : nullptr;
             constexpr int CHB = 16;   // words per thread and poll round (40 = one round at the test shape: +-2 %)
             for (int e0 = tid; e0 < n1 + n2; e0 += 256 * CHB) {
-                long spins = 0;
                 u64 w[CHB];
                 unsigned long long valid = 0;
 #pragma unroll
                 for (int i = 0; i < CHB; ++i)
                     if (e0 + 256 * i < n1 + n2) valid |= 1ull << i;
-                while (true) {
-                    bool ok = true;
-#pragma unroll
-                    for (int i = 0; i < CHB; ++i) {
-                        const int e = e0 + 256 * i;
-                        if ((valid >> i) & 1ull) {
-                            const bool first = e < n1;
-                            w[i] = __hip_atomic_load(first ? src1 + e : src2 + (e - n1), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                            ok = ok && ((uint32_t)(w[i] >> 32) == (first ? tag - 1u : tag));
-                        }
-                    }
-                    if (ok) break;
-                    if (++spins > kSpinLimit) __builtin_trap();
-                    __builtin_amdgcn_s_sleep(8);
-                }
+                wave_poll<CHB, true>(src1, n1, src2, n2, e0, valid, tag, w);
 #pragma unroll
                 for (int i = 0; i < CHB; ++i) {
                     const int e = e0 + 256 * i;
