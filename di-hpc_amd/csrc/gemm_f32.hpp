@@ -180,7 +180,11 @@ template <int BM, int BN, int BK> struct GemmOcc {
     static constexpr int value = lds <= 36 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : 2;
 };
 
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
+// INTERIOR: every tile of the launch lies entirely inside A, B and its K slice (M % BM == N % BN == K % BK == 0, no
+// generic operand) -- decided on the host, so that each instantiation holds ONE main loop: the branch-free prefetch
+// loop (see TileStage::load_fast) or the guarded one.  (Both loops in one kernel behind a uniform branch cost 20-40
+// registers and spilled in the NT variants.)
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool INTERIOR>
 __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int WAVES_M = BM / (32 * WM);
     static_assert(WAVES_M * (BN / (32 * WN)) == 4, "4 waves per workgroup");
@@ -255,11 +259,7 @@ __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_ke
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    // Workgroups whose tiles lie entirely inside A, B and their K slice (uniform; all of them in the LSTM's large
-    // products) take a loop with branch-free prefetches, see TileStage::load_fast; the rest keep the guarded loop.
-    const bool interior = AMODE != kGeneric && BMODE != kGeneric && m0 + BM <= g.M && n0 + BN <= g.N &&
-                          (KE - kbeg) % BK == 0;
-    if (interior) {
+    if constexpr (INTERIOR) {
         sa.init(g.A, g.a_sm, g.a_sk, m0, kbeg + BK);
         sb.init(g.B, g.b_sn, g.b_sk, n0, kbeg + BK);
         for (int kt = 0; kt < ktiles; ++kt) {
@@ -325,16 +325,20 @@ inline void launch_gemm_tile(const GemmArgs& g_in, int am, int bm, hipStream_t s
     extern int g_gemm_xcd;   // tuning knob (hpc_rll_tune_set key 10)
     GemmArgs g = g_in;
     g.xcd_swizzle = (g_gemm_xcd && ((long)grid.x * grid.y) % 8 == 0 && grid.y >= 8) ? 1 : 0;
+    const bool interior = g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0;
 #define HPC_RLL_GEMM_CASE(AM, BMD)                                                                          \
     if (am == AM && bm == BMD) {                                                                            \
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, AM, BMD>), grid, dim3(256), 0, st, g);          \
+        if (interior)                                                                                       \
+            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, AM, BMD, true>), grid, dim3(256), 0, st, g); \
+        else                                                                                                \
+            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, AM, BMD, false>), grid, dim3(256), 0, st, g); \
         return;                                                                                             \
     }
     HPC_RLL_GEMM_CASE(kContigK, kContigMN)    // NN
     HPC_RLL_GEMM_CASE(kContigK, kContigK)     // NT
     HPC_RLL_GEMM_CASE(kContigMN, kContigMN)   // TN
 #undef HPC_RLL_GEMM_CASE
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, kGeneric, kGeneric>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, kGeneric, kGeneric, false>), grid, dim3(256), 0, st, g);
 }
 
 // Tile shape launch_gemm picks for an (M, N) problem.
