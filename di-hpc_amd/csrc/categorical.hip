@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void categorical_small_kernel(const float* __r
                                                                 const float* __restrict__ c2,
                                                                 const float* __restrict__ g2,
                                                                 float* __restrict__ grad, long rows, int N) {
-    __shared__ __attribute__((aligned(16))) float tile[kSmallRows * kSmallMaxN];
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // kSmallRows * N floats (6 KB at N = 6: 8 workgroups per CU)
     const float u1 = (BWD && g1) ? g1[0] : 1.f;
     const float u2 = (BWD && c2 != nullptr) ? (g2 ? g2[0] : 1.f) : 0.f;
     for (long row0 = (long)blockIdx.x * kSmallRows; row0 < rows; row0 += (long)gridDim.x * kSmallRows) {
@@ -411,14 +411,17 @@ __global__ __launch_bounds__(256) void categorical_small_kernel(const float* __r
             const long a = action[row];
             float m = kNegInf;
             for (int i = 0; i < N; ++i) m = fmaxf(m, clamp_logit(x[i]));
-            float sum = 0.f;
-            for (int i = 0; i < N; ++i) sum += __expf(clamp_logit(x[i]) - m);
-            const float lse = m + __logf(sum);
-            float h = 0.f;
+            // partition sum and entropy from ONE exp per element: H = log s - (sum e_i d_i) / s, d_i = x_i - m
+            float sum = 0.f, t = 0.f;
             for (int i = 0; i < N; ++i) {
-                const float lp = clamp_logit(x[i]) - lse;
-                h -= __expf(lp) * lp;
+                const float d = clamp_logit(x[i]) - m;
+                const float e = __expf(d);
+                sum += e;
+                t = fmaf(e, d, t);
             }
+            const float ls = log_sum(sum);
+            const float lse = m + ls;
+            const float h = ls - t * __builtin_amdgcn_rcpf(sum);
             if (!BWD) {
                 logp_out[row] = ((a >= 0 && a < N) ? clamp_logit(x[a]) : 0.f) - lse;
                 if (ent_out) ent_out[row] = h;
@@ -745,7 +748,8 @@ int categorical_forward(const float* logits, const int64_t* action, float* logp,
     if (rows == 0) return HPC_RLL_OK;
     if (!logits || !action || !logp) return HPC_RLL_EINVAL;
     if ((N % 4) != 0 && N <= kSmallMaxN && al16(logits)) {
-        hipLaunchKernelGGL(categorical_small_kernel<false>, dim3(grid_for(rows, kSmallRows)), dim3(256), 0, st, logits,
+        hipLaunchKernelGGL(categorical_small_kernel<false>, dim3(grid_for(rows, kSmallRows)), dim3(256),
+                           (size_t)kSmallRows * N * sizeof(float), st, logits,
                            action, logp, ent, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (float*)nullptr, rows, N);
         const hipError_t e = hipGetLastError();
@@ -778,7 +782,8 @@ int categorical_backward(const float* logits, const int64_t* action, const float
     if (rows == 0) return HPC_RLL_OK;
     if (!logits || !action || !c1 || !grad) return HPC_RLL_EINVAL;
     if ((N % 4) != 0 && N <= kSmallMaxN && al16(logits) && al16(grad)) {
-        hipLaunchKernelGGL(categorical_small_kernel<true>, dim3(grid_for(rows, kSmallRows)), dim3(256), 0, st, logits,
+        hipLaunchKernelGGL(categorical_small_kernel<true>, dim3(grid_for(rows, kSmallRows)), dim3(256),
+                           (size_t)kSmallRows * N * sizeof(float), st, logits,
                            action, (float*)nullptr, (float*)nullptr, c1, g1, c2, g2, grad, rows, N);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? HPC_RLL_OK : (int)e;
