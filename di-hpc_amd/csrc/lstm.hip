@@ -734,7 +734,8 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
                                      int H, int L, float dropout_p, uint64_t seed, void* stream) {
     if (S <= 0 || B <= 0 || I <= 0 || H <= 0 || L <= 0 || L > 16) return HPC_RLL_EINVAL;
     if (H > 2048) return HPC_RLL_EUNSUPPORTED;
-    if (!x || !h0 || !c0 || !wx || !wh || !ln_gamma || !ws || !dx || !dh0 || !dc0 || !dwx || !dwh || !dbias ||
+    // dx may be NULL: the caller does not need the gradient of the layer-0 input (its S*B x I x 4H product is skipped)
+    if (!x || !h0 || !c0 || !wx || !wh || !ln_gamma || !ws || !dh0 || !dc0 || !dwx || !dwh || !dbias ||
         !dln_gamma || !dln_beta)
         return HPC_RLL_EINVAL;
     hipStream_t st = (hipStream_t)stream;

@@ -36,7 +36,8 @@ class HPCLSTMFunction(torch.autograd.Function):
         x, h0, c0, wx, wh, ln_gamma, ws = ctx.saved
         dropout, seed, bias_shape, beta_shape = ctx.cfg
         new = lambda ref: torch.empty_like(ref)  # noqa: E731
-        dx, dh0, dc0, dwx, dwh = new(x), new(h0), new(c0), new(wx), new(wh)
+        dx = new(x) if ctx.needs_input_grad[0] else None     # x without grad: the layer-0 input-gradient GEMM is skipped
+        dh0, dc0, dwx, dwh = new(h0), new(c0), new(wx), new(wh)
         dbias = torch.empty(bias_shape, dtype=torch.float32, device=x.device)
         dgamma = new(ln_gamma)
         dbeta = torch.empty(beta_shape, dtype=torch.float32, device=x.device)

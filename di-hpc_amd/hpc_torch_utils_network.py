@@ -53,8 +53,8 @@ def LstmForward(inputs, outputs, dropout: float, seed: int = 0) -> None:
 
 def LstmBackward(inputs, outputs, dropout: float, seed: int = 0) -> None:
     """inputs = [dy (S,B,H)|None, dhn (L,B,H)|None, dcn (L,B,H)|None, x, h0, c0, wx, wh, ln_gamma, ws];
-    outputs = [dx, dh0, dc0, dwx, dwh, dbias, d_ln_gamma, d_ln_beta].  Reference: lstm.cu:188-379 (which zeroes the
-    incoming dhn/dcn; here they are honoured)."""
+    outputs = [dx|None, dh0, dc0, dwx, dwh, dbias, d_ln_gamma, d_ln_beta].  Reference: lstm.cu:188-379 (which zeroes the
+    incoming dhn/dcn; here they are honoured).  dx = None skips the input-gradient product of layer 0 (x needs no grad)."""
     dy, dhn, dcn, x, h0, c0, wx, wh, gamma, ws = inputs
     dx, dh0, dc0, dwx, dwh, dbias, dgamma, dbeta = outputs
     dev = x.device
@@ -65,7 +65,8 @@ def LstmBackward(inputs, outputs, dropout: float, seed: int = 0) -> None:
         N.require(dhn, "dhn", shape=(L, B, H), device=dev)
     if dcn is not None:
         N.require(dcn, "dcn", shape=(L, B, H), device=dev)
-    N.require(dx, "dx", shape=(S, B, I), device=dev)
+    if dx is not None:
+        N.require(dx, "dx", shape=(S, B, I), device=dev)
     N.require(dh0, "dh0", shape=(L, B, H), device=dev)
     N.require(dc0, "dc0", shape=(L, B, H), device=dev)
     for t, ref, nm in ((dwx, wx, "dwx"), (dwh, wh, "dwh"), (dgamma, gamma, "d_ln_gamma"), (dbeta, gamma, "d_ln_beta")):
@@ -74,7 +75,7 @@ def LstmBackward(inputs, outputs, dropout: float, seed: int = 0) -> None:
             raise RuntimeError(f"{nm}: {t.numel()} elements, expected {ref.numel()}")
     N.require(dbias, "dbias", device=dev)
     N.call("hpc_rll_lstm_backward", dev, N.ptr(dy), N.ptr(dhn), N.ptr(dcn), x.data_ptr(), h0.data_ptr(), c0.data_ptr(),
-           wx.data_ptr(), wh.data_ptr(), gamma.data_ptr(), ws.data_ptr(), dx.data_ptr(), dh0.data_ptr(), dc0.data_ptr(),
+           wx.data_ptr(), wh.data_ptr(), gamma.data_ptr(), ws.data_ptr(), N.ptr(dx), dh0.data_ptr(), dc0.data_ptr(),
            dwx.data_ptr(), dwh.data_ptr(), dbias.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), S, B, I, H, L,
            float(dropout), int(seed))
 

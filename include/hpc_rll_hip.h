@@ -229,7 +229,8 @@ int hpc_rll_scatter_connection_backward(const float* grad_out, const int64_t* lo
  * must be kept (unmodified) from forward to backward.  All GEMMs are exact fp32 on the matrix cores.
  * dropout_p in [0,1): inter-layer dropout, mask = stateless hash of (seed, layer, element).
  * backward: dy (S,B,H), dhn, dcn (L,B,H) may each be NULL (= zero).  Unlike the reference, gradients
- * flowing in through hn / cn are honoured.
+ * flowing in through hn / cn are honoured.  dx may be NULL when the gradient of x is not needed: the
+ * S*B x I x 4H input-gradient product of layer 0 is then skipped.
  * ------------------------------------------------------------------------------------------ */
 int64_t hpc_rll_lstm_workspace_floats(int S, int B, int I, int H, int L, float dropout_p);
 int hpc_rll_lstm_forward(const float* x, const float* h0, const float* c0, const float* wx, const float* wh,

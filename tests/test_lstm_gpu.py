@@ -156,6 +156,28 @@ def test_lstm_reference_usage_pattern():
     assert torch.equal(out[-1], h[-1])
 
 
+@pytest.mark.parametrize("S,B,I,H,L", [(12, 3, 40, 48, 3), (10, 2, 24, 320, 2), (8, 20, 36, 64, 2)])   # wavefront / per-layer / step kernels
+def test_lstm_input_without_grad(S, B, I, H, L):
+    """x.requires_grad = False: the C ABI gets dx = NULL and skips the layer-0 input-gradient product; every other
+    gradient is bit-identical to the run that also produces dx."""
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(3)
+    m = LSTM(S, B, I, H, L).to(DEV)
+    x = torch.randn(S, B, I, device=DEV)
+    h0, c0 = torch.randn(L, B, H, device=DEV, requires_grad=True), torch.randn(L, B, H, device=DEV, requires_grad=True)
+    grads = []
+    for need in (True, False):
+        for p in list(m.parameters()) + [h0, c0]:
+            p.grad = None
+        xi = x.clone().requires_grad_(need)
+        y, (hn, cn) = m(xi, (h0, c0))
+        (y.sum() + (hn * cn).sum()).backward()
+        assert (xi.grad is not None) == need
+        grads.append([p.grad.clone() for p in list(m.parameters()) + [h0, c0]])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B", [16, 4])          # step-kernel path / persistent path
 def test_lstm_dropout(B):
     from hpc_rll.torch_utils.network.rnn import LSTM
