@@ -177,7 +177,8 @@ struct TileStage {
 // a 1024-tile product (the C4 recurrent GEMM) ran as 768 + a 256-workgroup tail at one workgroup per CU.
 template <int BM, int BN, int BK> struct GemmOcc {
     static constexpr int lds = 2 * BK * (BM + BN) * 4;
-    static constexpr int value = lds <= 36 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : 2;
+    // (256x128 tiles hold 128 accumulator registers per lane: two waves per SIMD)
+    static constexpr int value = BM * BN >= 256 * 128 ? 2 : lds <= 36 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : 2;
 };
 
 // INTERIOR: every tile of the launch lies entirely inside A, B and its K slice (M % BM == N % BN == K % BK == 0, no
@@ -408,6 +409,22 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     const GemmTile t = g.big ? gemm_tile_big(g.M, g.N, g.K) : gemm_tile_of(g.M, g.N);
     const int bk = g_gemm_bk ? g_gemm_bk
                              : (((am == kContigK && bm == kContigMN) || (g.big && t.bm == 128 && t.bn == 128)) ? 16 : 32);
+    extern int g_gemm_tile256;   // tuning knob (hpc_rll_tune_set key 16)
+    if (g_gemm_tile256 && t.bm == 128 && t.bn == 128 && bk == 16 && am != kGeneric && bm != kGeneric &&
+        g.M % 256 == 0 && g.N % 128 == 0 && g.K % 16 == 0 &&
+        (long)(g.M / 256) * (g.N / 128) * (g.splitk > 1 ? g.splitk : 1) >= 512) {
+        // 256x128x16, 128x64 per wave: 6 operand registers per 8 MFMAs instead of 4 per 4 (LDS read traffic -25 %)
+        const dim3 grid(g.N / 128, g.M / 256, g.splitk > 1 ? g.splitk : 1);
+        GemmArgs h = g;
+        h.xcd_swizzle = 0;
+#define HPC_RLL_GEMM256(AM, BMD)                                                                                   \
+        if (am == AM && bm == BMD) {                                                                               \
+            hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 16, 4, 2, AM, BMD, true>), grid, dim3(256), 0, st, h);      \
+            return;                                                                                                \
+        }
+        HPC_RLL_GEMM256(kContigK, kContigMN) HPC_RLL_GEMM256(kContigK, kContigK) HPC_RLL_GEMM256(kContigMN, kContigMN)
+#undef HPC_RLL_GEMM256
+    }
     if (t.bm == 32) launch_gemm_tile<32, 128, 32, 1, 1>(g, am, bm, st);
     else if (t.bm == 128 && t.bn == 128) {
         if (bk == 16) launch_gemm_tile<128, 128, 16, 2, 2>(g, am, bm, st);

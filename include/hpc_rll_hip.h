@@ -97,7 +97,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * key 11: LSTM backward products against transposed weight copies (large batches) on/off.  key 12: 128x128 tiles
  * for the dh product when it runs as NN.  key 13: workgroups the latency-regime split-K aims for (default 256).
  * key 14: k-tiles (of 32) a slice must keep in the throughput-regime split-K (default 8).  key 15: smallest
- * ceil(H/256) that takes the 16-byte forward cell kernel (default 3, 0 = never). */
+ * ceil(H/256) that takes the 16-byte forward cell kernel (default 3, 0 = never).  key 16: 1 = 256x128x16 GEMM tiles (128x64 per wave) for large interior
+ * products -- an experiment, measured neutral (C4 LSTM 79.1 / 164.4 vs 79.6 / 163.6 ms), default 0.
+ */
 int hpc_rll_tune_set(int key, int value);
 
 /* TD(lambda) -- replaces TdLambdaForward/Backward (rl_utils/entry.h:68-77, src/rl_utils/td_lambda.cu:8-52).

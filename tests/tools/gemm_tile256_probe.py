@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""256x128x16 GEMM tiles (tune key 16) vs the default 128x128x16: bit-compare on NN / NT / TN products, then the C4
+LSTM forward / backward with the knob off and on, interleaved in one process."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+import torch  # noqa: E402
+import hpc_rll._native as N  # noqa: E402
+import hpc_torch_utils_network as U  # noqa: E402
+from hpc_rll.torch_utils.network.rnn import LSTM  # noqa: E402
+dev = torch.device("cuda:0")
+
+
+def t(fn, k=3):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(k):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / k
+
+
+torch.manual_seed(0)
+for (M, Nn, K, kind) in [(4096, 4096, 1024, "nn"), (65536, 4096, 1024, "nn"), (8192, 1024, 4096, "nt"), (1024, 4096, 32768, "tn")]:
+    if kind == "nn":
+        a, b = torch.randn(M, K, device=dev), torch.randn(K, Nn, device=dev)
+    elif kind == "nt":
+        a, b = torch.randn(M, K, device=dev), torch.randn(Nn, K, device=dev).t()
+    else:
+        a, b = torch.randn(K, M, device=dev).t(), torch.randn(K, Nn, device=dev)
+    outs, times = [], []
+    for knob in (0, 1):
+        N.check(N.lib.hpc_rll_tune_set(16, knob))
+        c = U.gemm_f32(a, b)
+        outs.append(c.clone())
+        times.append(t(lambda: U.gemm_f32(a, b, out=c)))
+    same = torch.equal(outs[0], outs[1])
+    fl = 2.0 * M * Nn * K
+    print(f"{kind} M={M} N={Nn} K={K}: 128x128 {times[0]*1e3:.0f} us ({fl/times[0]/1e9:.1f} TF)  256x128 {times[1]*1e3:.0f} us "
+          f"({fl/times[1]/1e9:.1f} TF)  bit-identical={same}", flush=True)
+    del a, b, c, outs
+
+S, B, I, H, L = 128, 4096, 1024, 1024, 1
+m = LSTM(S, B, I, H, L).to(dev)
+x = torch.randn(S, B, I, device=dev, requires_grad=True)
+best = {}
+for rnd in range(2):
+    for knob in (0, 1):
+        N.check(N.lib.hpc_rll_tune_set(16, knob))
+        y, _ = m(x, None)
+        g = torch.ones_like(y)
+        y.backward(g, retain_graph=True)
+        tf = t(lambda: m(x, None), k=2)
+        y, _ = m(x, None)
+        tb = t(lambda: y.backward(g, retain_graph=True), k=2)
+        b0 = best.get(knob, (1e9, 1e9))
+        best[knob] = (min(b0[0], tf), min(b0[1], tb))
+        del y
+N.check(N.lib.hpc_rll_tune_set(16, 0))
+print("C4 LSTM: " + "  ".join(f"tile256={k}: fwd {v[0]:.1f} ms bwd {v[1]:.1f} ms" for k, v in best.items()))
