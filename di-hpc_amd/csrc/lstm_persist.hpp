@@ -55,8 +55,7 @@ __device__ __forceinline__ void xchg_put_all(u64* base, size_t rep_words, int nr
 }
 
 
-// wait until every word idx[i] with bit i of `valid` set carries `tag`; the loads of a poll round are issued back to
-// back (one memory round trip per round, whatever NL is)
+// wait until every word idx[i] with bit i of `valid` set carries `tag`.
 // PAR = false: a load under `valid ? load : const` compiles to a branch per word with s_waitcnt vmcnt(0) inside, i.e.
 // the NL words of a poll are fetched one round trip after the other.  For the few-word exchanges of row sums that
 // trickle is what one wants (alternating-process A/B on one box: issuing them together made the step 15 % SLOWER --
