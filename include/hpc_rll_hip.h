@@ -92,13 +92,14 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * (1..64).  key 1: k-depth of the fp32 GEMM tiles (16, 32, or 0 = chosen by operand layout).  key 2: threads per
  * block of the scatter output kernel (256/512/1024).  key 3: persistent small-batch LSTM path on (1) / off (0).
  * key 4: replicas of every exchange word of that path (1..32).  key 5: minimum hidden units per workgroup there.
- * key 6/7: split-K target and 128x128 tiles for the weight-gradient GEMMs.  key 8: layer-wavefront LSTM on/off.
+ * key 6, key 7: split-K target / 128x128 tiles for the weight-gradient GEMMs.  key 8: layer-wavefront LSTM on/off.
  * key 9: LDS KiB per workgroup of the scatter backward kernel (16..128).  key 10: XCD-aware GEMM tile order on/off.
  * key 11: LSTM backward products against transposed weight copies (large batches) on/off.  key 12: 128x128 tiles
  * for the dh product when it runs as NN.  key 13: workgroups the latency-regime split-K aims for (default 256).
  * key 14: k-tiles (of 32) a slice must keep in the throughput-regime split-K (default 8).  key 15: smallest
- * ceil(H/256) that takes the 16-byte forward cell kernel (default 3, 0 = never).  key 16: 1 = 256x128x16 GEMM tiles (128x64 per wave) for large interior
- * products -- an experiment, measured neutral (C4 LSTM 79.1 / 164.4 vs 79.6 / 163.6 ms), default 0.
+ * ceil(H/256) that takes the 16-byte forward cell kernel (default 3, 0 = never).  key 16: 1 = 256x128x16 GEMM
+ * tiles (128x64 per wave) for large interior products -- an experiment, measured neutral (C4 LSTM 79.1 / 164.4 vs
+ * 79.6 / 163.6 ms), default 0.
  */
 int hpc_rll_tune_set(int key, int value);
 

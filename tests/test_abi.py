@@ -81,6 +81,23 @@ def test_argument_errors_are_status_codes_not_crashes():
     assert L.hpc_rll_vtrace_workspace_floats(10, 20) >= 6 * 200
 
 
+def test_tuning_knobs_documented_and_guarded():
+    """hpc_rll_tune_set is host-only code: every key the header documents accepts its shipped default and rejects an
+    out-of-range value with a status (no GPU needed); an undocumented key is an argument error."""
+    import re
+    from hpc_rll import _native as N
+    hdr = open(N.HEADER_PATH).read()
+    doc = hdr[hdr.index("Tuning knobs"):hdr.index("int hpc_rll_tune_set")]
+    keys = sorted({int(k) for k in re.findall(r"key (\d+)", doc)})
+    assert keys == list(range(len(keys))) and len(keys) >= 17, keys
+    defaults = {0: 24, 1: 0, 2: 1024, 3: 1, 4: 4, 5: 0, 6: 768, 7: 1, 8: 1, 9: 64, 10: 1, 11: 1, 12: 1, 13: 256, 14: 8,
+                15: 3, 16: 0}
+    for k in keys:
+        assert N.lib.hpc_rll_tune_set(k, defaults[k]) == 0, k
+        assert N.lib.hpc_rll_tune_set(k, -7) != 0, k
+    assert N.lib.hpc_rll_tune_set(len(keys), 0) != 0
+
+
 def test_c_program_links_and_runs(tmp_path):
     """The boundary is a plain C ABI: a C program (no Python, no torch) compiles against include/hpc_rll_hip.h, links
     the shared library and calls the entry points that need no GPU."""
