@@ -3,7 +3,7 @@
 
 #include "hpc_rll_hip.h"
 
-extern "C" int hpc_rll_abi_version(void) { return 1; }
+extern "C" int hpc_rll_abi_version(void) { return 2; }
 
 extern "C" const char* hpc_rll_status_string(int status) {
     switch (status) {
@@ -16,3 +16,12 @@ extern "C" const char* hpc_rll_status_string(int status) {
     if (status > 0) return hipGetErrorString((hipError_t)status);
     return "hpc_rll: unknown status";
 }
+
+extern "C" int hpc_rll_stream_is_capturing(void* stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const hipError_t e = hipStreamIsCapturing((hipStream_t)stream, &st);
+    if (e != hipSuccess) return -(int)e - 1000;
+    return st == hipStreamCaptureStatusActive ? 1 : 0;
+}
+
+extern "C" int hpc_rll_stream_synchronize(void* stream) { return (int)hipStreamSynchronize((hipStream_t)stream); }

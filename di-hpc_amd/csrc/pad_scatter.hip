@@ -130,6 +130,89 @@ __global__ __launch_bounds__(256) void unpad_kernel(const float* __restrict__ pa
     }
 }
 
+// ------------------------------------------------------------------------------------------------ packed table
+// lengths (n,) int64 -> table rows {base + stride * exclusive_sum(lengths)[i], 1, 1, lengths[i]}.  Three tiny launches:
+// per-chunk sums (kScanChunk elements per workgroup), one workgroup scanning the chunk sums, per-chunk scan + write.
+constexpr int kScanChunk = 2048;   // 256 threads x 8 elements
+
+__device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// inclusive scan over the 256 threads of a workgroup; returns the thread's inclusive prefix, *total = workgroup sum
+__device__ __forceinline__ int64_t block_incl_scan_i64(int64_t x, int64_t* lds /* 4 */, int64_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t incl = wave_incl_scan_i64(x, lane);
+    if (lane == 63) lds[w] = incl;
+    __syncthreads();
+    int64_t off = 0;
+    for (int i = 0; i < w; ++i) off += lds[i];
+    *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return incl + off;
+}
+
+__global__ __launch_bounds__(256) void packed_chunk_sums_kernel(const int64_t* __restrict__ lengths, long n,
+                                                                int64_t* __restrict__ sums) {
+    __shared__ int64_t lds[4];
+    const long base = (long)blockIdx.x * kScanChunk;
+    int64_t s = 0;
+    for (int k = 0; k < 8; ++k) {
+        const long i = base + k * 256 + threadIdx.x;
+        if (i < n) s += lengths[i];
+    }
+    int64_t total;
+    block_incl_scan_i64(s, lds, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// exclusive scan of the chunk sums in place (one workgroup, carried over rounds of 256)
+__global__ __launch_bounds__(256) void packed_scan_sums_kernel(int64_t* __restrict__ sums, long nchunks) {
+    __shared__ int64_t lds[4];
+    int64_t carry = 0;
+    for (long r = 0; r < nchunks; r += 256) {
+        const long i = r + threadIdx.x;
+        const int64_t v = i < nchunks ? sums[i] : 0;
+        int64_t total;
+        const int64_t incl = block_incl_scan_i64(v, lds, &total);
+        if (i < nchunks) sums[i] = carry + incl - v;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(256) void packed_table_kernel(const int64_t* __restrict__ lengths, long n,
+                                                           const int64_t* __restrict__ sums, int64_t base,
+                                                           int64_t stride, int64_t* __restrict__ table) {
+    __shared__ int64_t lds[4];
+    // thread t owns 8 CONSECUTIVE elements so that its serial prefix is cheap
+    const long first = (long)blockIdx.x * kScanChunk + (long)threadIdx.x * 8;
+    int64_t len[8];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        len[k] = first + k < n ? lengths[first + k] : 0;
+        s += len[k];
+    }
+    int64_t total;
+    int64_t off = sums[blockIdx.x] + block_incl_scan_i64(s, lds, &total) - s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (first + k < n) {
+            int64_t* row = table + (first + k) * 4;
+            row[0] = base + stride * off;
+            row[1] = 1;
+            row[2] = 1;
+            row[3] = len[k];
+        }
+        off += len[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ scatter
 // idx layout per b (int32): [head HW | last HW | next M]
 __global__ __launch_bounds__(256) void scatter_index_kernel(const int64_t* __restrict__ location,
@@ -340,6 +423,25 @@ extern "C" int hpc_rll_unpad_forward(const float* padded, const int64_t* table, 
     if (blocks > 256L * 16) blocks = 256L * 16;
     hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, padded, table, flat,
                        (long)n, (long)total, (unsigned)m0, (unsigned)m1, (unsigned)m2);
+    return last_error();
+}
+
+extern "C" int64_t hpc_rll_packed_table_scratch_int64(int64_t n) {
+    return n <= 0 ? 1 : (n + kScanChunk - 1) / kScanChunk;
+}
+
+extern "C" int hpc_rll_packed_table(const int64_t* lengths, int64_t n, int64_t base, int64_t stride, int64_t* table,
+                                    int64_t* scratch, void* stream) {
+    if (n < 0) return HPC_RLL_EINVAL;
+    if (n == 0) return HPC_RLL_OK;
+    if (!lengths || !table || !scratch) return HPC_RLL_EINVAL;
+    const long nchunks = (long)((n + kScanChunk - 1) / kScanChunk);
+    if (nchunks > 0x7fffffffL) return HPC_RLL_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(packed_chunk_sums_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, lengths, (long)n, scratch);
+    hipLaunchKernelGGL(packed_scan_sums_kernel, dim3(1), dim3(256), 0, st, scratch, nchunks);
+    hipLaunchKernelGGL(packed_table_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, lengths, (long)n, scratch, base,
+                       stride, table);
     return last_error();
 }
 

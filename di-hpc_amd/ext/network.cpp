@@ -1,0 +1,336 @@
+// network.cpp -- the compiled `hpc_torch_utils_network` extension module
+// (reference: src/torch_utils/network/entry.cpp:8-13, include/hpc/rll/cuda/torch_utils/network/entry.h:11-29).
+//
+// L2 functions LstmForward/Backward, ScatterConnectionForward/Backward with the reference's names and list convention
+// (native short lists AND the reference's positional lists, told apart by their lengths), plus the fused autograd ops
+// `lstm` and `scatter_connection` that hpc_rll.torch_utils.network.* call.  Host-only C++ over the C ABI.
+#include "common.hpp"
+
+#include <atomic>
+
+namespace hpc_rll_ext {
+namespace {
+
+// ========================================================================================================== LSTM
+struct LstmDims { int64_t S, B, I, H, L; at::Device dev; };
+
+LstmDims lstm_dims(const Tensor& x, const Tensor& h0, const Tensor& wx, const Tensor& wh) {
+    req(x, "x");
+    TORCH_CHECK(x.dim() == 3, "x: expected (S,B,I), got ", x.sizes());
+    const at::Device dev = x.device();
+    req(h0, "h0", dev);
+    TORCH_CHECK(h0.dim() == 3 && h0.size(1) == x.size(1), "h0: expected (L,", x.size(1), ",H), got ", h0.sizes());
+    const int64_t S = x.size(0), B = x.size(1), I = x.size(2), L = h0.size(0), H = h0.size(2), G = 4 * H;
+    req(wx, "wx", dev);
+    req(wh, "wh", dev);
+    TORCH_CHECK(wx.numel() == (I + (L - 1) * H) * G && wh.numel() == L * H * G, "wx/wh: ", wx.numel(), "/", wh.numel(),
+                " elements do not match I=", I, " H=", H, " L=", L);
+    return {S, B, I, H, L, dev};
+}
+
+int64_t lstm_ws_floats(const LstmDims& d, double dropout) {
+    const int64_t n = hpc_rll_lstm_workspace_floats(to_int(d.S, "S"), to_int(d.B, "B"), to_int(d.I, "I"), to_int(d.H, "H"),
+                                                    to_int(d.L, "L"), (float)dropout);
+    TORCH_CHECK(n >= 0, "lstm_workspace: invalid sizes");
+    return n;
+}
+
+void lstm_check_params(const LstmDims& d, const Tensor& c0, const Tensor& bias, const Tensor& gamma, const Tensor& beta) {
+    const int64_t G = 4 * d.H;
+    req(c0, "c0", d.dev, {d.L, d.B, d.H});
+    req(bias, "bias", d.dev);
+    req(gamma, "ln_gamma", d.dev);
+    req(beta, "ln_beta", d.dev);
+    TORCH_CHECK(bias.numel() == d.L * G && gamma.numel() == d.L * 2 * G && beta.numel() == d.L * 2 * G,
+                "bias / ln_gamma / ln_beta: wrong number of elements");
+}
+
+void lstm_forward_launch(const LstmDims& d, const Tensor& x, const Tensor& h0, const Tensor& c0, const Tensor& wx,
+                         const Tensor& wh, const Tensor& bias, const Tensor& gamma, const Tensor& beta, const Tensor& y,
+                         const Tensor& hn, const Tensor& cn, const Tensor& ws, double dropout, uint64_t seed) {
+    check(hpc_rll_lstm_forward(fptr(x), fptr(h0), fptr(c0), fptr(wx), fptr(wh), fptr(bias), fptr(gamma), fptr(beta),
+                               fmut(y), fmut(hn), fmut(cn), fmut(ws), (int)d.S, (int)d.B, (int)d.I, (int)d.H, (int)d.L,
+                               (float)dropout, seed, stream_of(d.dev)),
+          "hpc_rll_lstm_forward");
+}
+
+struct LstmGrads { Tensor dx, dh0, dc0, dwx, dwh, dbias, dgamma, dbeta; };
+
+void lstm_backward_launch(const LstmDims& d, const Tensor& dy, const Tensor& dhn, const Tensor& dcn, const Tensor& x,
+                          const Tensor& h0, const Tensor& c0, const Tensor& wx, const Tensor& wh, const Tensor& gamma,
+                          const Tensor& ws, const LstmGrads& g, double dropout, uint64_t seed) {
+    check(hpc_rll_lstm_backward(fptr(dy), fptr(dhn), fptr(dcn), fptr(x), fptr(h0), fptr(c0), fptr(wx), fptr(wh),
+                                fptr(gamma), fmut(ws), fmut(g.dx), fmut(g.dh0), fmut(g.dc0), fmut(g.dwx), fmut(g.dwh),
+                                fmut(g.dbias), fmut(g.dgamma), fmut(g.dbeta), (int)d.S, (int)d.B, (int)d.I, (int)d.H,
+                                (int)d.L, (float)dropout, seed, stream_of(d.dev)),
+          "hpc_rll_lstm_backward");
+}
+
+SavedByBuffer& saved() {
+    static SavedByBuffer* s = new SavedByBuffer();
+    return *s;
+}
+std::atomic<uint64_t> g_ref_seed{0x9E3779B97F4A7C15ull};
+
+// native:    inputs = [x (S,B,I), h0 (L,B,H), c0 (L,B,H), wx (flat), wh (flat), bias (L*4H), ln_gamma (L,8H),
+//            ln_beta (L,8H)]; outputs = [y (S,B,H), hn (L,B,H), cn (L,B,H), ws = lstm_workspace(...)]; (dropout, seed)
+// reference: same inputs (rnn.py:16); outputs = [xbuf, hbuf, hn (S,L,B,H), cn (S,L,B,H), ifog, ym (L,S,B,H), ln_in,
+//            ln_mean, ln_rstd, dropout_mask] (rnn.py:17): y is written to ym[L-1], the final states to hn[S-1] /
+//            cn[S-1] -- exactly the views the reference L1 returns (rnn.py:27-31); the other scratch buffers are not
+//            touched, the workspace is parked under `ifog`.  Reference: src/torch_utils/network/lstm.cu:29-186.
+void LstmForward(const TensorList& in, const TensorList& out, double dropout, std::optional<uint64_t> seed_opt) {
+    expect_len(in, 8, "LstmForward inputs");
+    TORCH_CHECK(out.size() == 4 || out.size() == 10, "LstmForward outputs: expected 4 (native) or 10 (reference)");
+    const LstmDims d = lstm_dims(in[0], in[1], in[3], in[4]);
+    lstm_check_params(d, in[2], in[5], in[6], in[7]);
+    c10::DeviceGuard g(d.dev);
+    if (out.size() == 4) {
+        req(out[0], "y", d.dev, {d.S, d.B, d.H});
+        req(out[1], "hn", d.dev, {d.L, d.B, d.H});
+        req(out[2], "cn", d.dev, {d.L, d.B, d.H});
+        req(out[3], "ws", d.dev, {lstm_ws_floats(d, dropout)});
+        lstm_forward_launch(d, in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], out[0], out[1], out[2], out[3],
+                            dropout, seed_opt.value_or(0));
+        return;
+    }
+    const Tensor &hn_all = out[2], &cn_all = out[3], &ifog = out[4], &ym = out[5];
+    req(hn_all, "hn", d.dev, {d.S, d.L, d.B, d.H});
+    req(cn_all, "cn", d.dev, {d.S, d.L, d.B, d.H});
+    req(ym, "ym", d.dev, {d.L, d.S, d.B, d.H});
+    req(ifog, "ifog", d.dev);
+    const uint64_t seed = dropout > 0.0 ? seed_opt.value_or(g_ref_seed.fetch_add(0x2545F4914F6CDD1Dull)) : 0;
+    Tensor ws = new_f32({lstm_ws_floats(d, dropout)}, d.dev);
+    lstm_forward_launch(d, in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], ym.select(0, d.L - 1),
+                        hn_all.select(0, d.S - 1), cn_all.select(0, d.S - 1), ws, dropout, seed);
+    SavedByBuffer::Entry e{{ws}};
+    e.seed = seed;
+    saved().put(ifog, std::move(e));
+}
+
+// native:    inputs = [dy (S,B,H)|None, dhn (L,B,H)|None, dcn (L,B,H)|None, x, h0, c0, wx, wh, ln_gamma, ws];
+//            outputs = [dx|None, dh0, dc0, dwx, dwh, dbias, d_ln_gamma, d_ln_beta]; (dropout, seed)
+// reference: inputs = [x, h0, c0, wx, wh, hn, cn, ifog, ym, ln_in, ln_mean, ln_rstd, ln_gamma, dropout_mask];
+//            outputs = [dgate, xbuf, hbuf, dx, dwx, dwh, dbias, d_ln_gamma, d_ln_beta, dy, dh, dc] (rnn.py:20-21,35-42).
+// The reference zeroes the incoming dhn/dcn (lstm.cu:309-310); here they are honoured in both conventions.
+// dx = None skips the input-gradient product of layer 0 (x needs no grad).  Reference: lstm.cu:188-379.
+void LstmBackward(const OptList& in, const OptList& out, double dropout, std::optional<uint64_t> seed_opt) {
+    const bool native = in.size() == 10 && out.size() == 8;
+    TORCH_CHECK(native || (in.size() == 14 && out.size() == 12),
+                "LstmBackward: expected 10 inputs / 8 outputs (native) or 14 / 12 (reference), got ", in.size(), " / ",
+                out.size());
+    auto T = [](const OptTensor& t) { return has(t) ? *t : undef(); };
+    Tensor dy, dhn, dcn, x, h0, c0, wx, wh, gamma, ws;
+    LstmGrads gr;
+    uint64_t seed = seed_opt.value_or(0);
+    if (native) {
+        dy = T(in[0]); dhn = T(in[1]); dcn = T(in[2]); x = T(in[3]); h0 = T(in[4]); c0 = T(in[5]); wx = T(in[6]);
+        wh = T(in[7]); gamma = T(in[8]); ws = T(in[9]);
+        gr = {T(out[0]), T(out[1]), T(out[2]), T(out[3]), T(out[4]), T(out[5]), T(out[6]), T(out[7])};
+    } else {
+        x = T(in[0]); h0 = T(in[1]); c0 = T(in[2]); wx = T(in[3]); wh = T(in[4]); gamma = T(in[12]);
+        TORCH_CHECK(has(in[7]), "LstmBackward: ifog is None");
+        auto e = saved().get(*in[7], "LstmBackward");
+        ws = e.tensors[0];
+        seed = e.seed;
+        dy = T(out[9]); dhn = T(out[10]); dcn = T(out[11]);
+        gr.dx = T(out[3]); gr.dwx = T(out[4]); gr.dwh = T(out[5]); gr.dbias = T(out[6]); gr.dgamma = T(out[7]);
+        gr.dbeta = T(out[8]);
+    }
+    const LstmDims d = lstm_dims(x, h0, wx, wh);
+    req(c0, "c0", d.dev, {d.L, d.B, d.H});
+    req(gamma, "ln_gamma", d.dev);
+    req(ws, "ws", d.dev, {lstm_ws_floats(d, dropout)});
+    c10::DeviceGuard g(d.dev);
+    if (!native) {   // the reference has no slots for dh0 / dc0
+        gr.dh0 = at::empty_like(h0);
+        gr.dc0 = at::empty_like(c0);
+        if (dy.defined() && !dy.is_contiguous()) dy = dy.contiguous();
+        if (dhn.defined() && !dhn.is_contiguous()) dhn = dhn.contiguous();
+        if (dcn.defined() && !dcn.is_contiguous()) dcn = dcn.contiguous();
+    }
+    if (dy.defined()) req(dy, "dy", d.dev, {d.S, d.B, d.H});
+    if (dhn.defined()) req(dhn, "dhn", d.dev, {d.L, d.B, d.H});
+    if (dcn.defined()) req(dcn, "dcn", d.dev, {d.L, d.B, d.H});
+    if (gr.dx.defined()) req(gr.dx, "dx", d.dev, {d.S, d.B, d.I});
+    req(gr.dh0, "dh0", d.dev, {d.L, d.B, d.H});
+    req(gr.dc0, "dc0", d.dev, {d.L, d.B, d.H});
+    const std::pair<const Tensor*, const Tensor*> same[] = {{&gr.dwx, &wx}, {&gr.dwh, &wh}, {&gr.dgamma, &gamma},
+                                                            {&gr.dbeta, &gamma}};
+    const char* names[] = {"dwx", "dwh", "d_ln_gamma", "d_ln_beta"};
+    for (int i = 0; i < 4; ++i) {
+        req(*same[i].first, names[i], d.dev);
+        TORCH_CHECK(same[i].first->numel() == same[i].second->numel(), names[i], ": ", same[i].first->numel(),
+                    " elements, expected ", same[i].second->numel());
+    }
+    req(gr.dbias, "dbias", d.dev);
+    TORCH_CHECK(gr.dbias.numel() == d.L * 4 * d.H, "dbias: wrong number of elements");
+    lstm_backward_launch(d, dy, dhn, dcn, x, h0, c0, wx, wh, gamma, ws, gr, dropout, seed);
+}
+
+struct LstmFn : public ag::Function<LstmFn> {
+    static ag::tensor_list forward(ag::AutogradContext* ctx, const Tensor& x, const Tensor& wx, const Tensor& wh,
+                                   const Tensor& bias, const Tensor& gamma, const Tensor& beta, const Tensor& h0,
+                                   const Tensor& c0, double dropout, int64_t seed) {
+        const LstmDims d = lstm_dims(x, h0, wx, wh);
+        lstm_check_params(d, c0, bias, gamma, beta);
+        c10::DeviceGuard g(d.dev);
+        Tensor y = new_f32({d.S, d.B, d.H}, d.dev), hn = new_f32({d.L, d.B, d.H}, d.dev),
+               cn = new_f32({d.L, d.B, d.H}, d.dev);
+        Tensor ws = new_f32({lstm_ws_floats(d, dropout)}, d.dev);
+        lstm_forward_launch(d, x, h0, c0, wx, wh, bias, gamma, beta, y, hn, cn, ws, dropout, (uint64_t)seed);
+        ctx->save_for_backward({x, h0, c0, wx, wh, gamma, ws});
+        ctx->saved_data["dropout"] = dropout;
+        ctx->saved_data["seed"] = seed;
+        ctx->saved_data["bias_shape"] = bias.sizes().vec();
+        ctx->saved_data["beta_shape"] = beta.sizes().vec();
+        return {y, hn, cn};
+    }
+    static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {
+        const auto s = ctx->get_saved_variables();
+        const Tensor &x = s[0], &h0 = s[1], &c0 = s[2], &wx = s[3], &wh = s[4], &gamma = s[5], &ws = s[6];
+        const LstmDims d = lstm_dims(x, h0, wx, wh);
+        c10::DeviceGuard g(d.dev);
+        auto cont = [](const Tensor& t) { return t.defined() ? t.contiguous() : t; };
+        LstmGrads gr;
+        gr.dx = ctx->needs_input_grad(0) ? at::empty_like(x) : undef();   // x without grad: layer-0 dx GEMM is skipped
+        gr.dh0 = at::empty_like(h0);
+        gr.dc0 = at::empty_like(c0);
+        gr.dwx = at::empty_like(wx);
+        gr.dwh = at::empty_like(wh);
+        gr.dbias = new_f32(ctx->saved_data["bias_shape"].toIntVector(), d.dev);
+        gr.dgamma = at::empty_like(gamma);
+        gr.dbeta = new_f32(ctx->saved_data["beta_shape"].toIntVector(), d.dev);
+        lstm_backward_launch(d, cont(grads[0]), cont(grads[1]), cont(grads[2]), x, h0, c0, wx, wh, gamma, ws, gr,
+                             ctx->saved_data["dropout"].toDouble(), (uint64_t)ctx->saved_data["seed"].toInt());
+        return {gr.dx, gr.dwx, gr.dwh, gr.dbias, gr.dgamma, gr.dbeta, gr.dh0, gr.dc0, undef(), undef()};
+    }
+};
+
+// out (M,N) (+)= a (M,K) @ b (K,N) in exact fp32 on the matrix cores; a and b may be arbitrary 2-D strided views (e.g.
+// w.t()), which is how the NN / NT / TN layouts of the LSTM are expressed.
+Tensor gemm_f32(const Tensor& a, const Tensor& b, const OptTensor& out_opt, bool accumulate) {
+    TORCH_CHECK(a.defined() && b.defined() && a.is_cuda() && b.is_cuda() && a.dim() == 2 && b.dim() == 2 &&
+                a.scalar_type() == at::kFloat && b.scalar_type() == at::kFloat && a.size(1) == b.size(0) &&
+                a.device() == b.device(), "gemm_f32: a (M,K), b (K,N) fp32 on one GPU expected");
+    const int64_t M = a.size(0), K = a.size(1), N = b.size(1);
+    const at::Device dev = a.device();
+    c10::DeviceGuard g(dev);
+    Tensor out = has(out_opt) ? *out_opt : new_f32({M, N}, dev);
+    req(out, "out", dev, {M, N});
+    check(hpc_rll_gemm_f32(fptr(a), fptr(b), fmut(out), to_int(M, "M"), to_int(N, "N"), to_int(K, "K"), a.stride(0),
+                           a.stride(1), b.stride(0), b.stride(1), out.stride(0), accumulate ? 1 : 0, stream_of(dev)),
+          "hpc_rll_gemm_f32");
+    return out;
+}
+
+// ============================================================================================= ScatterConnection
+struct ScatterDims { int64_t B, M, N, H, W; at::Device dev; };
+
+ScatterDims scatter_check(const Tensor& x, const Tensor& location, int64_t H, int64_t W) {
+    req(x, "x");
+    TORCH_CHECK(x.dim() == 3, "x: expected (B,M,N), got ", x.sizes());
+    const int64_t B = x.size(0), M = x.size(1), N = x.size(2);
+    req(location, "location", x.device(), {B, M, 2}, at::kLong);
+    return {B, M, N, H, W, x.device()};
+}
+int scatter_mode(const std::string& t) {
+    TORCH_CHECK(t == "cover" || t == "add", "scatter_type: '", t, "'");
+    return t == "add" ? 1 : 0;
+}
+void scatter_forward_launch(const ScatterDims& d, const Tensor& x, const Tensor& location, const Tensor& out, int add) {
+    const int B = to_int(d.B, "B"), M = to_int(d.M, "M"), N = to_int(d.N, "N"), H = to_int(d.H, "H"), W = to_int(d.W, "W");
+    Tensor ws = at::empty({hpc_rll_scatter_workspace_ints(B, M, H, W)}, at::TensorOptions().dtype(at::kInt).device(d.dev));
+    check(hpc_rll_scatter_connection_forward(fptr(x), iptr(location), fmut(out), ws.data_ptr<int32_t>(), B, M, N, H, W, add,
+                                             stream_of(d.dev)),
+          "hpc_rll_scatter_connection_forward");
+}
+void scatter_backward_launch(const Tensor& grad_out, const Tensor& location, const Tensor& grad_x) {
+    check(hpc_rll_scatter_connection_backward(fptr(grad_out), iptr(location), fmut(grad_x), (int)grad_out.size(0),
+                                              (int)location.size(1), (int)grad_out.size(1), (int)grad_out.size(2),
+                                              (int)grad_out.size(3), stream_of(grad_out.device())),
+          "hpc_rll_scatter_connection_backward");
+}
+
+// inputs = [x (B,M,N) fp32, location (B,M,2) int64 (y,x)], outputs = [out (B,N,H,W)] (fully overwritten).
+// Reference: src/torch_utils/network/scatter_connection.cu:8-49.
+void ScatterConnectionForward(const TensorList& in, const TensorList& out, const std::string& scatter_type) {
+    expect_len(in, 2, "ScatterConnectionForward inputs");
+    expect_len(out, 1, "ScatterConnectionForward outputs");
+    req(in[0], "x");
+    const Tensor& o = req(out[0], "output", in[0].device());
+    TORCH_CHECK(in[0].dim() == 3 && o.dim() == 4 && o.size(0) == in[0].size(0) && o.size(1) == in[0].size(2),
+                "output: expected (B,N,H,W) matching x (B,M,N), got ", o.sizes(), " for x ", in[0].sizes());
+    const ScatterDims d = scatter_check(in[0], in[1], o.size(2), o.size(3));
+    c10::DeviceGuard g(d.dev);
+    scatter_forward_launch(d, in[0], in[1], o, scatter_mode(scatter_type));
+}
+
+// inputs = [grad_out (B,N,H,W), location (B,M,2)], outputs = [grad_x (B,M,N)].  scatter_connection.cu:51-73.
+void ScatterConnectionBackward(const TensorList& in, const TensorList& out) {
+    expect_len(in, 2, "ScatterConnectionBackward inputs");
+    expect_len(out, 1, "ScatterConnectionBackward outputs");
+    const Tensor& go = req(in[0], "grad_out");
+    TORCH_CHECK(go.dim() == 4, "grad_out: expected (B,N,H,W), got ", go.sizes());
+    const at::Device dev = go.device();
+    TORCH_CHECK(in[1].defined() && in[1].dim() == 3, "location: expected (B,M,2)");
+    const int64_t M = in[1].size(1);
+    req(in[1], "location", dev, {go.size(0), M, 2}, at::kLong);
+    req(out[0], "grad_x", dev, {go.size(0), M, go.size(1)});
+    c10::DeviceGuard g(dev);
+    scatter_backward_launch(go, in[1], out[0]);
+}
+
+struct ScatterFn : public ag::Function<ScatterFn> {
+    static Tensor forward(ag::AutogradContext* ctx, const Tensor& x, const Tensor& location, int64_t H, int64_t W,
+                          int64_t add) {
+        const ScatterDims d = scatter_check(x, location, H, W);
+        c10::DeviceGuard g(d.dev);
+        Tensor out = new_f32({d.B, d.N, H, W}, d.dev);
+        scatter_forward_launch(d, x, location, out, (int)add);
+        ctx->save_for_backward({location});
+        ctx->saved_data["N"] = d.N;
+        return out;
+    }
+    static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {
+        if (!ctx->needs_input_grad(0)) return {undef(), undef(), undef(), undef(), undef()};
+        const Tensor location = ctx->get_saved_variables()[0];
+        Tensor go = grads[0].contiguous();
+        req(go, "grad_out", location.device());
+        c10::DeviceGuard g(go.device());
+        Tensor gx = new_f32({go.size(0), location.size(1), go.size(1)}, go.device());
+        scatter_backward_launch(go, location, gx);
+        return {gx, undef(), undef(), undef(), undef()};
+    }
+};
+
+}  // namespace
+}  // namespace hpc_rll_ext
+
+PYBIND11_MODULE(hpc_torch_utils_network, m) {
+    using namespace hpc_rll_ext;
+    namespace py = pybind11;
+    m.doc() = "hpc_torch_utils_network: LayerNorm-LSTM and ScatterConnection for MI355X (gfx950) -- compiled "
+              "PyTorch-ROCm extension over the C ABI of libhpc_rll_hip.so (reference: src/torch_utils/network/entry.cpp:8-13)";
+    bind_common(m);
+    m.def("LstmForward", &LstmForward, py::arg("inputs"), py::arg("outputs"), py::arg("dropout"),
+          py::arg("seed") = py::none(), "lstm forward (HIP)");
+    m.def("LstmBackward", &LstmBackward, py::arg("inputs"), py::arg("outputs"), py::arg("dropout"),
+          py::arg("seed") = py::none(), "lstm backward (HIP)");
+    m.def("ScatterConnectionForward", &ScatterConnectionForward, "scatter_connection forward (HIP)");
+    m.def("ScatterConnectionBackward", &ScatterConnectionBackward, "scatter_connection backward (HIP)");
+    m.def("lstm_workspace", [](int64_t S, int64_t B, int64_t I, int64_t H, int64_t L, double dropout, const at::Device& dev) {
+        return new_f32({lstm_ws_floats(LstmDims{S, B, I, H, L, dev}, dropout)}, dev);
+    });
+    m.def("gemm_f32", &gemm_f32, py::arg("a"), py::arg("b"), py::arg("out") = py::none(), py::arg("accumulate") = false);
+
+    m.def("lstm", [](const Tensor& x, const Tensor& wx, const Tensor& wh, const Tensor& bias, const Tensor& gamma,
+                     const Tensor& beta, const Tensor& h0, const Tensor& c0, double dropout, int64_t seed) {
+        return LstmFn::apply(x, wx, wh, bias, gamma, beta, h0, c0, dropout, seed);
+    }, py::arg("x"), py::arg("wx"), py::arg("wh"), py::arg("bias"), py::arg("ln_gamma"), py::arg("ln_beta"), py::arg("h0"),
+          py::arg("c0"), py::arg("dropout") = 0.0, py::arg("seed") = 0,
+          "(y, hn, cn) = LayerNorm-LSTM(x (S,B,I), h0, c0 (L,B,H)); differentiable wrt x, the parameters, h0 and c0");
+    m.def("scatter_connection", [](const Tensor& x, const Tensor& location, int64_t H, int64_t W,
+                                   const std::string& scatter_type) {
+        return ScatterFn::apply(x, location, H, W, (int64_t)scatter_mode(scatter_type));
+    }, py::arg("x"), py::arg("location"), py::arg("H"), py::arg("W"), py::arg("scatter_type"));
+}

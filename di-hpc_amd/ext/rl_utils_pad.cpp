@@ -1,0 +1,313 @@
+// rl_utils_pad.cpp -- Pad / GroupPad / Unpad {1,2,3}D, the group-split policies and the packed (CSR-style) variants
+// of the `hpc_rl_utils` module.  Reference: include/hpc/rll/cuda/rl_utils/entry.h:10-59, src/rl_utils/padding.cu:8-582.
+//
+// Host side of a ragged python list: n tensors are described to ONE kernel launch by a device table
+// {pointer | flat offset, d0, d1, d2} built here with a plain C++ loop into pinned memory (the reference does a
+// cudaMalloc + blocking cudaMemcpy of raw pointers per call, padding.cu:118-138).
+#include "common.hpp"
+
+#include <algorithm>
+#include <array>
+#include <numeric>
+
+namespace hpc_rll_ext {
+namespace {
+
+using Shape3 = std::array<int64_t, 3>;
+
+// (d0,d1,d2) with the tensor's own axes right-aligned: a rank-1 tensor of length L is (1,1,L).
+Shape3 dims3(at::IntArrayRef s) {
+    Shape3 r{1, 1, 1};
+    for (size_t i = 0; i < s.size(); ++i) r[3 - s.size() + i] = s[i];
+    return r;
+}
+
+// table (n,4) int64 = [data_ptr, d0, d1, d2]; shapes (n,rank) int64.  Pure host logic.
+void fill_pad_table(const TensorList& inputs, int rank, int64_t* table, int64_t* shapes) {
+    const int64_t n = (int64_t)inputs.size();
+    for (int64_t i = 0; i < n; ++i) {
+        const Tensor& t = inputs[i];
+        int64_t* row = table + 4 * i;
+        row[0] = (int64_t)(uintptr_t)t.data_ptr();
+        row[1] = row[2] = row[3] = 1;
+        for (int d = 0; d < rank; ++d) {
+            const int64_t v = t.size(d);
+            row[4 - rank + d] = v;
+            shapes[i * rank + d] = v;
+        }
+    }
+}
+
+void check_pad_inputs(const TensorList& inputs, int rank, const at::Device& dev) {
+    for (size_t i = 0; i < inputs.size(); ++i) {
+        const Tensor& t = inputs[i];
+        const bool ok = t.defined() && t.is_cuda() && t.device() == dev && t.scalar_type() == at::kFloat &&
+                        t.is_contiguous() && t.dim() == rank;
+        if (!ok) {   // slow path only to produce the precise message
+            const std::string name = "inputs[" + std::to_string(i) + "]";
+            req(t, name.c_str(), dev);
+            TORCH_CHECK(t.dim() == rank, name, ": rank ", t.dim(), ", expected ", rank);
+        }
+    }
+}
+
+Tensor to_device_table(const Tensor& pinned, const at::Device& dev) { return pinned.to(dev, /*non_blocking=*/true); }
+
+Tensor pinned_i64(at::IntArrayRef shape) {
+    return at::empty(shape, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+}
+
+// list of n rank-`rank` tensors -> [new_x (n, max_shape...) fp32, mask (same shape) int32]
+TensorList pad_forward(const TensorList& inputs, int64_t value, int rank, const int64_t* max_shape /* rank ints or null */) {
+    const int64_t n = (int64_t)inputs.size();
+    TORCH_CHECK(n > 0, "Padding: empty input list");
+    req(inputs[0], "inputs[0]");
+    const at::Device dev = inputs[0].device();
+    check_pad_inputs(inputs, rank, dev);
+    c10::DeviceGuard g(dev);
+    Tensor table = pinned_i64({n, 4});
+    std::vector<int64_t> shapes((size_t)n * rank);
+    fill_pad_table(inputs, rank, table.data_ptr<int64_t>(), shapes.data());
+    std::vector<int64_t> out_shape(rank + 1, 0);
+    out_shape[0] = n;
+    if (max_shape) {
+        for (int d = 0; d < rank; ++d) out_shape[d + 1] = max_shape[d];
+    } else {
+        for (int64_t i = 0; i < n; ++i)
+            for (int d = 0; d < rank; ++d) out_shape[d + 1] = std::max(out_shape[d + 1], shapes[i * rank + d]);
+    }
+    const Shape3 m = dims3(at::IntArrayRef(out_shape).slice(1));
+    Tensor dtable = to_device_table(table, dev);
+    Tensor new_x = at::empty(out_shape, at::TensorOptions().dtype(at::kFloat).device(dev));
+    Tensor mask = at::empty(out_shape, at::TensorOptions().dtype(at::kInt).device(dev));
+    check(hpc_rll_pad_forward(dtable.const_data_ptr<int64_t>(), new_x.data_ptr<float>(), mask.data_ptr<int32_t>(), n,
+                              to_int(m[0], "max_shape"), to_int(m[1], "max_shape"), to_int(m[2], "max_shape"),
+                              (int)value, stream_of(dev)),
+          "hpc_rll_pad_forward");
+    return {new_x, mask};
+}
+
+// inputs sorted by numel; group g = inputs[group_idx[g]:group_idx[g+1]] padded to max_shape[g*rank:(g+1)*rank].
+// One pad launch per group.  Returns [list of new_x, list of mask].  Reference: padding.cu:142-226,299-379,458-541.
+std::vector<TensorList> group_pad_forward(const TensorList& inputs, const std::vector<int64_t>& group_cnt,
+                                          const std::vector<int64_t>& max_shape, const std::vector<int64_t>& group_id,
+                                          const std::vector<int64_t>& group_idx, int64_t value, int rank) {
+    const size_t ng = group_cnt.size();
+    TORCH_CHECK(group_idx.size() == ng + 1, "GroupPad: group_idx must hold len(group_cnt)+1 boundaries");
+    TORCH_CHECK(max_shape.size() == ng * rank, "GroupPad: max_shape must hold ", rank, " ints per group");
+    TORCH_CHECK(group_id.empty() || group_id.size() == inputs.size(), "GroupPad: group_id must hold one id per tensor");
+    std::vector<TensorList> res(2);
+    for (size_t gi = 0; gi < ng; ++gi) {
+        const int64_t lo = group_idx[gi], hi = group_idx[gi + 1];
+        TORCH_CHECK(0 <= lo && lo <= hi && hi <= (int64_t)inputs.size(), "GroupPad: bad group boundaries");
+        TensorList sub(inputs.begin() + lo, inputs.begin() + hi);
+        TensorList xm = pad_forward(sub, value, rank, max_shape.data() + gi * rank);
+        res[0].push_back(xm[0]);
+        res[1].push_back(xm[1]);
+    }
+    return res;
+}
+
+// Host table of the inverse: table (n,4) = [flat offset, d0, d1, d2], numel (n), offs (n+1); raises if a shape does
+// not fit the padded tensor.
+struct UnpadPlan { std::vector<int64_t> table, numel, offs, sh; int64_t n; };
+UnpadPlan unpad_plan(const std::vector<int64_t>& shapes, at::IntArrayRef padded_shape, int rank) {
+    UnpadPlan p;
+    TORCH_CHECK(shapes.size() % rank == 0, "shapes: ", shapes.size(), " ints is not a multiple of the rank ", rank);
+    const int64_t n = p.n = (int64_t)shapes.size() / rank;
+    p.table.assign((size_t)n * 4, 1);
+    p.numel.resize(n);
+    p.offs.assign(n + 1, 0);
+    p.sh = shapes;
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t e = 1;
+        for (int d = 0; d < rank; ++d) {
+            const int64_t v = shapes[i * rank + d];
+            if (v < 0 || v > padded_shape[d]) {
+                TORCH_CHECK(false, "shapes: ", at::IntArrayRef(shapes.data() + i * rank, rank),
+                            " does not fit the padded tensor ", padded_shape);
+            }
+            p.table[4 * i + 4 - rank + d] = v;
+            e *= v;
+        }
+        p.numel[i] = e;
+        p.table[4 * i] = p.offs[i];
+        p.offs[i + 1] = p.offs[i] + e;
+    }
+    return p;
+}
+
+// x (n, m...) padded; shapes = flat int list (rank ints per tensor, the hpc convention, rl_utils/padding.py:101-104).
+// Returns n tensors that are views of ONE flat buffer.  Reference: padding.cu:228-260,381-415,543-582.
+TensorList unpad_forward(const Tensor& x, const std::vector<int64_t>& shapes, int rank) {
+    req(x, "x");
+    TORCH_CHECK(x.dim() == rank + 1, "x: rank ", x.dim(), ", expected ", rank + 1);
+    const int64_t n = x.size(0);
+    TORCH_CHECK((int64_t)shapes.size() == n * rank, "shapes: ", shapes.size(), " ints, expected ", n, "*", rank);
+    const at::Device dev = x.device();
+    const UnpadPlan p = unpad_plan(shapes, x.sizes().slice(1), rank);
+    const int64_t total = p.offs[n];
+    c10::DeviceGuard g(dev);
+    Tensor flat = new_f32({total}, dev);
+    if (n && total) {
+        Tensor table = pinned_i64({n, 4});
+        std::copy(p.table.begin(), p.table.end(), table.data_ptr<int64_t>());
+        Tensor dtable = to_device_table(table, dev);
+        const Shape3 m = dims3(x.sizes().slice(1));
+        check(hpc_rll_unpad_forward(x.const_data_ptr<float>(), dtable.const_data_ptr<int64_t>(), flat.data_ptr<float>(), n,
+                                    total, to_int(m[0], "shape"), to_int(m[1], "shape"), to_int(m[2], "shape"),
+                                    stream_of(dev)),
+              "hpc_rll_unpad_forward");
+    }
+    TensorList out;
+    out.reserve(n);
+    for (int64_t i = 0; i < n; ++i)
+        out.push_back(flat.as_strided(
+            at::IntArrayRef(p.sh.data() + i * rank, rank),
+            rank == 1 ? std::vector<int64_t>{1}
+                      : (rank == 2 ? std::vector<int64_t>{p.sh[i * 2 + 1], 1}
+                                   : std::vector<int64_t>{p.sh[i * 3 + 1] * p.sh[i * 3 + 2], p.sh[i * 3 + 2], 1}),
+            p.offs[i]));
+    return out;
+}
+
+// ---- group-split policies (host logic in the C ABI; reference: padding.cu:8-108)
+std::vector<std::vector<int64_t>> split_group(const TensorList& inputs, int64_t group, bool oracle, uint64_t seed) {
+    const int64_t n = (int64_t)inputs.size();
+    TORCH_CHECK(n > 0, "split_group: empty input list");
+    const int rank = (int)inputs[0].dim();
+    TORCH_CHECK(rank >= 1 && rank <= 3, "split_group: rank ", rank, " not in 1..3");
+    std::vector<int32_t> sizes((size_t)n * rank);
+    for (int64_t i = 0; i < n; ++i) {
+        TORCH_CHECK(inputs[i].dim() == rank, "split_group: inputs[", i, "] has rank ", inputs[i].dim());
+        for (int d = 0; d < rank; ++d) sizes[i * rank + d] = (int32_t)inputs[i].size(d);
+    }
+    const int64_t gmax = std::max<int64_t>(group, 1);
+    std::vector<int32_t> shapes((size_t)gmax * rank), pos((size_t)gmax + 1);
+    const int ng = oracle ? hpc_rll_oracle_split_group(sizes.data(), (int)n, rank, (int)group, shapes.data(), pos.data())
+                          : hpc_rll_sample_split_group(sizes.data(), (int)n, rank, (int)group, seed, shapes.data(),
+                                                       pos.data());
+    if (ng < 0) check(ng, "split_group");
+    std::vector<std::vector<int64_t>> res;
+    for (int gi = 0; gi < ng; ++gi) res.emplace_back(shapes.begin() + gi * rank, shapes.begin() + (gi + 1) * rank);
+    res.emplace_back(pos.begin(), pos.begin() + ng + 1);
+    return res;
+}
+
+// ---- packed (CSR-style) variants, not in the reference: ONE flat buffer + a device vector of lengths, the table is
+// built on the device (exclusive scan in the C ABI), no host loop and -- when max_len / total are given -- no host sync.
+Tensor packed_table(const Tensor& lengths, int64_t base, int64_t stride, const at::Device& dev) {
+    const int64_t n = lengths.numel();
+    Tensor table = at::empty({n, 4}, at::TensorOptions().dtype(at::kLong).device(dev));
+    Tensor scratch = at::empty({hpc_rll_packed_table_scratch_int64(n)}, at::TensorOptions().dtype(at::kLong).device(dev));
+    check(hpc_rll_packed_table(lengths.const_data_ptr<int64_t>(), n, base, stride, table.data_ptr<int64_t>(),
+                               scratch.data_ptr<int64_t>(), stream_of(dev)),
+          "hpc_rll_packed_table");
+    return table;
+}
+
+// flat (sum(lengths),) fp32, lengths (n,) int64 on the same GPU -> [new_x (n,max_len) fp32, mask (n,max_len) int32].
+TensorList pad1d_packed(const Tensor& flat, const Tensor& lengths, std::optional<int64_t> max_len, int64_t value) {
+    req(flat, "flat");
+    const at::Device dev = flat.device();
+    req(lengths, "lengths", dev, at::kLong);
+    TORCH_CHECK(flat.dim() == 1 && lengths.dim() == 1, "Padding1DPacked: flat and lengths must be 1-D");
+    const int64_t n = lengths.numel();
+    c10::DeviceGuard g(dev);
+    int64_t ml = 0;
+    if (max_len.has_value()) ml = *max_len;
+    else if (n) ml = lengths.max().item<int64_t>();   // the only host sync; pass max_len to avoid it
+    Tensor new_x = new_f32({n, ml}, dev);
+    Tensor mask = at::empty({n, ml}, at::TensorOptions().dtype(at::kInt).device(dev));
+    if (n && ml) {
+        Tensor table = packed_table(lengths, (int64_t)(uintptr_t)flat.data_ptr(), 4, dev);
+        check(hpc_rll_pad_forward(table.const_data_ptr<int64_t>(), new_x.data_ptr<float>(), mask.data_ptr<int32_t>(), n, 1, 1,
+                                  to_int(ml, "max_len"), (int)value, stream_of(dev)),
+              "hpc_rll_pad_forward");
+    }
+    return {new_x, mask};
+}
+
+// Inverse: x (n,max_len), lengths (n,) int64 -> flat (sum(lengths),).
+Tensor unpad1d_packed(const Tensor& x, const Tensor& lengths, std::optional<int64_t> total) {
+    req(x, "x");
+    const at::Device dev = x.device();
+    req(lengths, "lengths", dev, at::kLong);
+    TORCH_CHECK(x.dim() == 2 && lengths.dim() == 1 && lengths.numel() == x.size(0),
+                "UnPadding1DPacked: x must be (n,max_len) and lengths (n,)");
+    const int64_t n = x.size(0);
+    c10::DeviceGuard g(dev);
+    const int64_t tot = total.has_value() ? *total : (n ? lengths.sum().item<int64_t>() : 0);
+    Tensor flat = new_f32({tot}, dev);
+    if (n && tot) {
+        Tensor table = packed_table(lengths, 0, 1, dev);
+        check(hpc_rll_unpad_forward(x.const_data_ptr<float>(), table.const_data_ptr<int64_t>(), flat.data_ptr<float>(), n, tot,
+                                    1, 1, to_int(x.size(1), "max_len"), stream_of(dev)),
+              "hpc_rll_unpad_forward");
+    }
+    return flat;
+}
+
+}  // namespace
+
+void bind_padding(pybind11::module_& m) {
+    namespace py = pybind11;
+    using IntList = std::vector<int64_t>;
+    m.def("Pad1DForward", [](const TensorList& in, int64_t value) { return pad_forward(in, value, 1, nullptr); },
+          "list of n (L_i,) tensors -> [new_x (n,maxL) fp32, mask (n,maxL) int32]  (padding.cu:111-140)");
+    m.def("Pad2DForward", [](const TensorList& in, int64_t value) { return pad_forward(in, value, 2, nullptr); },
+          "padding.cu:262-297");
+    m.def("Pad3DForward", [](const TensorList& in, int64_t value) { return pad_forward(in, value, 3, nullptr); },
+          "padding.cu:417-456");
+    m.def("GroupPad1DForward", [](const TensorList& in, const IntList& cnt, const IntList& ms, const IntList& gid,
+                                  const IntList& gidx, int64_t value) {
+        return group_pad_forward(in, cnt, ms, gid, gidx, value, 1);
+    }, "padding.cu:142-226");
+    m.def("GroupPad2DForward", [](const TensorList& in, const IntList& cnt, const IntList& ms, const IntList& gid,
+                                  const IntList& gidx, int64_t value) {
+        return group_pad_forward(in, cnt, ms, gid, gidx, value, 2);
+    }, "padding.cu:299-379");
+    m.def("GroupPad3DForward", [](const TensorList& in, const IntList& cnt, const IntList& ms, const IntList& gid,
+                                  const IntList& gidx, int64_t value) {
+        return group_pad_forward(in, cnt, ms, gid, gidx, value, 3);
+    }, "padding.cu:458-541");
+    m.def("Unpad1DForward", [](const Tensor& x, const IntList& shapes) { return unpad_forward(x, shapes, 1); },
+          "padding.cu:228-260");
+    m.def("Unpad2DForward", [](const Tensor& x, const IntList& shapes) { return unpad_forward(x, shapes, 2); },
+          "padding.cu:381-415");
+    m.def("Unpad3DForward", [](const Tensor& x, const IntList& shapes) { return unpad_forward(x, shapes, 3); },
+          "padding.cu:543-582");
+    m.def("oracle_split_group", [](const TensorList& in, int64_t group) { return split_group(in, group, true, 0); },
+          "inputs sorted by numel -> [shape_0, ..., shape_{g-1}, positions]: DP minimising the padded element count "
+          "(padding.cu:44-108; same result as hpc_rll/origin/padding.py:11-50 for 1-D lists)");
+    m.def("sample_split_group", [](const TensorList& in, int64_t group, std::optional<uint64_t> seed) {
+        // random cuts (padding.cu:8-43).  The reference uses C rand(); here a splitmix64 stream seeded from python's
+        // `random` (or `seed`), so a run is reproducible under random.seed.
+        const uint64_t s = seed.has_value()
+                               ? *seed
+                               : py::module_::import("random").attr("getrandbits")(63).cast<uint64_t>();
+        return split_group(in, group, false, s);
+    }, py::arg("inputs"), py::arg("group"), py::arg("seed") = py::none());
+    m.def("pad1d_packed", &pad1d_packed, py::arg("flat"), py::arg("lengths"), py::arg("max_len") = py::none(),
+          py::arg("value") = 0);
+    m.def("unpad1d_packed", &unpad1d_packed, py::arg("x"), py::arg("lengths"), py::arg("total") = py::none());
+
+    // host-logic hooks for the CPU test tier (no GPU needed): the tables the pad / unpad kernels consume
+    m.def("_pad_table", [](const TensorList& in, int rank) {
+        const int64_t n = (int64_t)in.size();
+        Tensor table = at::empty({n, 4}, at::kLong), shapes = at::empty({n, rank}, at::kLong);
+        for (const Tensor& t : in) TORCH_CHECK(t.dim() == rank, "rank mismatch");
+        fill_pad_table(in, rank, table.data_ptr<int64_t>(), shapes.data_ptr<int64_t>());
+        return std::make_pair(table, shapes);
+    });
+    m.def("_unpad_table", [](const IntList& shapes, const IntList& padded_shape, int rank) {
+        const UnpadPlan p = unpad_plan(shapes, padded_shape, rank);
+        auto as_t = [](const std::vector<int64_t>& v, at::IntArrayRef shape) {
+            return at::tensor(v, at::kLong).reshape(shape);
+        };
+        return std::make_tuple(as_t(p.table, {p.n, 4}), as_t(p.numel, {p.n}), as_t(p.offs, {p.n + 1}),
+                               as_t(p.sh, {p.n, rank}));
+    });
+}
+
+}  // namespace hpc_rll_ext

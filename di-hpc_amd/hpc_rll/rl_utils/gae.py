@@ -7,32 +7,13 @@ Differences, all deliberate:
     that every call overwrites (reference gae.py:39);
   * backward exists: the reference returns None for every input (gae.py:17-18), here
     ``adv.backward(g)`` yields d/dvalue and d/dreward (analytic adjoint of hpc_rll.origin.gae).
+
+The autograd node lives in the compiled extension (``hpc_rl_utils.gae``, a torch::autograd::Function): one pybind
+call per forward, backward runs entirely inside the autograd engine.
 """
 import torch
 
 import hpc_rl_utils
-
-
-class GAEFunction(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, value, reward, gamma, lambda_):
-        adv = torch.empty_like(reward)
-        hpc_rl_utils.GaeForward([value, reward], [adv], gamma, lambda_)
-        ctx.gamma, ctx.lambda_ = gamma, lambda_
-        return adv
-
-    @staticmethod
-    def backward(ctx, grad_adv):
-        need_v, need_r = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if not (need_v or need_r):
-            return None, None, None, None
-        grad_adv = grad_adv.contiguous()
-        T, B = grad_adv.shape
-        gv = torch.empty(T + 1, B, dtype=grad_adv.dtype, device=grad_adv.device) if need_v else None
-        gr = torch.empty_like(grad_adv) if need_r else None
-        hpc_rl_utils.GaeBackward([grad_adv], [gv, gr], ctx.gamma, ctx.lambda_)
-        return gv, gr, None, None
 
 
 class GAE(torch.nn.Module):
@@ -50,4 +31,4 @@ class GAE(torch.nn.Module):
         """value (T+1,B), reward (T,B) -> adv (T,B); all fp32 contiguous on the GPU."""
         assert value.is_cuda
         assert reward.is_cuda
-        return GAEFunction.apply(value, reward, gamma, lambda_)
+        return hpc_rl_utils.gae(value, reward, gamma, lambda_)

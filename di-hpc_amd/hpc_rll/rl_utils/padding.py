@@ -90,32 +90,12 @@ def UnPadding3D(x: Union[torch.Tensor, List[torch.Tensor]], shapes: Union[List, 
 # ---------------------------------------------------------------------------------------------------------------------
 def Padding1DPacked(flat: torch.Tensor, lengths: torch.Tensor, max_len: int = None, value: int = 0):
     """flat (sum(lengths),) fp32, lengths (n,) int64 on the same GPU -> (new_x (n,max_len) fp32, mask (n,max_len) int32).
-    Row i of new_x holds flat[offset_i : offset_i + lengths[i]] followed by ``value``."""
-    assert flat.is_cuda and lengths.is_cuda and lengths.dtype == torch.int64 and flat.dtype == torch.float32
-    n = lengths.numel()
-    if max_len is None:
-        max_len = int(lengths.max().item()) if n else 0          # the only host sync; pass max_len to avoid it
-    offs = torch.cumsum(lengths, 0) - lengths
-    one = torch.ones_like(lengths)
-    table = torch.stack([flat.data_ptr() + offs * 4, one, one, lengths], 1).contiguous()
-    new_x = torch.empty(n, max_len, dtype=torch.float32, device=flat.device)
-    mask = torch.empty(n, max_len, dtype=torch.int32, device=flat.device)
-    hpc_rl_utils.N.call("hpc_rll_pad_forward", flat.device, table.data_ptr(), new_x.data_ptr(), mask.data_ptr(), n, 1, 1,
-                        int(max_len), int(value))
+    Row i of new_x holds flat[offset_i : offset_i + lengths[i]] followed by ``value``.  The offsets are an exclusive scan
+    done on the device inside the extension; ``max_len=None`` costs the only host sync (lengths.max())."""
+    new_x, mask = hpc_rl_utils.pad1d_packed(flat, lengths, max_len, value)
     return new_x, mask
 
 
 def UnPadding1DPacked(x: torch.Tensor, lengths: torch.Tensor, total: int = None) -> torch.Tensor:
     """Inverse of :func:`Padding1DPacked`: x (n,max_len), lengths (n,) int64 -> flat (sum(lengths),)."""
-    assert x.is_cuda and lengths.is_cuda and lengths.dtype == torch.int64 and x.dim() == 2 and x.is_contiguous()
-    n, max_len = x.shape
-    if total is None:
-        total = int(lengths.sum().item())
-    offs = torch.cumsum(lengths, 0) - lengths
-    one = torch.ones_like(lengths)
-    table = torch.stack([offs, one, one, lengths], 1).contiguous()
-    flat = torch.empty(total, dtype=torch.float32, device=x.device)
-    if n and total:
-        hpc_rl_utils.N.call("hpc_rll_unpad_forward", x.device, x.data_ptr(), table.data_ptr(), flat.data_ptr(), n, total, 1,
-                            1, int(max_len))
-    return flat
+    return hpc_rl_utils.unpad1d_packed(x, lengths, total)

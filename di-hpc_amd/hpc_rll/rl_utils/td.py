@@ -6,6 +6,8 @@ td.py:63,165,242,332,439,549).
 Differences: outputs and scratch are allocated per call (the reference returns the same module
 buffer every call); inputs are validated; ``weight=None`` works for TD-lambda (the reference reads its (B,) default
 buffer as (T,B): SURVEY.md A.2); optional batch-axis data parallelism (``sharded=True``, see hpc_rll.dist).
+The autograd nodes are compiled torch::autograd::Functions in ``hpc_rl_utils`` (``td_lambda``, ``q_nstep_td``,
+``dist_nstep_td``, ``iqn_nstep_td``, ``qrdqn_nstep_td``): one pybind call per forward.
 """
 from typing import Optional
 
@@ -15,33 +17,25 @@ import hpc_rl_utils
 from hpc_rll import dist as _dp
 
 
-def _new(shape, ref):
-    return torch.empty(shape, dtype=torch.float32, device=ref.device)
+def _assert_cuda(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda
 
 
-# ------------------------------------------------------------------------------------------------ TD(lambda)
-class TDLambdaFunction(torch.autograd.Function):
+class _ShardedLoss(torch.nn.Module):
+    """Shared data-parallel plumbing: 1/(GLOBAL count) scale in, ONE all-reduce of the loss scalar out."""
 
-    @staticmethod
-    def forward(ctx, value, reward, weight, gamma, lambda_, sharded, group):
-        T, B = reward.shape
-        loss, grad_buf = _new((1,), reward), _new((T, B), reward)
-        hpc_rl_utils.TdLambdaForward([value, reward, weight], [loss, grad_buf], gamma, lambda_,
-                                     _dp.loss_scale(T * B, group, sharded))
-        _dp.all_reduce_losses_(loss, group, sharded)
-        ctx.grad_buf = grad_buf
+    def _scale(self, local_count):
+        return _dp.loss_scale(local_count, self.group, True) if self.sharded else None
+
+    def _reduce(self, loss):
+        if self.sharded:
+            _dp.all_reduce_losses_(loss.detach(), self.group, True)
         return loss
 
-    @staticmethod
-    def backward(ctx, grad_loss):
-        grad_buf = ctx.grad_buf
-        T, B = grad_buf.shape
-        grad_value = _new((T + 1, B), grad_buf)
-        hpc_rl_utils.TdLambdaBackward([grad_loss.contiguous(), grad_buf], [grad_value])
-        return grad_value, None, None, None, None, None, None
 
-
-class TDLambda(torch.nn.Module):
+class TDLambda(_ShardedLoss):
     """TD(lambda) loss: 0.5 * mean(weight * (lambda_return - value[:-1])^2), gradient w.r.t. ``value`` only."""
 
     def __init__(self, T, B, sharded: bool = False, group=None):
@@ -50,72 +44,13 @@ class TDLambda(torch.nn.Module):
 
     def forward(self, value, reward, weight=None, gamma: float = 0.9, lambda_: float = 0.8) -> torch.Tensor:
         """value (T+1,B), reward (T,B), weight None | (B,) | (T,B) -> loss (1,)."""
-        assert value.is_cuda
-        assert reward.is_cuda
-        if weight is not None:
-            assert weight.is_cuda
-        return TDLambdaFunction.apply(value, reward, weight, gamma, lambda_, self.sharded, self.group)
+        _assert_cuda(value, reward, weight)
+        return self._reduce(hpc_rl_utils.td_lambda(value, reward, weight, gamma, lambda_, self._scale(reward.numel())))
 
 
-# ------------------------------------------------------------------------------------------------ q n-step TD
-class _QNStepFunctionBase(torch.autograd.Function):
-    FWD = BWD = None
-
-    @classmethod
-    def _forward(cls, ctx, q, next_n_q, action, next_n_action, reward, done, weight, gamma, sharded, group):
-        B, N = q.shape
-        td_err, loss, grad_buf = _new((B,), q), _new((1,), q), _new((B,), q)
-        cls.FWD([q, next_n_q, action, next_n_action, reward, done, weight], [td_err, loss, grad_buf], gamma,
-                _dp.loss_scale(B, group, sharded))
-        _dp.all_reduce_losses_(loss, group, sharded)
-        ctx.saved = (grad_buf, action, (B, N))
-        ctx.mark_non_differentiable(td_err)
-        return loss, td_err
-
-    @classmethod
-    def _backward(cls, ctx, grad_loss):
-        grad_buf, action, shape = ctx.saved
-        grad_q = _new(shape, grad_buf)
-        cls.BWD([grad_loss.contiguous(), grad_buf, action], [grad_q])
-        return grad_q
-
-
-class QNStepTDFunction(_QNStepFunctionBase):
-    FWD = staticmethod(hpc_rl_utils.QNStepTdForward)
-    BWD = staticmethod(hpc_rl_utils.QNStepTdBackward)
-
-    @staticmethod
-    def forward(ctx, q, next_n_q, action, next_n_action, reward, done, weight, gamma, sharded, group):
-        return QNStepTDFunction._forward(ctx, q, next_n_q, action, next_n_action, reward, done, weight, gamma, sharded,
-                                         group)
-
-    @staticmethod
-    def backward(ctx, grad_loss, grad_td_err):
-        return (QNStepTDFunction._backward(ctx, grad_loss),) + (None,) * 9
-
-
-class QNStepTDRescaleFunction(_QNStepFunctionBase):
-    FWD = staticmethod(hpc_rl_utils.QNStepTdRescaleForward)
-    BWD = staticmethod(hpc_rl_utils.QNStepTdRescaleBackward)
-
-    @staticmethod
-    def forward(ctx, q, next_n_q, action, next_n_action, reward, done, weight, gamma, sharded, group):
-        return QNStepTDRescaleFunction._forward(ctx, q, next_n_q, action, next_n_action, reward, done, weight, gamma,
-                                                sharded, group)
-
-    @staticmethod
-    def backward(ctx, grad_loss, grad_td_err):
-        return (QNStepTDRescaleFunction._backward(ctx, grad_loss),) + (None,) * 9
-
-
-def _assert_cuda(*ts):
-    for t in ts:
-        if t is not None:
-            assert t.is_cuda
-
-
-class QNStepTD(torch.nn.Module):
+class QNStepTD(_ShardedLoss):
     """n-step TD error for q-learning: (mean(weight*(q[b,a]-target)^2), per-sample (q-target)^2)."""
+    _RESCALE = False
 
     def __init__(self, T, B, N, sharded: bool = False, group=None):
         super().__init__()
@@ -123,47 +58,17 @@ class QNStepTD(torch.nn.Module):
 
     def forward(self, q, next_n_q, action, next_n_action, reward, done, weight, gamma: float):
         _assert_cuda(q, next_n_q, action, next_n_action, reward, done, weight)
-        return QNStepTDFunction.apply(q, next_n_q, action, next_n_action, reward, done, weight, gamma, self.sharded,
-                                      self.group)
+        loss, td_err = hpc_rl_utils.q_nstep_td(q, next_n_q, action, next_n_action, reward, done, weight, gamma,
+                                               self._RESCALE, self._scale(q.shape[0]))
+        return self._reduce(loss), td_err
 
 
-class QNStepTDRescale(torch.nn.Module):
+class QNStepTDRescale(QNStepTD):
     """n-step TD error with value rescaling h / h^-1 (eps = 1e-2)."""
-
-    def __init__(self, T, B, N, sharded: bool = False, group=None):
-        super().__init__()
-        self.T, self.B, self.N, self.sharded, self.group = T, B, N, sharded, group
-
-    def forward(self, q, next_n_q, action, next_n_action, reward, done, weight, gamma: float):
-        _assert_cuda(q, next_n_q, action, next_n_action, reward, done, weight)
-        return QNStepTDRescaleFunction.apply(q, next_n_q, action, next_n_action, reward, done, weight, gamma,
-                                             self.sharded, self.group)
+    _RESCALE = True
 
 
-# ------------------------------------------------------------------------------------------------ dist (C51)
-class DistNStepTDFunction(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, dist, next_n_dist, action, next_n_action, reward, done, weight, gamma, v_min, v_max, sharded,
-                group):
-        B, N, n_atom = dist.shape
-        td_err, loss, buf = _new((B,), dist), _new((1,), dist), _new((B, n_atom), dist)
-        hpc_rl_utils.DistNStepTdForward([dist, next_n_dist, action, next_n_action, reward, done, weight],
-                                        [td_err, loss, buf], gamma, v_min, v_max, _dp.loss_scale(B, group, sharded))
-        _dp.all_reduce_losses_(loss, group, sharded)
-        ctx.saved = (buf, action, (B, N, n_atom))
-        ctx.mark_non_differentiable(td_err)
-        return loss, td_err
-
-    @staticmethod
-    def backward(ctx, grad_loss, grad_td_err):
-        buf, action, shape = ctx.saved
-        grad_dist = _new(shape, buf)
-        hpc_rl_utils.DistNStepTdBackward([grad_loss.contiguous(), buf, action], [grad_dist])
-        return (grad_dist,) + (None,) * 11
-
-
-class DistNStepTD(torch.nn.Module):
+class DistNStepTD(_ShardedLoss):
     """C51 distributional n-step TD error (categorical projection + cross entropy)."""
 
     def __init__(self, T, B, N, n_atom, sharded: bool = False, group=None):
@@ -175,35 +80,12 @@ class DistNStepTD(torch.nn.Module):
         _assert_cuda(dist, next_n_dist, action, next_n_action, reward, done, weight)
         # (the reference additionally asserts dist[b,a] > 0 with a host sync, rl_utils/td.py:101-103; a log of a
         #  non-positive probability shows up as nan/inf in the loss instead of stalling the stream here)
-        return DistNStepTDFunction.apply(dist, next_n_dist, action, next_n_action, reward, done, weight, gamma, v_min,
-                                         v_max, self.sharded, self.group)
+        loss, td_err = hpc_rl_utils.dist_nstep_td(dist, next_n_dist, action, next_n_action, reward, done, weight, gamma,
+                                                  v_min, v_max, self._scale(dist.shape[0]))
+        return self._reduce(loss), td_err
 
 
-# ------------------------------------------------------------------------------------------------ IQN
-class IQNNStepTDErrorFunction(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, q, next_n_q, action, next_n_action, reward, done, replay_quantiles, weight, value_gamma, gamma,
-                kappa, sharded, group):
-        tau, B, N = q.shape
-        loss, td_err, grad_buf = _new((1,), q), _new((B,), q), _new((B, tau), q)
-        hpc_rl_utils.IQNNStepTDErrorForward(
-            [q, next_n_q, action, next_n_action, reward, done, replay_quantiles, weight, value_gamma],
-            [loss, td_err, grad_buf], gamma, kappa, _dp.loss_scale(B, group, sharded))
-        _dp.all_reduce_losses_(loss, group, sharded)
-        ctx.saved = (grad_buf, action, (tau, B, N))
-        ctx.mark_non_differentiable(td_err)
-        return loss, td_err
-
-    @staticmethod
-    def backward(ctx, grad_loss, grad_td_err):
-        grad_buf, action, shape = ctx.saved
-        grad_q = _new(shape, grad_buf)
-        hpc_rl_utils.IQNNStepTDErrorBackward([grad_loss.contiguous(), grad_buf, action], [grad_q])
-        return (grad_q,) + (None,) * 12
-
-
-class IQNNStepTDError(torch.nn.Module):
+class IQNNStepTDError(_ShardedLoss):
     """IQN n-step TD error (quantile Huber loss over tau x tau' pairs)."""
 
     def __init__(self, tau, tauPrime, T, B, N, sharded: bool = False, group=None):
@@ -215,35 +97,12 @@ class IQNNStepTDError(torch.nn.Module):
                 kappa: float = 1.0, weight: Optional[torch.Tensor] = None,
                 value_gamma: Optional[torch.Tensor] = None):
         _assert_cuda(q, next_n_q, action, next_n_action, reward, done, replay_quantiles, weight, value_gamma)
-        return IQNNStepTDErrorFunction.apply(q, next_n_q, action, next_n_action, reward, done, replay_quantiles,
-                                             weight, value_gamma, gamma, kappa, self.sharded, self.group)
+        loss, td_err = hpc_rl_utils.iqn_nstep_td(q, next_n_q, action, next_n_action, reward, done, replay_quantiles,
+                                                 weight, value_gamma, gamma, kappa, self._scale(q.shape[1]))
+        return self._reduce(loss), td_err
 
 
-# ------------------------------------------------------------------------------------------------ QR-DQN
-class QRDQNNStepTDErrorFunction(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, q, next_n_q, action, next_n_action, reward, done, weight, value_gamma, gamma, tau_value, sharded,
-                group):
-        B, N, tau = q.shape
-        loss, td_err, grad_buf = _new((1,), q), _new((B,), q), _new((B, tau), q)
-        hpc_rl_utils.QRDQNNStepTDErrorForward(
-            [q, next_n_q, action, next_n_action, reward, done, weight, value_gamma], [loss, td_err, grad_buf], gamma,
-            tau_value, _dp.loss_scale(B, group, sharded))
-        _dp.all_reduce_losses_(loss, group, sharded)
-        ctx.saved = (grad_buf, action, (B, N, tau))
-        ctx.mark_non_differentiable(td_err)
-        return loss, td_err
-
-    @staticmethod
-    def backward(ctx, grad_loss, grad_td_err):
-        grad_buf, action, shape = ctx.saved
-        grad_q = _new(shape, grad_buf)
-        hpc_rl_utils.QRDQNNStepTDErrorBackward([grad_loss.contiguous(), grad_buf, action], [grad_q])
-        return (grad_q,) + (None,) * 11
-
-
-class QRDQNNStepTDError(torch.nn.Module):
+class QRDQNNStepTDError(_ShardedLoss):
     """QR-DQN n-step TD error.  Like the reference kernel (and its test, which passes ``tau`` = the integer count
     to the oracle) the quantile weight is |tau - 1[err <= 0]| with tau = the number of quantiles; pass
     ``tau_value`` to use something else (e.g. a true fraction)."""
@@ -256,5 +115,6 @@ class QRDQNNStepTDError(torch.nn.Module):
                 weight: Optional[torch.Tensor] = None, value_gamma: Optional[torch.Tensor] = None,
                 tau_value: Optional[float] = None):
         _assert_cuda(q, next_n_q, action, next_n_action, reward, done, weight, value_gamma)
-        return QRDQNNStepTDErrorFunction.apply(q, next_n_q, action, next_n_action, reward, done, weight, value_gamma,
-                                               gamma, tau_value, self.sharded, self.group)
+        loss, td_err = hpc_rl_utils.qrdqn_nstep_td(q, next_n_q, action, next_n_action, reward, done, weight, value_gamma,
+                                                   gamma, tau_value, self._scale(q.shape[0]))
+        return self._reduce(loss), td_err

@@ -6,6 +6,7 @@ parameters (``wx``, ``wh``, ``bias``, ``ln_gamma``, ``ln_beta``; layouts rnn.py:
 Differences: gradients flowing in through the returned final states are propagated (the reference
 zeroes them, lstm.cu:309-310); scratch lives in one workspace tensor allocated per call instead of ~20 module
 buffers (one of them mis-sized, rnn.py:130); the dropout mask is a stateless hash of (seed, layer, element).
+The autograd node is ``hpc_torch_utils_network.lstm`` (compiled torch::autograd::Function).
 """
 import math
 
@@ -13,38 +14,6 @@ import torch
 import torch.nn as nn
 
 import hpc_torch_utils_network
-
-
-class HPCLSTMFunction(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, x, wx, wh, bias, ln_gamma, ln_beta, h0, c0, dropout, seed):
-        S, B, I = x.shape
-        L, _, H = h0.shape
-        dev = x.device
-        y = torch.empty(S, B, H, dtype=torch.float32, device=dev)
-        hn = torch.empty(L, B, H, dtype=torch.float32, device=dev)
-        cn = torch.empty(L, B, H, dtype=torch.float32, device=dev)
-        ws = hpc_torch_utils_network.lstm_workspace(S, B, I, H, L, dropout, dev)
-        hpc_torch_utils_network.LstmForward([x, h0, c0, wx, wh, bias, ln_gamma, ln_beta], [y, hn, cn, ws], dropout, seed)
-        ctx.saved = (x, h0, c0, wx, wh, ln_gamma, ws)
-        ctx.cfg = (dropout, seed, bias.shape, ln_beta.shape)
-        return y, hn, cn
-
-    @staticmethod
-    def backward(ctx, dy, dh, dc):
-        x, h0, c0, wx, wh, ln_gamma, ws = ctx.saved
-        dropout, seed, bias_shape, beta_shape = ctx.cfg
-        new = lambda ref: torch.empty_like(ref)  # noqa: E731
-        dx = new(x) if ctx.needs_input_grad[0] else None     # x without grad: the layer-0 input-gradient GEMM is skipped
-        dh0, dc0, dwx, dwh = new(h0), new(c0), new(wx), new(wh)
-        dbias = torch.empty(bias_shape, dtype=torch.float32, device=x.device)
-        dgamma = new(ln_gamma)
-        dbeta = torch.empty(beta_shape, dtype=torch.float32, device=x.device)
-        cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
-        hpc_torch_utils_network.LstmBackward([cont(dy), cont(dh), cont(dc), x, h0, c0, wx, wh, ln_gamma, ws],
-                                             [dx, dh0, dc0, dwx, dwh, dbias, dgamma, dbeta], dropout, seed)
-        return dx, dwx, dwh, dbias, dgamma, dbeta, dh0, dc0, None, None
 
 
 class LSTM(nn.Module):
@@ -84,5 +53,6 @@ class LSTM(nn.Module):
         assert c0.is_cuda
         p = self.dropout if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
-        y, h, c = HPCLSTMFunction.apply(inputs, self.wx, self.wh, self.bias, self.ln_gamma, self.ln_beta, h0, c0, p, seed)
+        y, h, c = hpc_torch_utils_network.lstm(inputs, self.wx, self.wh, self.bias, self.ln_gamma, self.ln_beta, h0, c0,
+                                               p, seed)
         return y, [h, c]

@@ -3,28 +3,11 @@
 scatter_type)`` and ``forward(x, location)``.
 
 ``cover`` is deterministic here (the largest entity index at a cell wins, which is what the CPU oracle's
-sequential ``scatter_`` does); the reference kernel is a last-writer-wins race."""
+sequential ``scatter_`` does); the reference kernel is a last-writer-wins race.
+The autograd node is ``hpc_torch_utils_network.scatter_connection`` (compiled torch::autograd::Function)."""
 import torch
 
 import hpc_torch_utils_network
-
-
-class ScatterConnectionFunction(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, input, location, H, W, scatter_type):
-        B, M, N = input.shape
-        output = torch.empty(B, N, H, W, dtype=input.dtype, device=input.device)
-        hpc_torch_utils_network.ScatterConnectionForward([input, location], [output], scatter_type)
-        ctx.saved = (location, (B, M, N))
-        return output
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        location, shape = ctx.saved
-        grad_in = torch.empty(shape, dtype=grad_out.dtype, device=grad_out.device)
-        hpc_torch_utils_network.ScatterConnectionBackward([grad_out.contiguous(), location], [grad_in])
-        return grad_in, None, None, None, None
 
 
 class ScatterConnection(torch.nn.Module):
@@ -39,4 +22,4 @@ class ScatterConnection(torch.nn.Module):
     def forward(self, x: torch.Tensor, location: torch.Tensor) -> torch.Tensor:
         assert x.is_cuda
         assert location.is_cuda
-        return ScatterConnectionFunction.apply(x, location, self.H, self.W, self.scatter_type)
+        return hpc_torch_utils_network.scatter_connection(x, location, self.H, self.W, self.scatter_type)

@@ -36,6 +36,11 @@ extern "C" {
 int hpc_rll_abi_version(void);
 /* Human readable message for a status returned by any entry point (static storage). */
 const char* hpc_rll_status_string(int status);
+/* Stream helpers for host bindings that must not call the HIP runtime themselves (the torch extension is host-only
+ * C++): is_capturing returns 1 while `stream` records into a hipGraph, 0 if not, a negative code on error;
+ * synchronize blocks the host until the stream has drained (positive hipError_t on failure). */
+int hpc_rll_stream_is_capturing(void* stream);
+int hpc_rll_stream_synchronize(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GAE  -- replaces GaeForward (include/hpc/rll/cuda/rl_utils/entry.h:62-66, src/rl_utils/gae.cu:8-28,
@@ -204,6 +209,13 @@ int hpc_rll_pad_forward(const int64_t* table, float* new_x, int32_t* mask, int64
                         int value, void* stream);
 int hpc_rll_unpad_forward(const float* padded, const int64_t* table, float* flat, int64_t n, int64_t total,
                           int m0, int m1, int m2, void* stream);
+/* Packed (CSR-style) ragged input: lengths (n,) int64 on the device -> the (n,4) table the two kernels above take,
+ * row i = {base + stride * sum(lengths[:i]), 1, 1, lengths[i]} (pad: base = address of the flat buffer, stride = 4;
+ * unpad: base = 0, stride = 1).  A device-side exclusive scan: no host loop, no synchronisation.
+ * scratch: hpc_rll_packed_table_scratch_int64(n) int64. */
+int64_t hpc_rll_packed_table_scratch_int64(int64_t n);
+int hpc_rll_packed_table(const int64_t* lengths, int64_t n, int64_t base, int64_t stride, int64_t* table,
+                         int64_t* scratch, void* stream);
 /* Group-split policies over a list sorted by numel (host code; padding.cu:8-108).  sizes: n x dim int32.
  * Write <= `group` rows of `dim` ints to group_shapes and <= group+1 boundaries to positions; return the
  * number of groups (>= 1) or a negative HPC_RLL_E* code.  oracle = the O(group * n^2) DP minimising padded

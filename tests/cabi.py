@@ -1,10 +1,9 @@
-"""ctypes loader for the C-ABI HIP library (include/hpc_rll_hip.h).
+"""TEST-ONLY ctypes access to the raw C ABI of libhpc_rll_hip.so (include/hpc_rll_hip.h).
 
-There is deliberately NO fallback: if ``libhpc_rll_hip.so`` is missing or does not export a declared symbol,
-importing this module raises -- the product path never silently degrades to eager PyTorch.
-
-The ctypes prototypes are generated from the C header itself (the single source of truth for the ABI), so
-the Python binding cannot drift from ``include/hpc_rll_hip.h``.
+The product binds the C ABI from compiled C++ (di-hpc_amd/ext/*.cpp -> hpc_rl_utils.so, hpc_torch_utils_network.so,
+hpc_models.so); this module exists so that the tests can call individual entry points directly (expert launch
+configurations, argument-error statuses, symbol coverage).  The ctypes prototypes are generated from the C header
+itself, so they cannot drift from ``include/hpc_rll_hip.h``; a missing symbol raises at import.
 
 torch is imported first on purpose: torch's bundled ``libamdhip64.so`` has the same soname
 (``libamdhip64.so.7``) as the ROCm one the library was linked against, so once torch is loaded the
@@ -17,14 +16,14 @@ import re
 
 import torch  # noqa: F401  (must precede the dlopen below, see docstring)
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("HPC_RLL_LIB") or os.path.join(_HERE, "_lib", "libhpc_rll_hip.so")  # env: kernel experiments
-HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "hpc_rll_hip.h")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_ROOT, "di-hpc_amd", "hpc_rll", "_lib", "libhpc_rll_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "hpc_rll_hip.h")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build it with `python di-hpc_amd/build.py` (hipcc --offload-arch=gfx950). "
-        "hpc_rll has no CPU/eager fallback.")
+        "There is no CPU/eager fallback.")
 
 lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 
@@ -61,7 +60,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     _fn.restype = _res
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 if lib.hpc_rll_abi_version() != ABI_VERSION:
     raise ImportError(f"libhpc_rll_hip.so ABI {lib.hpc_rll_abi_version()} != expected {ABI_VERSION}; rebuild")
 
@@ -85,23 +84,6 @@ def stream_ptr(device=None) -> int:
 
 def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
-
-
-def require(t, name, dtype=torch.float32, shape=None, device=None):
-    """Input validation the reference omits (status.h:15-17 defines CHECK_* but never uses them)."""
-    if not isinstance(t, torch.Tensor):
-        raise RuntimeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
-    if not t.is_cuda:
-        raise RuntimeError(f"{name}: must live on a GPU (hpc_rll has no CPU path)")
-    if device is not None and t.device != device:
-        raise RuntimeError(f"{name}: on {t.device}, expected {device}")
-    if t.dtype != dtype:
-        raise RuntimeError(f"{name}: dtype {t.dtype}, expected {dtype}")
-    if not t.is_contiguous():
-        raise RuntimeError(f"{name}: must be contiguous")
-    if shape is not None and tuple(t.shape) != tuple(shape):
-        raise RuntimeError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
-    return t
 
 
 def call(name, dev, *args):

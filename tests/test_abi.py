@@ -21,21 +21,21 @@ def test_header_declares_something():
 
 
 def test_library_exports_every_declared_symbol():
-    from hpc_rll import _native
+    import cabi as _native
     lib = ctypes.CDLL(_native.LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"libhpc_rll_hip.so lacks {missing}"
 
 
 def test_python_signature_table_matches_header():
-    from hpc_rll import _native
+    import cabi as _native
     declared = set(declared_symbols())
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
     assert len(declared) >= 30
 
 
 def test_abi_version_and_status_strings():
-    from hpc_rll import _native
+    import cabi as _native
     assert _native.lib.hpc_rll_abi_version() == _native.ABI_VERSION
     assert _native.lib.hpc_rll_status_string(0) == b"ok"
     assert b"invalid" in _native.lib.hpc_rll_status_string(-1)
@@ -65,7 +65,7 @@ def test_cpu_tensor_is_rejected_loudly():
 
 def test_argument_errors_are_status_codes_not_crashes():
     """Invalid arguments are rejected with a negative status BEFORE any HIP call is made (so this runs without a GPU)."""
-    from hpc_rll import _native
+    import cabi as _native
     L = _native.lib
     assert L.hpc_rll_gae_forward(None, None, None, None, 4, 4, 0.99, None) == -1            # null pointers
     assert L.hpc_rll_gae_forward(None, None, None, None, -1, 4, 0.99, None) == -1           # negative size
@@ -85,7 +85,7 @@ def test_tuning_knobs_documented_and_guarded():
     """hpc_rll_tune_set is host-only code: every key the header documents accepts its shipped default and rejects an
     out-of-range value with a status (no GPU needed); an undocumented key is an argument error."""
     import re
-    from hpc_rll import _native as N
+    import cabi as N
     hdr = open(N.HEADER_PATH).read()
     doc = hdr[hdr.index("Tuning knobs"):hdr.index("int hpc_rll_tune_set")]
     keys = sorted({int(k) for k in re.findall(r"key (\d+)", doc)})
@@ -117,4 +117,4 @@ def test_c_program_links_and_runs(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and "abi 1 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    assert r.returncode == 0 and "abi 2 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -65,7 +65,8 @@ def test_native_library_is_loaded():
     import hpc_rl_utils
     maps = open("/proc/self/maps").read()
     assert "libhpc_rll_hip.so" in maps
-    assert hpc_rl_utils.N.lib.hpc_rll_abi_version() == 1
+    assert hpc_rl_utils.abi_version() == 2
+    assert "hpc_rl_utils.so" in maps            # the compiled torch extension, not a python shim
 
 
 def test_golden_fixtures(dev, golden):
@@ -114,6 +115,7 @@ def test_fp64_oracle_small(dev):
 
 
 def _ex_call(dev, v, r, ga, gamma, lam, vec, lc, nw, flags=-1):
+    import cabi
     import hpc_rl_utils as U
     T, B = r.shape
     tv, tr, tg = (torch.from_numpy(x).to(dev) for x in (v, r, ga))
@@ -121,10 +123,10 @@ def _ex_call(dev, v, r, ga, gamma, lam, vec, lc, nw, flags=-1):
     gv = torch.full((T + 1, B), float("nan"), device=dev)
     gr = torch.full((T, B), float("nan"), device=dev)
     coef = U.gae_coef(T, gamma, lam, dev)
-    s = U.N.stream_ptr(dev)
-    st1 = U.N.lib.hpc_rll_gae_forward_ex(tv.data_ptr(), tr.data_ptr(), adv.data_ptr(), coef.data_ptr(), T, B, gamma,
+    s = cabi.stream_ptr(dev)
+    st1 = cabi.lib.hpc_rll_gae_forward_ex(tv.data_ptr(), tr.data_ptr(), adv.data_ptr(), coef.data_ptr(), T, B, gamma,
                                          vec, lc, nw, flags, s)
-    st2 = U.N.lib.hpc_rll_gae_backward_ex(tg.data_ptr(), gv.data_ptr(), gr.data_ptr(), coef.data_ptr(), T, B, gamma,
+    st2 = cabi.lib.hpc_rll_gae_backward_ex(tg.data_ptr(), gv.data_ptr(), gr.data_ptr(), coef.data_ptr(), T, B, gamma,
                                           vec, lc, nw, flags, s)
     torch.cuda.synchronize()
     return st1, st2, adv.cpu().numpy(), gv.cpu().numpy(), gr.cpu().numpy()

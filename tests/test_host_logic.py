@@ -71,14 +71,15 @@ def test_large_list_is_fast():
 
 
 def test_pad_and_unpad_host_tables():
-    """The (pointer, shape) tables the pad / unpad kernels consume are built with C-level iteration + numpy
-    (hpc_rl_utils._pad_table / _unpad_table); pure host logic, checked here against the obvious per-tensor loops."""
+    """The (pointer, shape) tables the pad / unpad kernels consume are built by C++ loops in the extension
+    (hpc_rl_utils._pad_table / _unpad_table expose them); pure host logic, checked here against the obvious
+    per-tensor loops."""
     import hpc_rl_utils as U
     rng = np.random.default_rng(0)
     for rank in (1, 2, 3):
         shapes = [tuple(int(v) for v in rng.integers(1, 6, rank)) for _ in range(17)]
         xs = [torch.zeros(*s) for s in shapes]
-        table, sh = U._pad_table(xs, rank)
+        table, sh = (t.numpy() for t in U._pad_table(xs, rank))
         assert table.shape == (17, 4) and sh.shape == (17, rank)
         for i, (t, s_) in enumerate(zip(xs, shapes)):
             assert table[i, 0] == t.data_ptr()
@@ -86,7 +87,7 @@ def test_pad_and_unpad_host_tables():
             assert tuple(sh[i]) == s_
         flat_shapes = [d for s_ in shapes for d in s_]
         lim = tuple(int(v) for v in np.max(np.array(shapes), axis=0))
-        tab, numel, offs, sh2 = U._unpad_table(flat_shapes, lim, rank)
+        tab, numel, offs, sh2 = (t.numpy() for t in U._unpad_table(flat_shapes, lim, rank))
         want = [int(np.prod(s_)) for s_ in shapes]
         assert numel.tolist() == want and offs.tolist() == [0] + list(np.cumsum(want))
         assert tab[:, 0].tolist() == offs[:-1].tolist()
@@ -95,5 +96,5 @@ def test_pad_and_unpad_host_tables():
         bad[0] = lim[0] + 1                                      # does not fit the padded tensor
         with pytest.raises(RuntimeError):
             U._unpad_table(bad, lim, rank)
-    tab, numel, offs, _ = U._unpad_table([], (4,), 1)            # empty list
+    tab, numel, offs, _ = (t.numpy() for t in U._unpad_table([], (4,), 1))   # empty list
     assert tab.shape == (0, 4) and offs.tolist() == [0]

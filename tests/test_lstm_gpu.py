@@ -197,13 +197,13 @@ def test_lstm_dropout(B):
     torch.manual_seed(5)
     y2, _ = m(x, None)
     assert torch.equal(y1, y2)                         # same seed -> same mask
-    import hpc_rll._native as N
+    import hpc_torch_utils_network as N
     try:                                               # every path draws the same stateless-hash mask
-        N.check(N.lib.hpc_rll_tune_set(3, 0), "tune_set")
+        N.tune_set(3, 0)
         torch.manual_seed(5)
         y3, _ = m(x, None)
     finally:
-        N.check(N.lib.hpc_rll_tune_set(3, 1), "tune_set")
+        N.tune_set(3, 1)
     assert rel_err(y3.detach().cpu().numpy(), y1.detach().cpu().numpy()) < 1e-5
     assert not torch.equal(y1, y0) and torch.isfinite(y1).all()
     def grads():
@@ -218,10 +218,10 @@ def test_lstm_dropout(B):
     g1 = grads()
     assert np.isfinite(g1[0]).all() and np.abs(g1[0]).sum() > 0
     try:                                               # backward applies the same masks on every path
-        N.check(N.lib.hpc_rll_tune_set(3, 0), "tune_set")
+        N.tune_set(3, 0)
         g0 = grads()
     finally:
-        N.check(N.lib.hpc_rll_tune_set(3, 1), "tune_set")
+        N.tune_set(3, 1)
     for a, b in zip(g0, g1):
         assert rel_err(a, b) < 2e-4
 
@@ -234,7 +234,7 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
     path (GEMM + cell kernel per step).  Same math, different summation order in the recurrent products, and fp32
     rounding is amplified along the S*L chain of LayerNorms, so the two paths are compared through the fp64 oracle:
     the persistent path must be as close to it as the step path is (factor 2), or within the base tolerance."""
-    import hpc_rll._native as N
+    import hpc_torch_utils_network as N
     from hpc_rll.torch_utils.network.rnn import LSTM
     torch.manual_seed(S * 131 + H)
     m = LSTM(S, B, I, H, L).to(DEV)
@@ -256,16 +256,16 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
                                                             m.wh.grad, m.bias.grad, m.ln_gamma.grad, m.ln_beta.grad)]
 
     try:
-        N.check(N.lib.hpc_rll_tune_set(3, 0), "tune_set")
+        N.tune_set(3, 0)
         step = run()
     finally:
-        N.check(N.lib.hpc_rll_tune_set(3, 1), "tune_set")
+        N.tune_set(3, 1)
     pers = run()                                       # layer wavefront where eligible, else per-layer kernels
     try:
-        N.check(N.lib.hpc_rll_tune_set(8, 0), "tune_set")
+        N.tune_set(8, 0)
         pers_layer = run()                             # per-layer persistent kernels
     finally:
-        N.check(N.lib.hpc_rll_tune_set(8, 1), "tune_set")
+        N.tune_set(8, 1)
     dims = [I] + [H] * L
     offs = np.cumsum([0] + [d * 4 * H for d in dims])
     leaf = lambda t: t.detach().double().cpu().requires_grad_(True)  # noqa: E731
