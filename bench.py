@@ -8,8 +8,15 @@ followed by ``adv.backward(grad_adv)`` through the drop-in ``hpc_rll.rl_utils.ga
 kernels behind the C ABI).  Inputs are resident in HBM before the timed region.  The batch axis shards
 across ranks with NO data-path collective (every trajectory is independent), so per-GPU
 work is fixed as N grows: weak scaling; ``value`` = (N * T * B) * K / max-over-ranks wall time.
-``--scaling strong`` splits a fixed global batch instead (SURVEY.md 8d asks for both readings) and ``--graph``
-replays the step from a captured hipGraph -- the launch-latency regime strong scaling ends up in.
+``--scaling strong`` makes the headline ``value`` the strong reading instead (``--B`` is then the GLOBAL batch, split
+over the ranks) and ``--graph`` replays the step from a captured hipGraph -- the launch-latency regime strong scaling
+ends up in.
+
+Whatever the headline is, the same JSON line carries ``scaling_detail`` with BOTH readings BASELINE.md section 4 /
+SURVEY.md 8d ask for, measured in this run after the headline region: weak (B per GPU) and strong (global B = 65536
+split over the N ranks), each eager and as hipGraph replay, with per-rank step times and the RCCL world size seen.
+With one rank it also times the per-rank shapes an N = 2, 4, 8 strong-scaling run would hold (B = 32768, 16384, 8192),
+so the launch-latency regime is visible without a multi-GPU box.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline     -- dominant kernel's algorithmic bytes per launch / its average launch duration measured
@@ -78,6 +85,7 @@ def main():
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): B per GPU fixed; strong: --B is the GLOBAL batch, split over the ranks")
+    ap.add_argument("--no-scaling-detail", action="store_true", help="skip the extra weak/strong legs (profiler runs)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one fwd+bwd step in a hipGraph and replay it (the latency regime: small B per GPU)")
     args = ap.parse_args()
@@ -101,27 +109,33 @@ def main():
     from hpc_rll.rl_utils.gae import GAE
 
     T, B, gamma, lam = args.T, args.B, 0.99, 0.97
+    global_B = B if args.scaling == "strong" else B * world
     if args.scaling == "strong":
         assert B % world == 0, "strong scaling: the global batch must divide by the number of ranks"
         B //= world
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    value = torch.randn(T + 1, B, device=dev, generator=g).requires_grad_(True)
-    reward = torch.randn(T, B, device=dev, generator=g).requires_grad_(True)
-    grad_adv = torch.randn(T, B, device=dev, generator=g)
-    gae = GAE(T, B).to(dev)
-
-    def step():
-        value.grad = None
-        reward.grad = None
-        adv = gae(value, reward, gamma, lam)
-        adv.backward(grad_adv)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.graph:   # same kernels, same order; only the host-side launch path changes (one hipGraphLaunch per step)
+    def make_step(Bk, graph):
+        """(step callable, tensors) for one fwd+bwd pass at batch Bk on this rank; graph=True replays a hipGraph."""
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        value = torch.randn(T + 1, Bk, device=dev, generator=g).requires_grad_(True)
+        reward = torch.randn(T, Bk, device=dev, generator=g).requires_grad_(True)
+        grad_adv = torch.randn(T, Bk, device=dev, generator=g)
+        gae = GAE(T, Bk).to(dev)
+
+        def step():
+            value.grad = None
+            reward.grad = None
+            adv = gae(value, reward, gamma, lam)
+            adv.backward(grad_adv)
+
+        if not graph:
+            return step, (value, reward, grad_adv)
+        # same kernels, same order; only the host-side launch path changes (one hipGraphLaunch per step)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -130,23 +144,58 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         value.grad = None
         reward.grad = None
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
             gae(value, reward, gamma, lam).backward(grad_adv)
-        step = graph.replay  # noqa: F811
+        return cg.replay, (value, reward, grad_adv, cg)
 
-    for _ in range(args.warmup):
+    def timed(step, steps, warmup):
+        """W untimed steps, barrier + synchronize, EXACTLY `steps` timed steps, barrier + synchronize.
+        Returns (max over ranks, per-rank list) of the elapsed seconds."""
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        mine = time.perf_counter() - t0
+        if dist is None:
+            return mine, [mine]
+        t = torch.tensor([mine], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [x.item() for x in allt]
+        return max(per_rank), per_rank
+
+    step, keep = make_step(B, args.graph)
+    value, reward, grad_adv = keep[:3]
+    # device clock / allocator pre-roll: a freshly leased GPU idles at its low power state and the first ~10 ms of
+    # work run at ramping clocks.  Untimed, not part of W or K (the W warmup steps and the K timed steps follow).
+    for _ in range(30):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed, per_rank_s = timed(step, args.steps, args.warmup)
+
+    # ---- both scaling readings in the same line (VERDICT r01 item 2).  Bounded: ~200 steps per leg.
+    def leg(Bk, graph, steps=200, warmup=20):
+        st, keep_alive = make_step(Bk, graph)
+        mx, per = timed(st, steps, warmup)
+        del keep_alive
+        return {"B_per_gpu": Bk, "global_B": Bk * world, "launch": "hipGraph replay" if graph else "eager",
+                "ms_per_step": mx / steps * 1e3, "value": T * Bk * world * steps / mx,
+                "per_rank_ms_per_step": [p / steps * 1e3 for p in per]}
+
+    detail = None
+    if not args.no_scaling_detail:
+        GB = 65536
+        detail = {"world_size": world, "backend": (dist.get_backend() if dist is not None else None),
+                  "weak": {"eager": leg(B_DEFAULT, False), "graph": leg(B_DEFAULT, True)},
+                  "strong": None, "strong_per_rank_probe": None}
+        if GB % world == 0:
+            detail["strong"] = {"eager": leg(GB // world, False), "graph": leg(GB // world, True)}
+        if world == 1:   # what one rank of an N-GPU strong-scaling run of global B = 65536 holds, timed on this GPU
+            detail["strong_per_rank_probe"] = {str(n): {"eager": leg(GB // n, False), "graph": leg(GB // n, True)}
+                                               for n in (2, 4, 8)}
 
     # ---- per-kernel durations: HIP events on the launch stream (torch's current stream) around EVERY launch of
     # a second, instrumented pass over the same K steps in the same alternating fwd/bwd order as the timed
@@ -197,7 +246,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"GAE fwd+bwd, T={T}, B={B} per GPU, fp32 (BASELINE.json configs[1])",
-                       "T": T, "B_per_gpu": B, "global_B": B * world,
+                       "T": T, "B_per_gpu": B, "global_B": global_B,
                        "parallelism": f"batch-sharded x{world}, no data-path collective",
                        "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_launch / t_dom / 1e9, "peak": HBM_PEAK_GBS,
@@ -205,6 +254,8 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "fwd_us": t_fwd * 1e6, "bwd_us": t_bwd * 1e6,
                          "fwd_bwd_frac": (2 * bytes_launch) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS},
+            "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per_rank_s],
+            "scaling_detail": detail,
             "cpu_baseline": None if (args.skip_cpu_baseline or world > 1) else cpu_baseline(T, B, gamma, lam),
         }
         print(json.dumps(out), flush=True)

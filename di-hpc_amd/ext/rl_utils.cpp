@@ -254,10 +254,7 @@ struct VtraceFn : public ag::Function<VtraceFn> {
         vtrace_forward_launch(d, target, behaviour, action, value, reward, weight, losses, ws, gamma, lambda, rho_clip,
                               c_clip, rho_pg_clip, scale);
         ctx->save_for_backward({target, action, ws});
-        // 4th output: the packed (3,) buffer the three losses are views of, non-differentiable -- a data-parallel caller
-        // sums all three with ONE in-place all-reduce on it (hpc_rll.dist.all_reduce_losses_)
-        ctx->mark_non_differentiable({losses});
-        return {losses.narrow(0, 0, 1), losses.narrow(0, 1, 1), losses.narrow(0, 2, 1), losses};
+        return {losses.narrow(0, 0, 1), losses.narrow(0, 1, 1), losses.narrow(0, 2, 1)};
     }
     static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {
         ag::tensor_list out(12);
@@ -388,8 +385,8 @@ struct PpoFn : public ag::Function<PpoFn> {
                            scale);
         ctx->save_for_backward({ln, action, ws});
         Tensor info = out5.narrow(0, 3, 2);
-        ctx->mark_non_differentiable({info, out5});   // 5th output: the packed buffer, for ONE in-place all-reduce
-        return {out5.narrow(0, 0, 1), out5.narrow(0, 1, 1), out5.narrow(0, 2, 1), info, out5};
+        ctx->mark_non_differentiable({info});
+        return {out5.narrow(0, 0, 1), out5.narrow(0, 1, 1), out5.narrow(0, 2, 1), info};
     }
     static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {
         ag::tensor_list out(12);

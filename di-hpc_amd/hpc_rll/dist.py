@@ -43,6 +43,44 @@ def all_reduce_losses_(losses: torch.Tensor, group=None, sharded: bool = False, 
     return losses
 
 
+class _AllReduceSum(torch.autograd.Function):
+    """Differentiable sum over the ranks of a few loss scalars: forward packs them into ONE buffer and all-reduces it,
+    backward is the identity (d global / d local contribution = 1; every rank backpropagates its own shard)."""
+
+    @staticmethod
+    def forward(ctx, group, mean_slots, *losses):
+        ctx.sizes = [t.numel() for t in losses]
+        packed = torch.cat([t.reshape(-1) for t in losses])
+        all_reduce_losses_(packed, group, True, mean_slots)
+        return tuple(p.view_as(t) for p, t in zip(torch.split(packed, ctx.sizes), losses))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return (None, None) + grads
+
+
+def all_reduce_sum(losses, group=None, mean_slots=()):
+    """Sum the per-rank contributions of several loss tensors over the ranks with ONE all-reduce, keeping autograd
+    intact (used by VTrace / PPO, whose three / five scalars are separate autograd outputs).  ``mean_slots`` index the
+    flattened concatenation of ``losses``.  Returns new tensors; identity for a single rank."""
+    if world_size(group) == 1:
+        return tuple(losses)
+    return _AllReduceSum.apply(group, tuple(mean_slots), *losses)
+
+
+def all_reduce_max_int(value: int, group=None, device=None) -> int:
+    """max over the ranks of a python int (a globally consistent pad width / max shape for the
+    batch-sharded Pad ops).  One all-reduce(MAX) of one int64; identity for a single rank."""
+    import torch.distributed as dist
+    if world_size(group) == 1:
+        return int(value)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
 def shard_batch(t: Optional[torch.Tensor], dim: int, rank: int, world: int) -> Optional[torch.Tensor]:
     """Contiguous shard ``rank`` of ``world`` along the batch axis ``dim`` (None passes through)."""
     if t is None:

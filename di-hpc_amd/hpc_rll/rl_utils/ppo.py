@@ -34,10 +34,11 @@ class PPO(torch.nn.Module):
         assert dual_clip is None or dual_clip > 1.0, \
             "dual_clip value must be greater than 1.0, but get value: {}".format(dual_clip)
         scale = _dp.loss_scale(adv.numel(), self.group, True) if self.sharded else None
-        policy_loss, value_loss, entropy_loss, info, packed = hpc_rl_utils.ppo(
+        policy_loss, value_loss, entropy_loss, info = hpc_rl_utils.ppo(
             logits_new, logits_old, action, value_new, value_old, adv, return_, weight, clip_ratio, use_value_clip,
             0.0 if dual_clip is None else dual_clip, scale)
-        if self.sharded:
-            _dp.all_reduce_losses_(packed, self.group, True, mean_slots=(3, 4))   # the five scalars in ONE all-reduce
+        if self.sharded:   # the five scalars in ONE all-reduce; the two monitors are per-rank means -> averaged
+            policy_loss, value_loss, entropy_loss, info = _dp.all_reduce_sum(
+                (policy_loss, value_loss, entropy_loss, info), self.group, mean_slots=(3, 4))
         approx_kl, clipfrac = info.tolist()  # one host sync for both monitors (the reference does two .item())
         return hpc_ppo_loss(policy_loss, value_loss, entropy_loss), hpc_ppo_info(approx_kl, clipfrac)

@@ -33,8 +33,8 @@ class VTrace(torch.nn.Module):
         if weight is not None:
             assert weight.is_cuda
         scale = _dp.loss_scale(reward.numel(), self.group, True) if self.sharded else None
-        pg, v, e, packed = hpc_rl_utils.vtrace(target_output, behaviour_output, action, value, reward, weight, gamma,
-                                               lambda_, rho_clip_ratio, c_clip_ratio, rho_pg_clip_ratio, scale)
+        pg, v, e = hpc_rl_utils.vtrace(target_output, behaviour_output, action, value, reward, weight, gamma, lambda_,
+                                       rho_clip_ratio, c_clip_ratio, rho_pg_clip_ratio, scale)
         if self.sharded:
-            _dp.all_reduce_losses_(packed, self.group, True)     # pg, v, e are views of `packed`: ONE all-reduce
+            pg, v, e = _dp.all_reduce_sum((pg, v, e), self.group)     # the three scalars in ONE all-reduce
         return hpc_vtrace_loss(pg, v, e)

@@ -374,7 +374,7 @@ def scatter_connection(x: torch.Tensor, location: torch.Tensor, H: int, W: int, 
     (CPU ``scatter_`` is sequential); 'add': sum."""
     B, M, N = x.shape
     cell = location[..., 0] * W + location[..., 1]                  # (B,M)
-    out = torch.zeros(B, H * W, N, dtype=x.dtype)
+    out = torch.zeros(B, H * W, N, dtype=x.dtype, device=x.device)
     if scatter_type == "add":
         out = out.scatter_add(1, cell.unsqueeze(-1).expand(B, M, N), x)
     elif scatter_type == "cover":

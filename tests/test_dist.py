@@ -29,6 +29,41 @@ def _init(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
+def _run_guarded(rank, world, port, q, name, *a):
+    """Spawn target (top level: picklable).  Runs the worker `name`; an exception is put on the queue so that the
+    parent fails in seconds instead of at its timeout."""
+    try:
+        globals()[name](rank, world, port, q, *a)
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put(("error", rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+        raise
+
+
+def _collect(q, world, timeout):
+    res = []
+    for _ in range(world):
+        item = q.get(timeout=timeout)
+        assert item[0] != "error", f"worker {item[1]} failed:\n{item[2]}"
+        res.append(item)
+    return sorted(res, key=lambda t: t[0])
+
+
+def _spawn(target, world, timeout, *args):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_run_guarded, args=(r, world, port, q, target.__name__) + args) for r in range(world)]
+    [p.start() for p in ps]
+    try:
+        return _collect(q, world, timeout)
+    finally:
+        for p in ps:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+
+
 def _data(seed, T, B, N):
     rng = np.random.default_rng(seed)
     f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
@@ -72,19 +107,22 @@ def _cpu_worker(rank, world, port, q):
     assert all(torch.equal(p.grad, torch.full(p.shape, 3.0 * (i + 1))) for i, p in enumerate(ps[:3])) and ps[3].grad is None
     D.all_reduce_grads_(ps, None, average=True)
     assert all(torch.equal(p.grad, torch.full(p.shape, 3.0 * (i + 1))) for i, p in enumerate(ps[:3]))
+    # differentiable packed all-reduce (what VTrace / PPO use when sharded): sum, identity backward
+    a = torch.tensor([float(rank + 1)], requires_grad=True)
+    b = torch.tensor([10.0 * (rank + 1), 7.0], requires_grad=True)
+    ra, rb = D.all_reduce_sum((a, b), None, mean_slots=(2,))
+    (2 * ra.sum() + 3 * rb.sum()).backward()
+    assert ra.item() == 3.0 and rb.tolist() == [30.0, 7.0] and a.grad.item() == 2.0 and b.grad.tolist() == [3.0, 3.0]
+    assert D.all_reduce_max_int(5 + 3 * rank) == 8
     q.put((rank, loss.item(), v.grad.numpy(), three.numpy(), info.numpy()))
     dist.destroy_process_group()
 
 
+
 def test_cpu_gloo_two_ranks_match_single_process():
     from oracle import ref_torch as R
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    ps = [ctx.Process(target=_cpu_worker, args=(r, world, port, q)) for r in range(world)]
-    [p.start() for p in ps]
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-    [p.join(60) for p in ps]
+    world = 2
+    res = _spawn(_cpu_worker, world, 120)
     T, B, N = 12, 10, 5
     d = {k: torch.from_numpy(v) for k, v in _data(3, T, B, N).items()}
     v = d["value"].double().requires_grad_(True)
@@ -97,6 +135,84 @@ def test_cpu_gloo_two_ranks_match_single_process():
         assert np.allclose(gshard, v.grad.numpy()[:, rank * k:(rank + 1) * k], atol=1e-14)
         assert np.allclose(three, [x.item() for x in ls], atol=1e-12)
         assert np.allclose(info, [2.0, 4.0, 6.0, 0.5, 1.0])
+
+
+# ------------------------------------------------------------------ configs[4]: entity-sharded Scatter + Pad1D/Unpad
+def _c5_data(seed=9):
+    """n ragged 1-D entity feature lists and a (B,M,N) entity batch with (y,x) cells -- BASELINE.json configs[4] in small."""
+    rng = np.random.default_rng(seed)
+    n, B, M, N, H, W = 24, 8, 6, 4, 5, 7
+    lens = rng.integers(1, 12, n)
+    ents = [rng.standard_normal(int(k)).astype(np.float32) for k in lens]
+    x = rng.standard_normal((B, M, N)).astype(np.float32)
+    loc = np.stack([rng.integers(0, H, (B, M)), rng.integers(0, W, (B, M))], -1).astype(np.int64)
+    wmap = rng.standard_normal((B, N, H, W)).astype(np.float32)
+    wrow = rng.standard_normal(16).astype(np.float32)              # per-column weights of the padded matrix
+    return ents, x, loc, wmap, wrow, (H, W)
+
+
+def _c5_loss(pad, unpad, scatter, ents, x, loc, wmap, wrow, H, W, width, n_global, b_global, dev="cpu"):
+    """The scalar a rank contributes: weighted sums over its shard, already scaled by 1/(GLOBAL counts).
+    pad(list, value) -> (new_x, mask, shapes); the padded width is forced to the global `width`."""
+    new_x, mask, shapes = pad(ents)
+    k = new_x.shape[1]
+    assert k <= width
+    wr = torch.from_numpy(wrow).to(dev)[:k]
+    pad_term = (new_x * mask.to(new_x.dtype) * wr).sum() / n_global
+    back = unpad(new_x, shapes)                                   # round trip: bit exact
+    assert all(torch.equal(a, b) for a, b in zip(back, ents))
+    out = scatter(x, loc)
+    sc_term = (out * wmap).sum() / b_global
+    return (pad_term + sc_term).reshape(1)
+
+
+def _cpu_c5_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+    from hpc_rll import dist as D
+    from oracle import ref_torch as R
+    _init(rank, world, port)
+    ents, x, loc, wmap, wrow, (H, W) = _c5_data()
+    n, B = len(ents), x.shape[0]
+    lo, hi = rank * n // world, (rank + 1) * n // world            # shard by entity index
+    mine = [torch.from_numpy(e) for e in ents[lo:hi]]
+    width = D.all_reduce_max_int(max(t.numel() for t in mine))     # globally consistent pad width
+    xs = D.shard_batch(torch.from_numpy(x), 0, rank, world).requires_grad_(True)
+    ls = D.shard_batch(torch.from_numpy(loc), 0, rank, world)
+    ws = D.shard_batch(torch.from_numpy(wmap), 0, rank, world)
+    loss = _c5_loss(lambda l: R.pad(l, 0), R.unpad, lambda a, b: R.scatter_connection(a, b, H, W, "add"), mine, xs, ls,
+                    ws, wrow, H, W, width, n, B)
+    loss.backward()
+    total = D.all_reduce_losses_(loss.detach().clone(), None, sharded=True)
+    q.put((rank, total.item(), width, xs.grad.numpy()))
+    dist.destroy_process_group()
+
+
+
+def _c5_single(pad, unpad, scatter, dev="cpu"):
+    ents, x, loc, wmap, wrow, (H, W) = _c5_data()
+    te = [torch.from_numpy(e).to(dev) for e in ents]
+    tx = torch.from_numpy(x).to(dev).requires_grad_(True)
+    loss = _c5_loss(pad, unpad, scatter, te, tx, torch.from_numpy(loc).to(dev), torch.from_numpy(wmap).to(dev), wrow, H, W,
+                    max(len(e) for e in ents), len(ents), x.shape[0], dev)
+    loss.backward()
+    return loss.item(), max(len(e) for e in ents), tx.grad.cpu().numpy()
+
+
+def test_cpu_gloo_configs4_entity_sharded_scatter_pad():
+    """BASELINE.json configs[4] data-parallel leg on the CPU tier: Pad1D/Unpad + ScatterConnection sharded by entity
+    index, scalar loss all-reduced (gloo, world 2) == the single-process loss; the pad width is agreed with one int
+    all-reduce(max); the gradient of a shard equals the corresponding rows of the full gradient."""
+    from oracle import ref_torch as R
+    world = 2
+    res = _spawn(_cpu_c5_worker, world, 120)
+    full, width, gx = _c5_single(lambda l: R.pad(l, 0), R.unpad, lambda a, b: R.scatter_connection(a, b, 5, 7, "add"))
+    k = gx.shape[0] // world
+    for rank, total, w, g in res:
+        assert abs(total - full) < 1e-5 * max(1.0, abs(full))
+        assert w == width
+        assert np.allclose(g, gx[rank * k:(rank + 1) * k], atol=1e-7)
 
 
 def test_shard_and_scale_helpers():
@@ -142,8 +258,27 @@ def _gpu_worker(rank, world, port, q):
     y.sum().backward()
     D.all_reduce_grads_(list(m.parameters()), None)
     lstm = [p.grad.cpu().numpy() for p in m.parameters()] + [xs.grad.cpu().numpy()]
-    q.put((rank, l1.item(), [x.item() for x in l3], v.grad.cpu().numpy(), to.grad.cpu().numpy(), adv.cpu().numpy(), lstm))
+    # f-2: a batch-sharded per-sample output replicated on every rank, on DEVICE tensors
+    adv_full = D.all_gather_batch(adv, 1)
+    # configs[4]: entity-sharded Pad1D/Unpad + ScatterConnection through the HIP kernels, scalar loss all-reduced
+    from hpc_rll.rl_utils.padding import Padding1D, UnPadding1D
+    from hpc_rll.torch_utils.network.scatter_connection import ScatterConnection
+    ents, ex, loc, wmap, wrow, (H, W) = _c5_data()
+    n, EB = len(ents), ex.shape[0]
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    mine = [torch.from_numpy(e).to(dev) for e in ents[lo:hi]]
+    width = D.all_reduce_max_int(max(t.numel() for t in mine), device=dev)
+    exs = D.shard_batch(torch.from_numpy(ex), 0, rank, world).to(dev).requires_grad_(True)
+    sc = ScatterConnection(EB // world, ex.shape[1], ex.shape[2], H, W, "add")
+    c5 = _c5_loss(lambda l: Padding1D(l, value=0), UnPadding1D, sc, mine, exs,
+                  D.shard_batch(torch.from_numpy(loc), 0, rank, world).to(dev),
+                  D.shard_batch(torch.from_numpy(wmap), 0, rank, world).to(dev), wrow, H, W, width, n, EB, dev)
+    c5.backward()
+    c5_total = D.all_reduce_losses_(c5.detach().clone(), None, sharded=True)
+    q.put((rank, l1.item(), [x.item() for x in l3], v.grad.cpu().numpy(), to.grad.cpu().numpy(), adv.cpu().numpy(), lstm,
+           adv_full.cpu().numpy(), (c5_total.item(), width, exs.grad.cpu().numpy())))
     dist.destroy_process_group()
+
 
 
 @pytest.mark.gpu
@@ -153,13 +288,8 @@ def test_gpu_two_ranks_match_single_process():
     from hpc_rll.rl_utils.gae import GAE
     from hpc_rll.rl_utils.td import TDLambda
     from hpc_rll.rl_utils.vtrace import VTrace
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    ps = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
-    [p.start() for p in ps]
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
-    [p.join(60) for p in ps]
+    world = 2
+    res = _spawn(_gpu_worker, world, 300)
     dev = torch.device("cuda:0")
     T, B, N = 40, 256, 12
     d = {k: torch.from_numpy(v).to(dev) for k, v in _data(4, T, B, N).items()}
@@ -178,7 +308,16 @@ def test_gpu_two_ranks_match_single_process():
     y.sum().backward()
     full = [p.grad.cpu().numpy() for p in m.parameters()]
     k = B // world
-    for rank, r1, r3, gv, gt, radv, lstm in res:
+    from hpc_rll.rl_utils.padding import Padding1D, UnPadding1D
+    from hpc_rll.torch_utils.network.scatter_connection import ScatterConnection
+    ex_shape = _c5_data()[1].shape
+    c5_full, c5_width, c5_gx = _c5_single(lambda l: Padding1D(l, value=0), UnPadding1D,
+                                          ScatterConnection(ex_shape[0], ex_shape[1], ex_shape[2], 5, 7, "add"), dev)
+    for rank, r1, r3, gv, gt, radv, lstm, adv_full, (c5_total, c5_w, c5_g) in res:
+        assert np.array_equal(adv_full, adv)                       # all_gather_batch on device tensors: bit equal
+        ke = c5_gx.shape[0] // world
+        assert abs(c5_total - c5_full) < 1e-5 * max(1.0, abs(c5_full)) and c5_w == c5_width
+        assert np.array_equal(c5_g, c5_gx[rank * ke:(rank + 1) * ke])   # scatter backward is a gather: bit equal
         # Summed weight gradients == full-batch gradients.  The half batches (B=4) run the layer-wavefront kernels and
         # the full batch (B=8) the step kernels, so the two sides differ by fp32 rounding through S*L LayerNorms over
         # H=12 columns (tests/tools/lstm_dp_err_probe.py: 1e-5 and 4e-5 from the fp64 oracle respectively); the bound is
@@ -192,3 +331,67 @@ def test_gpu_two_ranks_match_single_process():
         assert rel_err(v.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gv) < 1e-6
         assert rel_err(to.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gt) < 1e-6
         assert np.array_equal(adv[:, rank * k:(rank + 1) * k], radv)     # GAE columns are independent: bit equal
+
+
+def _rccl_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+    from hpc_rll import dist as D
+    from hpc_rll.rl_utils.gae import GAE
+    from hpc_rll.rl_utils.ppo import PPO
+    from hpc_rll.rl_utils.vtrace import VTrace
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    T, B, N = 20, 64, 6
+    d = {k: torch.from_numpy(v).to(dev) for k, v in _data(6, T, B, N).items()}
+    to = d["target"].clone().requires_grad_(True)
+    v = d["value"].clone().requires_grad_(True)
+    l3 = VTrace(T, B, N, sharded=True)(to, d["behaviour"], d["action"], v, d["reward"])
+    sum(l3).sum().backward()
+    adv = GAE(T, B)(d["value"], d["reward"])
+    full = D.all_gather_batch(adv, 1)                              # all_gather_into_tensor over RCCL on device tensors
+    width = D.all_reduce_max_int(17)                               # device picked from the backend (nccl -> current GPU)
+    rng = np.random.default_rng(1)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev)  # noqa: E731
+    ln = f(B, N).requires_grad_(True)
+    act = torch.from_numpy(rng.integers(0, N, B)).to(dev)
+    loss, info = PPO(B, N, sharded=True)(ln, f(B, N), act, f(B), f(B), f(B), f(B))
+    sum(loss).sum().backward()
+    q.put((rank, [x.item() for x in l3], to.grad.cpu().numpy(), bool(torch.equal(full, adv)), width,
+           [x.item() for x in loss], list(info), ln.grad.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+
+@pytest.mark.gpu
+def test_gpu_rccl_backend_on_device_tensors():
+    """The `nccl` (= RCCL) backend with device tensors through every hpc_rll.dist entry point the sharded modules use:
+    packed differentiable all-reduce (VTrace, PPO), all_gather_batch, the int all-reduce(max).  One rank (a second
+    rank needs a second GPU; the multi-rank arithmetic is covered by the gloo tests above): results must equal the
+    unsharded modules exactly."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+    from hpc_rll.rl_utils.ppo import PPO
+    from hpc_rll.rl_utils.vtrace import VTrace
+    (res,) = _spawn(_rccl_worker, 1, 300)
+    _, r3, gt, gathered_ok, width, rl, rinfo, gln = res
+    dev = torch.device("cuda:0")
+    T, B, N = 20, 64, 6
+    d = {k: torch.from_numpy(v).to(dev) for k, v in _data(6, T, B, N).items()}
+    to = d["target"].clone().requires_grad_(True)
+    v = d["value"].clone().requires_grad_(True)
+    l3 = VTrace(T, B, N)(to, d["behaviour"], d["action"], v, d["reward"])
+    sum(l3).sum().backward()
+    assert [x.item() for x in l3] == r3 and np.array_equal(to.grad.cpu().numpy(), gt)
+    assert gathered_ok and width == 17
+    rng = np.random.default_rng(1)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev)  # noqa: E731
+    ln = f(B, N).requires_grad_(True)
+    act = torch.from_numpy(rng.integers(0, N, B)).to(dev)
+    loss, info = PPO(B, N)(ln, f(B, N), act, f(B), f(B), f(B), f(B))
+    sum(loss).sum().backward()
+    assert [x.item() for x in loss] == rl and list(info) == rinfo and np.array_equal(ln.grad.cpu().numpy(), gln)

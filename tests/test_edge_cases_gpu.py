@@ -119,3 +119,77 @@ def test_hip_graph_capture_replay():
     assert torch.equal(v.grad, eager_grad)
     for a, b in zip(outs, eager):
         assert torch.equal(a, b)
+
+
+def test_graph_capture_with_cold_coefficient_cache():
+    """a GAE call captured while its (T, gamma, lambda) coefficient table is NOT cached must (a) fill a
+    per-call table inside the capture, (b) not publish that table (its contents only exist once the graph has been
+    replayed), so an EAGER call with the same key between capture and replay still computes the right answer, and
+    (c) replay correctly afterwards."""
+    import hpc_rl_utils as U
+    T, B = 37, 300                                   # a T no other test uses with these (gamma, lambda)
+    gamma, lam = 0.9137, 0.8713
+    g = torch.Generator(device=DEV).manual_seed(3)
+    v = torch.randn(T + 1, B, device=DEV, generator=g)
+    r = torch.randn(T, B, device=DEV, generator=g)
+    ga = torch.randn(T, B, device=DEV, generator=g)
+    adv_g = torch.empty_like(r)
+    gv_g, gr_g = torch.empty_like(v), torch.empty_like(r)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        U.GaeForward([v, r], [torch.empty_like(r)], 0.99, 0.97)      # warm-up with ANOTHER key: the capture below misses
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        U.GaeForward([v, r], [adv_g], gamma, lam)
+        U.GaeBackward([ga], [gv_g, gr_g], gamma, lam)
+    # eager call with the SAME key before any replay: must not read an unfilled cached table
+    adv_e = torch.empty_like(r)
+    gv_e, gr_e = torch.empty_like(v), torch.empty_like(r)
+    U.GaeForward([v, r], [adv_e], gamma, lam)
+    U.GaeBackward([ga], [gv_e, gr_e], gamma, lam)
+    torch.cuda.synchronize()
+    from oracle import ref_torch as R
+    ref = R.gae(v.double().cpu(), r.double().cpu(), gamma, lam)
+    assert ((adv_e.double().cpu() - ref).abs() / ref.abs().clamp(min=1.0)).max().item() < 1e-5
+    adv_g.fill_(float("nan"))
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(adv_g, adv_e) and torch.equal(gv_g, gv_e) and torch.equal(gr_g, gr_e)
+    # many distinct keys: the cache is capped and never evicts, nothing goes stale
+    outs = []
+    for i in range(300):
+        o = torch.empty_like(r)
+        U.GaeForward([v, r], [o], 0.5 + i * 1e-3, 0.9)
+        outs.append(o)
+    again = torch.empty_like(r)
+    U.GaeForward([v, r], [again], 0.5, 0.9)
+    torch.cuda.synchronize()
+    assert torch.equal(again, outs[0])
+
+
+def test_inplace_change_between_forward_and_backward_is_caught():
+    """backward recomputes from saved INPUTS (logits, LSTM weights); they are saved with
+    save_for_backward, so autograd's version counter catches an in-place update between forward and backward."""
+    from hpc_rll.rl_utils.upgo import UPGO
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    T, B, N = 6, 10, 5
+    g = torch.Generator(device=DEV).manual_seed(0)
+    logits = torch.randn(T, B, N, device=DEV, generator=g)
+    to = logits.clone().requires_grad_(True)
+    a = torch.randint(0, N, (T, B), device=DEV, generator=g)
+    rho, r, v = (torch.rand(T, B, device=DEV, generator=g), torch.randn(T, B, device=DEV, generator=g),
+                 torch.randn(T + 1, B, device=DEV, generator=g))
+    h = to * 1.0                                    # non-leaf, so that an in-place op on it is legal
+    loss = UPGO(T, B, N)(h, rho, a, r, v)
+    h.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+    m = LSTM(4, 3, 6, 8, 1).to(DEV)
+    y, _ = m(torch.randn(4, 3, 6, device=DEV), None)
+    with torch.no_grad():
+        m.wh.add_(0.1)                              # e.g. optimizer.step() before a second backward
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        y.sum().backward()

@@ -59,6 +59,18 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
 
+    # ---- the floor: torch's own smallest fwd+bwd through the autograd engine on this box (one mul kernel each way)
+    x0 = rn(64).requires_grad_(True)
+    g0 = rn(64)
+
+    def fb0():
+        x0.grad = None
+        (x0 * 2.0).backward(g0)
+    out(op="torch reference: (x*2).backward(g)", shape="64", wall_us=wall(fb0), issue_us=host_only(fb0))
+    torch.autograd.set_multithreading_enabled(False)
+    out(op="torch reference, autograd multithreading off", shape="64", wall_us=wall(fb0))
+    torch.autograd.set_multithreading_enabled(True)
+
     # ---- GAE at the reference test shape and at the strong-scaling per-rank shape
     for T, B, target in ((1024, 64, 30.0), (1024, 8192, 60.0), (1024, 1024, None)):
         v, r, ga = rn(T + 1, B).requires_grad_(True), rn(T, B).requires_grad_(True), rn(T, B)
@@ -114,7 +126,7 @@ def main():
 
         def fo():
             x.grad = None
-            R.scatter_connection(x, (H, W), loc, typ).backward(go)
+            R.scatter_connection(x, loc, H, W, typ).backward(go)
         t_hip, t_eager = wall(fb, 50), wall(fo, 20, 3)
         out(op=f"scatter({typ}) fwd+bwd", shape=f"B={B} M={M} N={N} {H}x{W}", hip_us=t_hip, eager_us=t_eager,
             speedup=t_eager / t_hip, target_speedup=3.0)
