@@ -176,6 +176,30 @@ def main():
         step()
     elapsed, per_rank_s = timed(step, args.steps, args.warmup)
 
+    # ---- per-kernel durations, measured IMMEDIATELY after the timed region (same clocks / thermal state: on a power-
+    # capped part the step time drifts by ~5 % over the first seconds of streaming): HIP events on the launch stream
+    # (torch's current stream) around EVERY launch of a second, instrumented pass over the same K steps in the same
+    # alternating fwd/bwd order as the timed region (a kernel repeated back to back would find its inputs in the 256 MiB Infinity Cache and look
+    # faster than it is in the real sequence; rocprofv3 --kernel-trace of this command sees the same pattern).
+    v_d, r_d = value.detach(), reward.detach()
+    adv = torch.empty_like(r_d)
+    gv, gr = torch.empty_like(v_d), torch.empty_like(r_d)
+    n_ev = max(args.steps, 10)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_ev + 1)]
+    U.GaeForward([v_d, r_d], [adv], gamma, lam)
+    U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
+    ev[0].record()
+    for i in range(n_ev):
+        U.GaeForward([v_d, r_d], [adv], gamma, lam)
+        ev[2 * i + 1].record()
+        U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
+        ev[2 * i + 2].record()
+    ev[-1].synchronize()
+    t_fwd = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(n_ev)) / n_ev * 1e-3
+    t_bwd = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(n_ev)) / n_ev * 1e-3
+    bytes_launch = 12 * T * B + 4 * B  # either direction: SURVEY.md 8(d)
+    dom, t_dom = ("gae_bwd_kernel", t_bwd) if t_bwd >= t_fwd else ("gae_fwd_kernel", t_fwd)
+
     # ---- both scaling readings in the same line.  Bounded: ~200 steps per leg.
     def leg(Bk, graph, steps=200, warmup=20):
         st, keep_alive = make_step(Bk, graph)
@@ -196,29 +220,6 @@ def main():
         if world == 1:   # what one rank of an N-GPU strong-scaling run of global B = 65536 holds, timed on this GPU
             detail["strong_per_rank_probe"] = {str(n): {"eager": leg(GB // n, False), "graph": leg(GB // n, True)}
                                                for n in (2, 4, 8)}
-
-    # ---- per-kernel durations: HIP events on the launch stream (torch's current stream) around EVERY launch of
-    # a second, instrumented pass over the same K steps in the same alternating fwd/bwd order as the timed
-    # region (a kernel repeated back to back would find its inputs in the 256 MiB Infinity Cache and look
-    # faster than it is in the real sequence; rocprofv3 --kernel-trace of this command sees the same pattern).
-    v_d, r_d = value.detach(), reward.detach()
-    adv = torch.empty_like(r_d)
-    gv, gr = torch.empty_like(v_d), torch.empty_like(r_d)
-    n_ev = max(args.steps, 10)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_ev + 1)]
-    U.GaeForward([v_d, r_d], [adv], gamma, lam)
-    U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
-    ev[0].record()
-    for i in range(n_ev):
-        U.GaeForward([v_d, r_d], [adv], gamma, lam)
-        ev[2 * i + 1].record()
-        U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
-        ev[2 * i + 2].record()
-    ev[-1].synchronize()
-    t_fwd = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(n_ev)) / n_ev * 1e-3
-    t_bwd = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(n_ev)) / n_ev * 1e-3
-    bytes_launch = 12 * T * B + 4 * B  # either direction: SURVEY.md 8(d)
-    dom, t_dom = ("gae_bwd_kernel", t_bwd) if t_bwd >= t_fwd else ("gae_fwd_kernel", t_fwd)
 
     traffic = None
     tj = os.path.join(ROOT, "profiles", "gae_traffic.json")

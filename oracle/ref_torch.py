@@ -400,10 +400,21 @@ def scatter_connection(x: torch.Tensor, location: torch.Tensor, H: int, W: int, 
 # ---------------------------------------------------------------------------
 
 
+def _lstm_step(xs, h, c, wx, wh, gx, bx, gh, bh, b, eps):
+    H4 = wh.shape[1]
+    gate = F.layer_norm(xs @ wx, (H4,), gx, bx, eps) + F.layer_norm(h @ wh, (H4,), gh, bh, eps) + b
+    i, f, o, u = gate.chunk(4, dim=1)
+    c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(u)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    return h, c
+
+
 def lstm(x, h0, c0, wx: Sequence[torch.Tensor], wh: Sequence[torch.Tensor], bias, ln_gamma, ln_beta,
-         eps: float = 1e-5):
+         eps: float = 1e-5, checkpoint_steps: bool = False):
     """x (S,B,in); h0,c0 (L,B,H); wx[l] (in_l,4H); wh[l] (H,4H); bias (L,4H);
-    ln_gamma/ln_beta (L, 2*4H) = [x-half | h-half].  gate order i,f,o,u.  Returns y (S,B,H), h (L,B,H), c (L,B,H)."""
+    ln_gamma/ln_beta (L, 2*4H) = [x-half | h-half].  gate order i,f,o,u.  Returns y (S,B,H), h (L,B,H), c (L,B,H).
+    ``checkpoint_steps``: recompute every time step in backward (torch.utils.checkpoint) instead of keeping its
+    activations -- same arithmetic, lets the full configs[3] size run in fp64 on one GPU."""
     S = x.shape[0]
     L = len(wx)
     H4 = wh[0].shape[1]
@@ -415,11 +426,12 @@ def lstm(x, h0, c0, wx: Sequence[torch.Tensor], wh: Sequence[torch.Tensor], bias
         gx, bx = ln_gamma[l, :H4], ln_beta[l, :H4]
         gh, bh = ln_gamma[l, H4:], ln_beta[l, H4:]
         for s in range(S):
-            gate = (F.layer_norm(inp[s] @ wx[l], (H4,), gx, bx, eps)
-                    + F.layer_norm(h @ wh[l], (H4,), gh, bh, eps) + bias[l])
-            i, f, o, u = gate.chunk(4, dim=1)
-            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(u)
-            h = torch.sigmoid(o) * torch.tanh(c)
+            if checkpoint_steps:
+                from torch.utils.checkpoint import checkpoint
+                h, c = checkpoint(_lstm_step, inp[s], h, c, wx[l], wh[l], gx, bx, gh, bh, bias[l], eps,
+                                  use_reentrant=False)
+            else:
+                h, c = _lstm_step(inp[s], h, c, wx[l], wh[l], gx, bx, gh, bh, bias[l], eps)
             outs.append(h)
         inp = torch.stack(outs, 0)
         hs.append(h)

@@ -483,11 +483,95 @@ def gen_lstm():
     save("lstm", **out)
 
 
+def _reference_test_snippets():
+    """Pull the reference TEST's own oracle expressions for the hpc_models helpers out of
+    /root/reference/tests/test_actor_critic.py with `ast` (the module itself imports the CUDA extension, so it cannot
+    be imported here): the function torch_update_ae (:23-26) and the statements of actor_critic_pre_sample_val that
+    compute ori_out from ori_x / ori_key / ori_mask (:260-265).  They are executed from the reference tree at fixture
+    generation time; nothing of them is stored in this repository."""
+    import ast
+    path = os.path.join(REF, "tests", "test_actor_critic.py")
+    tree = ast.parse(open(path).read(), path)
+    ns = {"torch": torch}
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "torch_update_ae")
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    val = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "actor_critic_pre_sample_val")
+    stmts = [st for st in val.body if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Name)
+             and st.targets[0].id in ("ori_queries", "ori_query_result", "ori_step_logits", "ori_out")]
+    assert [st.targets[0].id for st in stmts] == ["ori_queries", "ori_query_result", "ori_step_logits", "ori_step_logits",
+                                                  "ori_step_logits", "ori_out"], "reference test changed"
+    pre_sample_code = compile(ast.Module(body=stmts, type_ignores=[]), path, "exec")
+
+    def pre_sample(ori_x, ori_key, ori_mask):
+        env = {"ori_x": ori_x, "ori_key": ori_key, "ori_mask": ori_mask}
+        exec(pre_sample_code, {"torch": torch}, env)
+        return env["ori_out"]
+    return ns["torch_update_ae"], pre_sample
+
+
+def gen_models():
+    """hpc_models: the reference has no `origin` module for these three helpers; its test validates
+    against inline torch expressions and torch.nn.LSTM (tests/test_actor_critic.py:23-26,124-154,259-264).  The fixtures
+    record exactly those expressions' outputs."""
+    out = {}
+    update_ae, pre_sample = _reference_test_snippets()
+    # update_ae: (B, E, D, seed)  (the reference test's own shape, B=8 E=512 D=256, runs in tests/test_models_gpu.py)
+    cases = [(8, 64, 48, 1), (3, 7, 5, 2), (17, 33, 100, 3)]
+    out["ae_cases"] = np.array(cases, dtype=np.int64)
+    for i, (B, E, D, seed) in enumerate(cases):
+        rng = np.random.default_rng(1200 + seed)
+        ae, key = rn(rng, B, D), rn(rng, B, E, D)
+        num = rng.integers(max(E - 2, 1), E, B).astype(np.int64)
+        sample = np.array([rng.integers(0, n + 1) for n in num], dtype=np.int64)       # may equal entity_num ("end")
+        end = sample == num
+        ref = update_ae(T_(ae), T_(key), T_(np.minimum(sample, E - 1)), T_(num), T_(end))
+        out.update({f"ae{i}_ae": ae, f"ae{i}_key": key, f"ae{i}_num": num, f"ae{i}_sample": sample,
+                    f"ae{i}_out": ref.numpy()})
+    # lstm_activation: (B, I, H, seed) against torch.nn.LSTM (:124-154)
+    cases = [(8, 32, 32, 1), (5, 12, 70, 2), (16, 48, 256, 3)]
+    out["act_cases"] = np.array(cases, dtype=np.int64)
+    for i, (B, I, H, seed) in enumerate(cases):
+        torch.manual_seed(1300 + seed)
+        lstm = torch.nn.LSTM(I, H, 1)
+        rng = np.random.default_rng(1300 + seed)
+        x, h0, c0 = T_(rn(rng, 1, B, I)), T_(rn(rng, 1, B, H)), T_(rn(rng, 1, B, H))
+        with torch.no_grad():
+            _, (hn, cn) = lstm.forward(x, (h0, c0))
+            ih = torch.matmul(x[0], lstm.weight_ih_l0.transpose(0, 1))
+            hh = torch.matmul(h0[0], lstm.weight_hh_l0.transpose(0, 1))
+            bias = lstm.bias_ih_l0 + lstm.bias_hh_l0
+        out.update({f"act{i}_ih": ih.numpy(), f"act{i}_hh": hh.numpy(), f"act{i}_bias": bias.numpy(),
+                    f"act{i}_c0": c0[0].numpy(), f"act{i}_hn": hn[0].numpy(), f"act{i}_cn": cn[0].numpy()})
+    # pre_sample: (B, E, H, seed)
+    cases = [(8, 64, 32, 1), (3, 9, 100, 2), (16, 50, 96, 3)]
+    out["pre_cases"] = np.array(cases, dtype=np.int64)
+    for i, (B, E, H, seed) in enumerate(cases):
+        rng = np.random.default_rng(1400 + seed)
+        x, key = rn(rng, 1, B, H), rn(rng, B, E, H)
+        mask = rng.random((B, E)) < 0.8
+        ref = pre_sample(T_(x), T_(key), T_(mask))
+        out.update({f"pre{i}_x": x, f"pre{i}_key": key, f"pre{i}_mask": mask, f"pre{i}_out": ref.numpy()})
+    save("models", **out)
+
+
+def write_api_surface():
+    """tests/golden/api_surface.json: the ast-parsed public surface of the reference's hpc_rll modules (what
+    tests/test_api_surface.py compares the drop-in package against).  Written ONLY here."""
+    import json
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import test_api_surface as A
+    json.dump(A.reference_surface(), open(A.SNAP, "w"), indent=1, sort_keys=True)
+    print("wrote", A.SNAP)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     gens = dict(gae=gen_gae, td_lambda=gen_td_lambda, vtrace=gen_vtrace, upgo=gen_upgo, ppo=gen_ppo, qntd=gen_qntd,
-                dntd=gen_dntd, iqn=gen_iqn, qrdqn=gen_qrdqn, padding=gen_padding, scatter=gen_scatter, lstm=gen_lstm)
+                dntd=gen_dntd, iqn=gen_iqn, qrdqn=gen_qrdqn, padding=gen_padding, scatter=gen_scatter, lstm=gen_lstm,
+                models=gen_models)
     for k, fn in gens.items():
         if not only or k in only:
             fn()
+    if not only or "api_surface" in only:
+        write_api_surface()
     print("all golden fixtures written and the oracle restatement agrees with hpc_rll.origin")

@@ -18,6 +18,16 @@ def _rel(ref, got):
     return ((ref - got).abs() / ref.abs().clamp(min=1.0)).max().item()
 
 
+def _nerr(ref, got):
+    """max |ref - got| / max |ref| -- a PER-TENSOR scale.  Gradients of mean-reduced losses are O(1/(T*B)) (~1e-7 at
+    configs[2]); `_rel` above divides by max(1, |ref|) and would accept an all-zero gradient there (ADVICE r01 #1)."""
+    ref, got = ref.double(), got.double()
+    scale = ref.abs().max().item()
+    assert scale > 0.0 and torch.isfinite(got).all(), "reference gradient is trivially zero / result not finite"
+    assert got.abs().max().item() > 0.25 * scale, "gradient has the wrong magnitude"
+    return (ref - got).abs().max().item() / scale
+
+
 def test_c3_return_suite_full_size():
     """configs[2]: V-trace + UPGO + TD-lambda, T=256, B=16384 (N=128 per tests/test_vtrace.py:13)."""
     from hpc_rll.rl_utils.td import TDLambda
@@ -41,7 +51,8 @@ def test_c3_return_suite_full_size():
     l64 = R.td_lambda_error(v64, reward.double(), weight.double(), 0.9, 0.8)
     l64.backward()
     assert rel_err(l64.item(), loss.item()) < 1e-5
-    assert _rel(v64.grad, v.grad) < 2e-5
+    # measured 1.3e-7 (profiles/r02_parity_probe.json); fixed bound, relative to the gradient's own scale (2e-6)
+    assert _nerr(v64.grad, v.grad) < 5e-6
 
     # ---- V-trace (losses + both gradients)
     to = target.clone().requires_grad_(True)
@@ -53,8 +64,8 @@ def test_c3_return_suite_full_size():
     l64 = R.vtrace_error(to64, behaviour.double(), action, v64, reward.double(), None)
     sum(l64).backward()
     assert rel_err([x.item() for x in l64], [x.item() for x in ls]) < 1e-5
-    assert _rel(v64.grad, v.grad) < 2e-5
-    assert _rel(to64.grad, to.grad) < 2e-5
+    assert _nerr(v64.grad, v.grad) < 5e-6          # measured 6.1e-7, gradient scale 5.7e-6
+    assert _nerr(to64.grad, to.grad) < 5e-6        # measured 6.1e-7, gradient scale 2.9e-6
     del to64, l64
 
     # ---- UPGO
@@ -64,11 +75,17 @@ def test_c3_return_suite_full_size():
     to64 = target.double().requires_grad_(True)
     l64 = R.upgo_loss(to64, rho.double(), action, reward.double(), value.double())
     l64.backward()
-    # the data-dependent lambda compares fp32 sums; with 4M comparisons a handful can flip between fp32 and fp64, each
-    # moving one return by O(1): compare the loss at 1e-4 and the gradient on the 99.99% of rows that agree
-    assert rel_err(l64.item(), loss.item()) < 1e-4
-    row_err = ((to64.grad - to.grad.double()).abs().amax(-1))
-    assert (row_err > 1e-9).double().mean().item() < 1e-3
+    # The data-dependent lambda_t = [r_{t+1} + V_{t+2} >= V_{t+1}] is evaluated in fp32 by the kernel (as by the fp32
+    # reference) and in fp64 by the oracle; a comparison whose two sides differ by less than an fp32 ulp can flip and
+    # moves one return by O(1).  Count the flips explicitly (absolute cap), compare the gradient on the columns whose
+    # masks agree at the same fixed bound as the other ops, and the loss at 1e-5 (a flip moves it by ~1/(T*B) = 2e-7).
+    lam32 = (reward + value[1:]) >= value[:-1]
+    lam64 = (reward.double() + value[1:].double()) >= value[:-1].double()
+    flips = lam32 != lam64
+    assert int(flips.sum().item()) <= 16, int(flips.sum().item())          # of 4,194,304 comparisons; measured 0
+    agree = ~flips.any(0)
+    assert rel_err(l64.item(), loss.item()) < 1e-5
+    assert _nerr(to64.grad[:, agree], to.grad[:, agree]) < 5e-6            # measured 1.5e-7, gradient scale 3.5e-6
 
 
 def test_c3_shard_additivity():
@@ -97,54 +114,67 @@ def test_c3_shard_additivity():
     assert rel_err(full.cpu().numpy(), parts.cpu().numpy()) < 1e-6
 
 
-def test_c4_lstm_full_size_forward():
-    """configs[3]: LSTM S=128, B=4096, H=1024 (input 1024, L=1).  Forward against the fp64 oracle evaluated on the GPU;
-    the full-size backward is covered by the transpose property <y, gy> consistency below at reduced S."""
+def _c4_module_and_oracle_params(S, B, I, H, L, seed):
     from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(seed)
+    m = LSTM(S, B, I, H, L).to(DEV)
+    leaf = lambda t: t.detach().double().requires_grad_(True)  # noqa: E731
+    return m, leaf, (leaf(m.wx.reshape(I, 4 * H)), leaf(m.wh.reshape(H, 4 * H)), leaf(m.bias.reshape(L, 4 * H)),
+                     leaf(m.ln_gamma), leaf(m.ln_beta))
+
+
+def test_c4_lstm_full_size_forward_and_backward():
+    """configs[3] at FULL size: LSTM S=128, B=4096, I=H=1024, L=1, forward AND every gradient against the fp64 oracle
+    evaluated on the GPU (each time step recomputed in backward -- torch.utils.checkpoint -- so that fp64 autograd
+    fits: same arithmetic).
+
+    FIXED tolerances, max|ref - got| / max|ref| per tensor.  128 LayerNorm-recurrent steps amplify
+    fp32 rounding: measured (tests/tools/r02_parity_probe.py -> profiles/r02_parity_probe.json) HIP vs fp64
+    y 5.4e-4, hn 5.2e-4, cn 1.8e-4, dx 5.4e-4, dh0 4.8e-4, dc0 7.2e-4, dwx/dwh/dbias/dgamma/dbeta 1.7-2.1e-4, while
+    torch's own fp32 evaluation of the same oracle is y 5.9e-4, dx 6.5e-4, dc0 8.2e-4, dw 1.6-2.0e-4 away from fp64.
+    Bounds: 1.5e-3 forward, 2e-3 gradients (~2.5x the measurement: the error of a chaotic recurrence is seed dependent)."""
     S, B, I, H, L = 128, 4096, 1024, 1024, 1
-    torch.manual_seed(0)
-    m = LSTM(S, B, I, H, L).to(DEV)
-    x = torch.randn(S, B, I, device=DEV)
-    h0 = torch.randn(L, B, H, device=DEV)
-    c0 = torch.randn(L, B, H, device=DEV)
-    with torch.no_grad():
-        y, (hn, cn) = m(x, (h0, c0))
-        wx = [m.wx.double().reshape(I, 4 * H)]
-        wh = [m.wh.double().reshape(H, 4 * H)]
-        oy, oh, oc = R.lstm(x.double(), h0.double(), c0.double(), wx, wh, m.bias.double().reshape(L, 4 * H),
-                            m.ln_gamma.double(), m.ln_beta.double())
-        oy32, _, _ = R.lstm(x, h0, c0, [w.float() for w in wx], [w.float() for w in wh], m.bias.reshape(L, 4 * H),
-                            m.ln_gamma, m.ln_beta)
-    tol = max(1e-5, 3.0 * _rel(oy, oy32))      # fp32 drift through 128 LayerNorm-recurrent steps (see test_lstm_gpu.py)
-    assert _rel(oy, y) < tol
-    assert _rel(oh, hn) < tol and _rel(oc, cn) < tol
-
-
-def test_c4_lstm_large_batch_gradients():
-    """Same widths as configs[3] (B=4096, I=H=1024) at S=4 so that fp64 autograd fits comfortably: every gradient."""
-    from hpc_rll.torch_utils.network.rnn import LSTM
-    S, B, I, H, L = 4, 4096, 1024, 1024, 1
-    torch.manual_seed(1)
-    m = LSTM(S, B, I, H, L).to(DEV)
+    m, leaf, (owx, owh, ob, og, obe) = _c4_module_and_oracle_params(S, B, I, H, L, 0)
     x = torch.randn(S, B, I, device=DEV, requires_grad=True)
     h0 = torch.randn(L, B, H, device=DEV, requires_grad=True)
     c0 = torch.randn(L, B, H, device=DEV, requires_grad=True)
     gy = torch.randn(S, B, H, device=DEV)
     y, (hn, cn) = m(x, (h0, c0))
     ((y * gy).sum() + hn.sum() - cn.sum()).backward()
-    leaf = lambda t: t.detach().double().requires_grad_(True)  # noqa: E731
     ox, oh0, oc0 = leaf(x), leaf(h0), leaf(c0)
-    owx, owh = leaf(m.wx.reshape(I, 4 * H)), leaf(m.wh.reshape(H, 4 * H))
-    ob, og, obe = leaf(m.bias.reshape(L, 4 * H)), leaf(m.ln_gamma), leaf(m.ln_beta)
+    oy, ohn, ocn = R.lstm(ox, oh0, oc0, [owx], [owh], ob, og, obe, checkpoint_steps=True)
+    ((oy * gy.double()).sum() + ohn.sum() - ocn.sum()).backward()
+    errs = {"y": _nerr(oy.detach(), y.detach()), "hn": _nerr(ohn.detach(), hn.detach()), "cn": _nerr(ocn.detach(), cn.detach())}
+    for k, e in errs.items():
+        assert e < 1.5e-3, (k, e)
+    for name, ref, got in (("dx", ox.grad, x.grad), ("dh0", oh0.grad, h0.grad), ("dc0", oc0.grad, c0.grad),
+                           ("dwx", owx.grad.reshape(-1), m.wx.grad), ("dwh", owh.grad.reshape(-1), m.wh.grad),
+                           ("dbias", ob.grad.reshape(-1), m.bias.grad), ("dgamma", og.grad, m.ln_gamma.grad),
+                           ("dbeta", obe.grad, m.ln_beta.grad)):
+        errs[name] = _nerr(ref, got)
+        assert errs[name] < 2e-3, (name, errs[name])
+    print("c4 full size", {k: f"{v:.1e}" for k, v in errs.items()})
+
+
+def test_c4_lstm_large_batch_gradients():
+    """Same widths as configs[3] (B=4096, I=H=1024) at S=4, where rounding has not been amplified yet: every gradient
+    within 2e-5 of the fp64 oracle relative to the tensor's own scale (measured <= 5.1e-6), forward 1e-5 (north_star)."""
+    S, B, I, H, L = 4, 4096, 1024, 1024, 1
+    m, leaf, (owx, owh, ob, og, obe) = _c4_module_and_oracle_params(S, B, I, H, L, 1)
+    x = torch.randn(S, B, I, device=DEV, requires_grad=True)
+    h0 = torch.randn(L, B, H, device=DEV, requires_grad=True)
+    c0 = torch.randn(L, B, H, device=DEV, requires_grad=True)
+    gy = torch.randn(S, B, H, device=DEV)
+    y, (hn, cn) = m(x, (h0, c0))
+    ((y * gy).sum() + hn.sum() - cn.sum()).backward()
+    ox, oh0, oc0 = leaf(x), leaf(h0), leaf(c0)
     oy, ohn, ocn = R.lstm(ox, oh0, oc0, [owx], [owh], ob, og, obe)
     ((oy * gy.double()).sum() + ohn.sum() - ocn.sum()).backward()
     assert _rel(oy.detach(), y) < 1e-5
     for ref, got in ((ox.grad, x.grad), (oh0.grad, h0.grad), (oc0.grad, c0.grad), (owx.grad.reshape(-1), m.wx.grad),
                      (owh.grad.reshape(-1), m.wh.grad), (ob.grad.reshape(-1), m.bias.grad), (og.grad, m.ln_gamma.grad),
                      (obe.grad, m.ln_beta.grad)):
-        # weight gradients sum 16384 products of O(1) terms: compare relative to the gradient's own scale
-        scale = ref.abs().max().clamp(min=1.0)
-        assert ((ref - got.double()).abs().max() / scale).item() < 2e-4
+        assert _nerr(ref, got) < 2e-5
 
 
 def test_c5_scatter_full_size():

@@ -52,3 +52,25 @@ def test_pre_sample(B, E, H):
     out = torch.zeros(B, E, device=DEV)
     hpc_models.actor_critic_pre_sample([key.to(DEV), x.to(DEV), mask.to(DEV)], [out])
     assert np.allclose(ref.numpy(), out.cpu().numpy(), rtol=1e-5, atol=1e-5)                  # the reference's own assert
+
+
+def test_models_golden_fixtures(golden):
+    """tests/golden/models.npz: outputs of the reference TEST's own oracle expressions (torch_update_ae, torch.nn.LSTM,
+    the pre-sample statements), executed from /root/reference by tests/golden/make_golden.py."""
+    import hpc_models
+    g = golden("models")
+    for i, (B, E, D, _) in enumerate(g["ae_cases"]):
+        ae = torch.from_numpy(g[f"ae{i}_ae"]).to(DEV)
+        hpc_models.actor_critic_update_ae([torch.from_numpy(g[f"ae{i}_key"]).to(DEV), torch.from_numpy(g[f"ae{i}_sample"]).to(DEV),
+                                           torch.from_numpy(g[f"ae{i}_num"]).to(DEV)], [ae])
+        assert np.array_equal(ae.cpu().numpy(), g[f"ae{i}_out"])                              # one fp32 add: bit exact
+    for i, (B, I, H, _) in enumerate(g["act_cases"]):
+        h, c = torch.empty(int(B), int(H), device=DEV), torch.from_numpy(g[f"act{i}_c0"]).to(DEV)
+        hpc_models.actor_critic_lstm_activation([torch.from_numpy(g[f"act{i}_{k}"]).to(DEV) for k in ("ih", "hh", "bias")], [h, c])
+        assert np.allclose(g[f"act{i}_hn"], h.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert np.allclose(g[f"act{i}_cn"], c.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    for i, (B, E, H, _) in enumerate(g["pre_cases"]):
+        out = torch.zeros(int(B), int(E), device=DEV)
+        hpc_models.actor_critic_pre_sample([torch.from_numpy(g[f"pre{i}_key"]).to(DEV), torch.from_numpy(g[f"pre{i}_x"]).to(DEV),
+                                            torch.from_numpy(g[f"pre{i}_mask"]).to(DEV)], [out])
+        assert np.allclose(g[f"pre{i}_out"], out.cpu().numpy(), rtol=1e-5, atol=1e-5)        # the reference's own assert

@@ -67,9 +67,6 @@ def main():
         x0.grad = None
         (x0 * 2.0).backward(g0)
     out(op="torch reference: (x*2).backward(g)", shape="64", wall_us=wall(fb0), issue_us=host_only(fb0))
-    torch.autograd.set_multithreading_enabled(False)
-    out(op="torch reference, autograd multithreading off", shape="64", wall_us=wall(fb0))
-    torch.autograd.set_multithreading_enabled(True)
 
     # ---- GAE at the reference test shape and at the strong-scaling per-rank shape
     for T, B, target in ((1024, 64, 30.0), (1024, 8192, 60.0), (1024, 1024, None)):
@@ -166,6 +163,23 @@ def main():
         v.grad = None
         sum(m3(to, bo, a, v, r)).backward()
     out(op="vtrace fwd+bwd", shape=f"T={T} B={B} N={N}", wall_us=wall(fb))
+
+    # ---- LAST (toggling the engine mode changes later timings): the autograd engine's cross-thread hand-off.  With
+    # multithreading off backward runs on the calling thread; the difference is torch's, not this library's.
+    out(op="torch reference again", shape="64", wall_us=wall(fb0))
+    T, B = 1024, 64
+    v, r, ga = rn(T + 1, B).requires_grad_(True), rn(T, B).requires_grad_(True), rn(T, B)
+    m = GAE(T, B)
+
+    def fbg():
+        v.grad = None
+        r.grad = None
+        m(v, r).backward(ga)
+    t_on = wall(fbg)
+    torch.autograd.set_multithreading_enabled(False)
+    out(op="gae fwd+bwd, autograd multithreading off", shape=f"T={T} B={B}", wall_us=wall(fbg), multithreaded_us=t_on)
+    out(op="torch reference, autograd multithreading off", shape="64", wall_us=wall(fb0))
+    torch.autograd.set_multithreading_enabled(True)
 
 
 if __name__ == "__main__":
