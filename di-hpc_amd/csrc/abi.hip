@@ -11,6 +11,10 @@ extern "C" const char* hpc_rll_status_string(int status) {
         case HPC_RLL_EINVAL: return "hpc_rll: invalid argument (negative size or null pointer)";
         case HPC_RLL_EALIGN: return "hpc_rll: pointer is not 4-byte aligned";
         case HPC_RLL_EUNSUPPORTED: return "hpc_rll: shape/configuration not supported by the gfx950 kernels";
+        case HPC_RLL_ETIMEOUT:
+            return "hpc_rll: a persistent LSTM kernel gave up waiting for its co-resident workgroups (another process "
+                   "held the GPU); the results of that call are invalid -- hpc_rll_clear_async_error() continues on the "
+                   "step kernels";
         default: break;
     }
     if (status > 0) return hipGetErrorString((hipError_t)status);

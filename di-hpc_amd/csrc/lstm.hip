@@ -570,8 +570,8 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     {   // persistent small-batch paths: {value, tag} exchange words (per-layer kernels / layer wavefront)
         size_t words = xchg_layout(B, H).total_words;
         WaveCfg wc{};
-        if (wave_shape_ok(S, B, H, L, 256, &wc) && wc.hx_words + wc.sx_words > words) words = wc.hx_words + wc.sx_words;
-        const bool wb = wave_bwd_shape_ok(S, B, H, L, 256, &wc);
+        if (wave_shape_ok(S, B, H, L, 256, &wc, true) && wc.hx_words + wc.sx_words > words) words = wc.hx_words + wc.sx_words;
+        const bool wb = wave_bwd_shape_ok(S, B, H, L, 256, &wc, true);
         if (wb && 2 * wc.hx_words + wc.sx_words > words) words = 2 * wc.hx_words + wc.sx_words;
         w.xchg = take(2 * words);
         w.dwave = take(wb ? (size_t)L * 3 * SB * G : 0);   // per-layer dgate/dXW/dHW (all layers are live at once)
@@ -616,6 +616,7 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
     if (S < 0 || B < 0 || I <= 0 || H <= 0 || L <= 0 || L > 16) return HPC_RLL_EINVAL;
     if (H > 2048) return HPC_RLL_EUNSUPPORTED;
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return HPC_RLL_EINVAL;
+    if (persist_async_status()) return HPC_RLL_ETIMEOUT;   // an earlier persistent launch gave up: see the header
     if (B == 0) return HPC_RLL_OK;
     if (!h0 || !c0 || !wx || !wh || !bias || !ln_gamma || !ln_beta || !hn || !cn) return HPC_RLL_EINVAL;
     if (S > 0 && (!x || !y || !ws)) return HPC_RLL_EINVAL;
@@ -624,7 +625,7 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
     const Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
     size_t wx_off = 0;
     WaveCfg wc{};
-    if (S > 0 && wave_fwd_ok(S, B, H, L, &wc)) {   // all layers in one launch, as a wavefront (lstm_wave.hpp)
+    if (S > 0 && wave_fwd_ok(S, B, H, L, &wc, st)) {   // all layers in one launch, as a wavefront (lstm_wave.hpp)
         const LayerWs& l0 = w.layer[0];
         {
             const int skf = gemm_splitk((int)SB, (int)G, I);
@@ -661,7 +662,7 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
         return last_error();
     }
     PersistCfg pc{};
-    const bool persist = S > 0 && persist_cfg(B, H, H, &pc);
+    const bool persist = S > 0 && persist_cfg(B, H, H, &pc) && persist_fwd_ok(pc, st);
     const XchgLayout xl = xchg_layout(B, H);
     if (persist && hipMemsetAsync(w.xchg, 0, xl.total_words * sizeof(u64), st) != hipSuccess) return last_error();
     for (int l = 0; l < L; ++l) {
@@ -735,6 +736,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
                                      int H, int L, float dropout_p, uint64_t seed, void* stream) {
     if (S <= 0 || B <= 0 || I <= 0 || H <= 0 || L <= 0 || L > 16) return HPC_RLL_EINVAL;
     if (H > 2048) return HPC_RLL_EUNSUPPORTED;
+    if (persist_async_status()) return HPC_RLL_ETIMEOUT;
     // dx may be NULL: the caller does not need the gradient of the layer-0 input (its S*B x I x 4H product is skipped)
     if (!x || !h0 || !c0 || !wx || !wh || !ln_gamma || !ws || !dh0 || !dc0 || !dwx || !dwh || !dbias ||
         !dln_gamma || !dln_beta)
@@ -752,7 +754,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
     float* seq_bufs[2] = {w.dseq_a, w.dseq_b};
     int flip = 0;
     PersistCfg pc{};
-    const bool persist = persist_cfg(B, H, 4 * H, &pc);
+    const bool persist = persist_cfg(B, H, 4 * H, &pc) && persist_bwd_ok(pc, st);
     const XchgLayout xl = xchg_layout(B, H);
     if (persist && hipMemsetAsync(w.xchg, 0, xl.total_words * sizeof(u64), st) != hipSuccess) return last_error();
     // weight / parameter gradients of layer l from its gate-gradient buffers, and (if `dxin`) d(layer input)
@@ -819,7 +821,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         }
     };
     WaveCfg wb{};
-    if (wave_bwd_shape_ok(S, B, H, L, persist_cu_count(), &wb) && w.dwave) {   // all layers in one launch (lstm_wave.hpp)
+    if (w.dwave && wave_bwd_ok(S, B, H, L, &wb, st)) {   // all layers in one launch (lstm_wave.hpp)
         const size_t words = 2 * wb.hx_words + wb.sx_words;
         if (hipMemsetAsync(w.xchg, 0, words * sizeof(u64), st) != hipSuccess) return last_error();
         const LayerWs& l0 = w.layer[0];
@@ -908,5 +910,43 @@ extern "C" int hpc_rll_gemm_f32(const float* A, const float* B, float* C, int M,
     if (!C || (K > 0 && (!A || !B))) return HPC_RLL_EINVAL;
     GemmArgs g{A, B, C, M, N, K, (long)a_sm, (long)a_sk, (long)b_sk, (long)b_sn, (long)ldc, accumulate};
     launch_gemm(g, (hipStream_t)stream);
+    return last_error();
+}
+
+// Sticky asynchronous status of the persistent LSTM kernels (see include/hpc_rll_hip.h).
+extern "C" int hpc_rll_async_error(void) { return hpc_rll::persist_async_status(); }
+
+extern "C" int hpc_rll_clear_async_error(void) {
+    using namespace hpc_rll;
+    PersistRuntime& r = persist_rt();
+    if (!persist_async_status()) return HPC_RLL_OK;
+    // residency was demonstrably not available in this deployment: the step kernels take over for good
+    r.disabled = true;
+    *(volatile unsigned*)r.host_status = 0u;
+    return HPC_RLL_OK;
+}
+
+// Test hook: launch a kernel that keeps every CU busy for ~`ms` milliseconds on `stream` (tests/test_lstm_gpu.py runs
+// the persistent LSTM on another stream meanwhile).  Not part of the operator set.
+namespace hpc_rll { namespace {
+__global__ __launch_bounds__(1024) void hog_kernel(long long ticks, unsigned* sink) {
+    extern __shared__ float hog_lds[];
+    const long long t0 = wall_clock64();
+    unsigned x = threadIdx.x;
+    while (wall_clock64() - t0 < ticks) x = x * 1664525u + 1013904223u;
+    hog_lds[threadIdx.x] = (float)x;
+    if (x == 0xdeadbeefu && sink) *sink = x;
+}
+} }
+extern "C" int hpc_rll_test_occupy_device(int ms, void* stream) {
+    using namespace hpc_rll;
+    if (ms < 0 || ms > 2000) return HPC_RLL_EINVAL;
+    const int cus = persist_cu_count();
+    if (cus <= 0) return HPC_RLL_EUNSUPPORTED;
+    const size_t lds = 96 * 1024;   // one workgroup per CU holds most of its LDS: a persistent kernel cannot co-reside
+    if (hipFuncSetAttribute((const void*)hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return last_error();
+    hipLaunchKernelGGL(hog_kernel, dim3(cus), dim3(1024), lds, (hipStream_t)stream, (long long)ms * 100000LL,
+                       (unsigned*)nullptr);   // wall_clock64 ticks at 100 MHz
     return last_error();
 }

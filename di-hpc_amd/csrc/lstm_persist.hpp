@@ -15,10 +15,17 @@
 //     Every poll round issues all of a thread's loads back to back, lanes read consecutive words (8 lanes per 64-byte
 //     sector), and buffers are double-buffered on the tag parity: a workgroup is at most one exchange ahead of the
 //     slowest, which has then finished reading the buffer being overwritten.
-//   * all workgroups must be co-resident: the grid is ceil(H/JW) <= 256 <= #CUs workgroups and LDS <= 144 KB, so on
-//     an otherwise idle device residency is guaranteed; waits are bounded (kSpinLimit polls ~ seconds) and trap
-//     rather than hang if that assumption is ever violated (e.g. several processes oversubscribing one GPU with
-//     large-H persistent kernels: hpc_rll_tune_set(3, 0) switches this path off).
+//   * all workgroups must be co-resident.  That is REQUESTED, not assumed:
+//       - at dispatch the runtime's own occupancy answer for the chosen instantiation
+//         (hipOccupancyMaxActiveBlocksPerMultiprocessor x the CU count of the CURRENT device) must cover the grid,
+//         otherwise the step kernels run;
+//       - persistent launches of one process are chained per device with an event, so two of them (different streams)
+//         never share the device half-resident;
+//       - waits are bounded (kSpinLimit polls ~ seconds).  A wave that gives up sets a device abort word, which every
+//         poll loop honours, writes a pinned HOST status word (system scope) and ENDS -- no trap, the HIP context
+//         survives.  The next LSTM entry point reports HPC_RLL_ETIMEOUT (like an asynchronous HIP error: the results of
+//         the call that timed out are invalid) until hpc_rll_clear_async_error(), which also switches the persistent
+//         paths off for the rest of the process.  Only another PROCESS holding CUs for seconds can cause that.
 // The saved-for-backward tensors (hw, gates, c, hseq, stats) are written exactly as the step-kernel path writes them,
 // so forward/backward paths can be mixed.
 #pragma once
@@ -26,7 +33,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 
+#include "hpc_rll_hip.h"
 #include "wave.hpp"
 
 namespace hpc_rll {
@@ -39,6 +50,25 @@ namespace {
 typedef unsigned long long u64;
 constexpr long kSpinLimit = 1L << 22;
 constexpr int kPersistMaxB = 4;
+
+// ---- bounded waits without a trap -------------------------------------------------------------------------------
+__device__ unsigned g_persist_abort = 0;                 // set by the first wave that gives up (sticky)
+__device__ unsigned* g_persist_host_status = nullptr;    // pinned host word, see PersistRuntime
+
+// one failed poll round: back off; every 1024 rounds look at the abort word / the limit
+__device__ __forceinline__ void persist_poll_failed(long& spins) {
+    if (__builtin_expect(((++spins) & 1023) == 0, 0)) {
+        if (__hip_atomic_load(&g_persist_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+            __builtin_amdgcn_endpgm();
+        if (spins >= kSpinLimit) {
+            __hip_atomic_store(&g_persist_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* hs = g_persist_host_status;
+            if (hs) __hip_atomic_store(hs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_endpgm();
+        }
+    }
+    __builtin_amdgcn_s_sleep(8);   // ~0.2 us, so that co-resident waves get the memory queue
+}
 
 __device__ __forceinline__ void xchg_put(u64* p, float v, uint32_t tag) {
     __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -92,8 +122,7 @@ __device__ __forceinline__ void xchg_get(const u64* base, const int (&idx)[NL], 
             if (poll_count && threadIdx.x == 0 && blockIdx.x == 0) *poll_count += (u64)(spins + 1) * 100;
             return;
         }
-        if (++spins > kSpinLimit) __builtin_trap();
-        __builtin_amdgcn_s_sleep(8);   // failed poll: back off (~0.2 us) so that co-resident waves get the memory queue
+        persist_poll_failed(spins);
     }
 }
 
@@ -580,16 +609,118 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(PersistBwd a) {
     }
 }
 
+// ---- host side of the residency protocol ----------------------------------------------------------------------
+constexpr int kMaxDevices = 64;
+struct PersistRuntime {
+    std::mutex mu;
+    unsigned* host_status = nullptr;      // hipHostMalloc'ed (mapped, portable): written by a wave that gave up
+    bool dev_ready[kMaxDevices] = {};     // g_persist_host_status set on that device
+    int cus[kMaxDevices] = {};
+    hipEvent_t chain[kMaxDevices] = {};   // last persistent launch on the device
+    bool chain_armed[kMaxDevices] = {};
+    std::map<std::tuple<int, const void*, size_t>, int> occupancy;   // (device, kernel, lds) -> blocks per CU
+    bool disabled = false;                // after a timeout was reported and cleared
+};
+inline PersistRuntime& persist_rt() {
+    static PersistRuntime* r = new PersistRuntime();
+    return *r;
+}
+inline int persist_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+    return dev;
+}
+// CU count of the CURRENT device (cached per device)
 inline int persist_cu_count() {
-    static int n = -1;
-    if (n < 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            v = 0;
-        n = v;
+    const int dev = persist_device();
+    if (dev < 0) return 0;
+    PersistRuntime& r = persist_rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        r.cus[dev] = v > 0 ? v : -1;
     }
-    return n;
+    return r.cus[dev] > 0 ? r.cus[dev] : 0;
+}
+// sticky asynchronous status: nonzero once any persistent kernel of this process gave up waiting
+inline int persist_async_status() {
+    PersistRuntime& r = persist_rt();
+    return (r.host_status && *(volatile unsigned*)r.host_status) ? HPC_RLL_ETIMEOUT : HPC_RLL_OK;
+}
+// May a persistent kernel be launched on `st` now?  Sets up the pinned status word / the device symbol on first use
+// (a synchronous copy: not possible while `st` is being captured into a graph -> the step kernels run that time).
+inline bool persist_runtime_ready(hipStream_t st) {
+    PersistRuntime& r = persist_rt();
+    if (r.disabled || persist_async_status()) return false;
+    const int dev = persist_device();
+    if (dev < 0) return false;
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.dev_ready[dev]) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    if (!r.host_status) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
+        r.host_status = (unsigned*)p;
+        *r.host_status = 0u;
+    }
+    void* dptr = nullptr;
+    if (hipHostGetDevicePointer(&dptr, r.host_status, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_persist_host_status), &dptr, sizeof(dptr)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipEventCreateWithFlags(&r.chain[dev], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    r.dev_ready[dev] = true;
+    return true;
+}
+// Does the runtime itself say that `blocks` workgroups of kernel `k` (256 threads, `lds` bytes) fit the device at once?
+template <class K> inline bool persist_resident(K k, int blocks, size_t lds) {
+    const int dev = persist_device();
+    const int cus = persist_cu_count();
+    if (dev < 0 || cus <= 0) return false;
+    PersistRuntime& r = persist_rt();
+    const auto key = std::make_tuple(dev, (const void*)k, lds);
+    {
+        std::lock_guard<std::mutex> lk(r.mu);
+        auto it = r.occupancy.find(key);
+        if (it != r.occupancy.end()) return (long)it->second * cus >= blocks;
+    }
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    std::lock_guard<std::mutex> lk(r.mu);
+    r.occupancy[key] = per_cu;
+    return (long)per_cu * cus >= blocks;
+}
+// Persistent launches of this process run one after the other on a device, whatever their streams.
+inline void persist_chain_before(hipStream_t st) {
+    const int dev = persist_device();
+    PersistRuntime& r = persist_rt();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (dev < 0 || hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.chain_armed[dev]) (void)hipStreamWaitEvent(st, r.chain[dev], 0);
+}
+inline void persist_chain_after(hipStream_t st) {
+    const int dev = persist_device();
+    PersistRuntime& r = persist_rt();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (dev < 0 || hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.dev_ready[dev] && hipEventRecord(r.chain[dev], st) == hipSuccess) r.chain_armed[dev] = true;
+}
+template <class K, class A> inline int persist_launch(K k, dim3 grid, size_t lds, const A& a, hipStream_t st) {
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    persist_chain_before(st);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    persist_chain_after(st);
+    return 0;
 }
 
 // HPC_RLL_LSTM_PROFILE=1: per-phase time of workgroup 0, printed after every layer (synchronises; debugging only)
@@ -631,20 +762,18 @@ inline bool persist_cfg(int B, int H, int row_floats /* per batch row staged in 
     if (g_lstm_jw == 2 || g_lstm_jw == 4) c.jw = c.jw > g_lstm_jw ? c.jw : g_lstm_jw;   // experiments: fewer, fatter workgroups
     c.nwg = (H + c.jw - 1) / c.jw;
     c.lds = ((size_t)4 * c.jw * H + (size_t)c.nb * row_floats + (size_t)c.nb * 8 * c.jw + 64 * c.nb + 64) * sizeof(float);
-    if (c.lds > 144 * 1024 || c.nwg > persist_cu_count() || c.nwg > 256) return false;
+    if (c.lds > 144 * 1024 || c.nwg > 256) return false;   // residency itself: persist_fwd_ok / persist_bwd_ok
     *out = c;
     return true;
 }
 
 template <int NB, int JW>
 inline int launch_persist_fwd_t(const PersistCfg& c, const PersistFwd& a, hipStream_t st) {
-    auto k = lstm_persist_fwd_kernel<NB, JW>;
-    if (c.lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(k, dim3(c.nwg), dim3(256), c.lds, st, a);
-    return 0;
+    return persist_launch(lstm_persist_fwd_kernel<NB, JW>, dim3(c.nwg), c.lds, a, st);
+}
+template <int NB, int JW>
+inline int resident_persist_fwd_t(const PersistCfg& c, const PersistFwd&, hipStream_t) {
+    return persist_resident(lstm_persist_fwd_kernel<NB, JW>, c.nwg, c.lds) ? 1 : 0;
 }
 
 #define HPC_RLL_PERSIST_DISPATCH(FN, c, a, st)                                         \
@@ -670,16 +799,30 @@ inline int launch_persist_fwd(const PersistCfg& c, const PersistFwd& a, hipStrea
 
 template <int NB, int JW>
 inline int launch_persist_bwd_t(const PersistCfg& c, const PersistBwd& a, hipStream_t st) {
-    auto k = lstm_persist_bwd_kernel<NB, JW>;
-    if (c.lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(k, dim3(c.nwg), dim3(256), c.lds, st, a);
-    return 0;
+    return persist_launch(lstm_persist_bwd_kernel<NB, JW>, dim3(c.nwg), c.lds, a, st);
 }
 inline int launch_persist_bwd(const PersistCfg& c, const PersistBwd& a, hipStream_t st) {
     HPC_RLL_PERSIST_DISPATCH(launch_persist_bwd_t, c, a, st);
+}
+template <int NB, int JW>
+inline int resident_persist_bwd_t(const PersistCfg& c, const PersistBwd&, hipStream_t) {
+    return persist_resident(lstm_persist_bwd_kernel<NB, JW>, c.nwg, c.lds) ? 1 : 0;
+}
+// The persistent kernels may run for this shape NOW: runtime set up, no pending async failure, and the runtime's own
+// occupancy figure covers the grid.
+inline int persist_fwd_resident_i(const PersistCfg& c, hipStream_t st) {
+    const PersistFwd a{};
+    HPC_RLL_PERSIST_DISPATCH(resident_persist_fwd_t, c, a, st);
+}
+inline int persist_bwd_resident_i(const PersistCfg& c, hipStream_t st) {
+    const PersistBwd a{};
+    HPC_RLL_PERSIST_DISPATCH(resident_persist_bwd_t, c, a, st);
+}
+inline bool persist_fwd_ok(const PersistCfg& c, hipStream_t st) {
+    return persist_runtime_ready(st) && persist_fwd_resident_i(c, st) == 1;
+}
+inline bool persist_bwd_ok(const PersistCfg& c, hipStream_t st) {
+    return persist_runtime_ready(st) && persist_bwd_resident_i(c, st) == 1;
 }
 
 // Exchange buffers in the workspace: a "big" region (forward: h, B*H words; backward: dHW, B*4H words) and a "sums"

@@ -74,8 +74,7 @@ __device__ __forceinline__ void wave_poll(const u64* src1, int n1, const u64* sr
             }
         }
         if (ok) return;
-        if (++spins > kSpinLimit) __builtin_trap();
-        __builtin_amdgcn_s_sleep(8);
+        persist_poll_failed(spins);
     }
 }
 
@@ -318,13 +317,9 @@ struct WaveCfg { int nb, jw, nwg; size_t lds; size_t hx_words, sx_words; };
 
 template <int NB, int JW, bool PARG>
 inline int launch_wave_fwd_k(const WaveCfg& c, const WaveFwd& a, hipStream_t st) {
-    auto k = lstm_wave_fwd_kernel<NB, JW, PARG>;
-    if (c.lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(k, dim3(c.nwg, a.L), dim3(256), c.lds, st, a);
-    return 0;
+    if (a.S < 0)   // residency query (see wave_fwd_resident): 1 = the runtime's occupancy figure covers the grid
+        return persist_resident(lstm_wave_fwd_kernel<NB, JW, PARG>, c.nwg * a.L, c.lds) ? 1 : 0;
+    return persist_launch(lstm_wave_fwd_kernel<NB, JW, PARG>, dim3(c.nwg, a.L), c.lds, a, st);
 }
 // Bulk gathers (2*B*H >= 1024 words, i.e. >= 4 per thread) fetch a poll's words together, small ones one after the
 // other.  Only the JW >= 4 kernels (H > 170 at L = 3) get the second instantiation: below that the gather is small.
@@ -350,8 +345,11 @@ inline int launch_wave_fwd(const WaveCfg& c, const WaveFwd& a, hipStream_t st) {
 // occupancy the runtime reports; so the path is taken only if some JW in {1,2,4,6,8} gives every one of the L*nwg
 // workgroups its own CU -- then the launch is co-resident by construction.  `cus` = 256 for workspace sizing.
 constexpr size_t kWaveMaxWords = (size_t)8 << 20;   // 64 MB of tagged exchange slots
-inline bool wave_shape_ok(int S, int B, int H, int L, int cus, WaveCfg* out) {
-    if (!g_lstm_wave || !g_lstm_persist || L < 2 || S < 1 || B < 1 || B > 4 || H < 1 || H > 1024) return false;
+// `sizing` (workspace layout): the answer must not depend on run-time switches, or forward and backward of one call
+// pair could carve the workspace differently.
+inline bool wave_shape_ok(int S, int B, int H, int L, int cus, WaveCfg* out, bool sizing = false) {
+    if (!sizing && (!g_lstm_wave || !g_lstm_persist)) return false;
+    if (L < 2 || S < 1 || B < 1 || B > 4 || H < 1 || H > 1024) return false;
     WaveCfg c;
     c.nb = B <= 1 ? 1 : B <= 2 ? 2 : 4;
     c.jw = 0;
@@ -367,8 +365,13 @@ inline bool wave_shape_ok(int S, int B, int H, int L, int cus, WaveCfg* out) {
     *out = c;
     return true;
 }
-inline bool wave_fwd_ok(int S, int B, int H, int L, WaveCfg* out) {
-    const bool ok = wave_shape_ok(S, B, H, L, persist_cu_count(), out);
+inline bool wave_fwd_ok(int S, int B, int H, int L, WaveCfg* out, hipStream_t st) {
+    bool ok = wave_shape_ok(S, B, H, L, persist_cu_count(), out) && persist_runtime_ready(st);
+    if (ok) {   // the runtime's own occupancy figure for the chosen instantiation must cover all L*nwg workgroups
+        WaveFwd q{};
+        q.S = -1; q.B = B; q.H = H; q.L = L;
+        ok = launch_wave_fwd(*out, q, st) == 1;
+    }
     if (getenv("HPC_RLL_LSTM_PROFILE"))
         fprintf(stderr, "[lstm wave] S=%d B=%d H=%d L=%d -> %s (jw=%d, %d workgroups per layer)\n", S, B, H, L,
                 ok ? "wavefront" : "per-layer kernels", ok ? out->jw : 0, ok ? out->nwg : 0);
@@ -644,13 +647,9 @@ __global__ __launch_bounds__(256) void lstm_wave_bwd_kernel(WaveBwd a) {
 
 template <int NB, int JW>
 inline int launch_wave_bwd_t(const WaveCfg& c, const WaveBwd& a, hipStream_t st) {
-    auto k = lstm_wave_bwd_kernel<NB, JW>;
-    if (c.lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(k, dim3(c.nwg, a.L), dim3(256), c.lds, st, a);
-    return 0;
+    if (a.S < 0)   // residency query (see wave_bwd_resident)
+        return persist_resident(lstm_wave_bwd_kernel<NB, JW>, c.nwg * a.L, c.lds) ? 1 : 0;
+    return persist_launch(lstm_wave_bwd_kernel<NB, JW>, dim3(c.nwg, a.L), c.lds, a, st);
 }
 inline int launch_wave_bwd(const WaveCfg& c, const WaveBwd& a, hipStream_t st) {
 #define HPC_RLL_WAVE_RUN(JW_)                                               \
@@ -665,9 +664,9 @@ inline int launch_wave_bwd(const WaveCfg& c, const WaveBwd& a, hipStream_t st) {
 }
 
 // backward eligibility: the forward rule plus the backward's LDS footprint and exchange storage
-inline bool wave_bwd_shape_ok(int S, int B, int H, int L, int cus, WaveCfg* out) {
+inline bool wave_bwd_shape_ok(int S, int B, int H, int L, int cus, WaveCfg* out, bool sizing = false) {
     WaveCfg c;
-    if (!wave_shape_ok(S, B, H, L, cus, &c)) return false;
+    if (!wave_shape_ok(S, B, H, L, cus, &c, sizing)) return false;
     // two layers of a wide LSTM: the doubled gather (dHW_l and dXW_{l+1}, 2*B*4H words per step) costs more than
     // halving the number of dependent steps saves (measured L=2, H=512: 2.0 ms per-layer vs 2.2 ms wavefront)
     if (L < 3 && H > 256) return false;
@@ -678,6 +677,13 @@ inline bool wave_bwd_shape_ok(int S, int B, int H, int L, int cus, WaveCfg* out)
     if (2 * c.hx_words + c.sx_words > kWaveMaxWords || c.lds > 144 * 1024) return false;
     *out = c;
     return true;
+}
+
+inline bool wave_bwd_ok(int S, int B, int H, int L, WaveCfg* out, hipStream_t st) {
+    if (!wave_bwd_shape_ok(S, B, H, L, persist_cu_count(), out) || !persist_runtime_ready(st)) return false;
+    WaveBwd q{};
+    q.S = -1; q.B = B; q.H = H; q.L = L;
+    return launch_wave_bwd(*out, q, st) == 1;
 }
 
 }  // namespace

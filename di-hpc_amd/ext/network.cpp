@@ -321,6 +321,14 @@ PYBIND11_MODULE(hpc_torch_utils_network, m) {
     m.def("lstm_workspace", [](int64_t S, int64_t B, int64_t I, int64_t H, int64_t L, double dropout, const at::Device& dev) {
         return new_f32({lstm_ws_floats(LstmDims{S, B, I, H, L, dev}, dropout)}, dev);
     });
+    m.def("async_error", []() { return hpc_rll_async_error(); },
+          "sticky status of the persistent small-batch LSTM kernels: 0, or HPC_RLL_ETIMEOUT (-4) once one gave up waiting");
+    m.def("clear_async_error", []() { check(hpc_rll_clear_async_error(), "hpc_rll_clear_async_error"); },
+          "acknowledge a timeout; the process continues on the step kernels");
+    m.def("_test_occupy_device", [](int ms, const at::Device& dev) {
+        c10::DeviceGuard g(dev);
+        check(hpc_rll_test_occupy_device(ms, stream_of(dev)), "hpc_rll_test_occupy_device");
+    }, "test hook: keep every CU of `dev` busy for ~ms milliseconds on torch's current stream");
     m.def("gemm_f32", &gemm_f32, py::arg("a"), py::arg("b"), py::arg("out") = py::none(), py::arg("accumulate") = false);
 
     m.def("lstm", [](const Tensor& x, const Tensor& wx, const Tensor& wh, const Tensor& bias, const Tensor& gamma,

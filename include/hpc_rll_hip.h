@@ -31,6 +31,7 @@ extern "C" {
 #define HPC_RLL_EINVAL (-1)     /* bad size / null pointer                      */
 #define HPC_RLL_EALIGN (-2)     /* pointer not 4-byte aligned                   */
 #define HPC_RLL_EUNSUPPORTED (-3) /* shape outside what the kernels implement   */
+#define HPC_RLL_ETIMEOUT (-4)   /* a persistent LSTM kernel gave up waiting for its co-resident workgroups */
 
 /* ABI version, bumped on any signature change. */
 int hpc_rll_abi_version(void);
@@ -257,6 +258,18 @@ int hpc_rll_lstm_backward(const float* dy, const float* dhn, const float* dcn, c
                           float* dx, float* dh0, float* dc0, float* dwx, float* dwh, float* dbias, float* dln_gamma,
                           float* dln_beta, int S, int B, int I, int H, int L, float dropout_p, uint64_t seed,
                           void* stream);
+/* Asynchronous status of the persistent small-batch LSTM kernels (B <= 4).  Their workgroups exchange data through
+ * memory and must all be resident at once; that is checked against the runtime's occupancy figure at dispatch and
+ * launches of one process are serialised per device, but ANOTHER PROCESS holding compute units for seconds can still
+ * starve one.  The kernel then gives up (no trap, no hang), and -- like an asynchronous HIP error -- every later
+ * hpc_rll_lstm_* call returns HPC_RLL_ETIMEOUT (the results of the launch that timed out are invalid) until
+ * hpc_rll_clear_async_error(), after which the process uses the step kernels only.  hpc_rll_async_error() reads the
+ * status without touching the device. */
+int hpc_rll_async_error(void);
+int hpc_rll_clear_async_error(void);
+/* Test hook, not an operator: occupy every compute unit (one 1024-thread workgroup holding 96 KB of LDS per CU) for
+ * ~ms milliseconds on `stream`. */
+int hpc_rll_test_occupy_device(int ms, void* stream);
 /* Exact-fp32 MFMA GEMM used by the LSTM, exposed for tests/benchmarks: C (M,N; row stride ldc) (+)= A * B with
  * A(m,k) = A[m*a_sm + k*a_sk], B(k,n) = B[k*b_sk + n*b_sn]. */
 int hpc_rll_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_sm, int64_t a_sk,

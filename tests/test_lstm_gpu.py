@@ -293,3 +293,54 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
         for got in (b, b2):
             assert np.isfinite(got).all(), k
             assert rel_err(o, got) < max(base, 2.0 * rel_err(o, a)), (k, rel_err(o, got), rel_err(o, a))
+
+
+@pytest.mark.parametrize("S,B,I,H,L", [(24, 3, 64, 384, 1), (16, 3, 48, 96, 3), (12, 4, 32, 512, 2)])   # per-layer / wavefront / mixed
+def test_persistent_lstm_survives_a_busy_device(S, B, I, H, L):
+    """VERDICT r01 item 5.  The persistent kernels need all their workgroups resident at once.  (a) A kernel that holds
+    EVERY compute unit (96 KB of LDS per CU) for ~150 ms runs on a second stream while the B <= 4 LSTM forward+backward
+    is issued on the main stream: the persistent workgroups cannot co-reside with it, they wait, and the results equal
+    the quiet run bit for bit -- no trap (there is none any more), no asynchronous error.  (b) Two LSTMs on two streams at
+    once: persistent launches of one process are chained per device, results equal the sequential run."""
+    import hpc_torch_utils_network as NW
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(S + H)
+    m = LSTM(S, B, I, H, L).to(DEV)
+    x = torch.randn(S, B, I, device=DEV)
+    gy = torch.randn(S, B, H, device=DEV)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y, (hn, cn) = m(xi, None)
+        ((y * gy).sum() + hn.sum() - cn.sum()).backward()
+        return [y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+
+    quiet = run()
+    torch.cuda.synchronize()
+    assert NW.async_error() == 0
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        NW._test_occupy_device(150, DEV)
+    busy = run()
+    torch.cuda.synchronize()
+    assert NW.async_error() == 0
+    for a, b in zip(quiet, busy):
+        assert torch.equal(a, b)
+    # (b) two streams at once
+    m2 = LSTM(S, B, I, H, L).to(DEV)
+    m2.load_state_dict(m.state_dict())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            y1, _ = m(x, None)
+        with torch.cuda.stream(s2):
+            y2, _ = m2(x, None)
+        outs.append((y1, y2))
+    torch.cuda.synchronize()
+    assert NW.async_error() == 0
+    for y1, y2 in outs:
+        assert torch.equal(y1.detach(), quiet[0]) and torch.equal(y2.detach(), quiet[0])
