@@ -17,7 +17,7 @@ import re
 import torch  # noqa: F401  (must precede the dlopen below, see docstring)
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_ROOT, "di-hpc_amd", "hpc_rll", "_lib", "libhpc_rll_hip.so")
+LIB_PATH = os.environ.get("HPC_RLL_LIB") or os.path.join(_ROOT, "di-hpc_amd", "hpc_rll", "_lib", "libhpc_rll_hip.so")  # env: kernel A/B tools
 HEADER_PATH = os.path.join(_ROOT, "include", "hpc_rll_hip.h")
 
 if not os.path.exists(LIB_PATH):

@@ -8,8 +8,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
-from hpc_rll import _native as N  # noqa: E402
+import cabi as N  # noqa: E402
 
 T = int(os.environ.get("TUNE_T", 1024))
 B = int(os.environ.get("TUNE_B", 65536))

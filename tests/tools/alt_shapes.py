@@ -4,8 +4,9 @@ candidate set, in the alternating fwd/bwd pattern (see alt_gae.py).  Prints one 
 import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from hpc_rll import _native as N
+import cabi as N
 lib = N.lib
 dev = torch.device("cuda:0")
 s = torch.cuda.current_stream().cuda_stream

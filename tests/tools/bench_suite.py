@@ -10,7 +10,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
+import cabi  # noqa: E402
 
 dev = torch.device("cuda:0")
 HBM, MFMA_F32 = 8000.0, 157.3   # GB/s, TFLOP/s (MI355X_MICROARCH.md)
@@ -175,7 +177,7 @@ def suite_c5(B=4096, M=256, N=64, H=64, W=64):
     rows.append(dict(op="unpad1d_python_api", shape=f"n={n}", fwd_ms=t_un * 1e3, note="list-of-tensors API incl. host table build"))
     print(json.dumps(rows[-1]), flush=True)
     mx = int(lens.max())
-    t_k = timed(lambda: U.N.call("hpc_rll_pad_forward", dev, table.data_ptr(), new_x.data_ptr(), mask.data_ptr(), n, 1, 1, mx, 0), n=5)
+    t_k = timed(lambda: cabi.call("hpc_rll_pad_forward", dev, table.data_ptr(), new_x.data_ptr(), mask.data_ptr(), n, 1, 1, mx, 0), n=5)
     report("pad1d_kernel", f"n={n} len~U[32,128)", t_k, 4 * int(lens.sum()) + 8 * n * mx)
     n1m = 1 << 20
     lens1m = torch.from_numpy(np.random.default_rng(1).integers(32, 128, n1m)).to(dev)

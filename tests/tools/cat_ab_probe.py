@@ -6,8 +6,9 @@ import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
-import hpc_rll._native as N  # noqa: E402
+import cabi as N  # noqa: E402
 alt = ctypes.CDLL(os.environ.get("ALT", os.path.join(ROOT, "tests", "tools", "micro", "libcat_old.so")))
 for name in ("hpc_rll_categorical_forward", "hpc_rll_categorical_backward"):
     getattr(alt, name).argtypes = N.SIGNATURES[name][1]

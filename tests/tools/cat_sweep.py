@@ -3,10 +3,12 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import hpc_rl_utils as U
+import cabi  # noqa: E402
 dev = torch.device("cuda:0")
-lib, s = U.N.lib, U.N.stream_ptr(dev)
+lib, s = cabi.lib, cabi.stream_ptr(dev)
 def t(fn, n=5):
     fn(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

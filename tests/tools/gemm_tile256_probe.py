@@ -5,8 +5,9 @@ import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
-import hpc_rll._native as N  # noqa: E402
+import cabi as N  # noqa: E402
 import hpc_torch_utils_network as U  # noqa: E402
 from hpc_rll.torch_utils.network.rnn import LSTM  # noqa: E402
 dev = torch.device("cuda:0")

@@ -4,6 +4,7 @@ import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 import hpc_torch_utils_network as U  # noqa: E402
 dev = torch.device("cuda:0")
@@ -32,11 +33,11 @@ for name, M, N, K, lay in shapes:
     outs = {}
     for rnd in range(3):
         for x in (1, 0):
-            assert U.N.lib.hpc_rll_tune_set(10, x) == 0
+            assert cabi.lib.hpc_rll_tune_set(10, x) == 0
             dt = t(lambda: U.gemm_f32(A, Bm, out=c))
             best[x] = min(best.get(x, 1e9), dt)
             outs[x] = c.clone()
     assert torch.equal(outs[0], outs[1])
     print(f"{name:7s} M={M} N={N} K={K}: xcd-aware {2.0*M*N*K/best[1]/1e12:6.1f} TF   plain {2.0*M*N*K/best[0]/1e12:6.1f} TF", flush=True)
     del a, b, c, A, Bm
-U.N.lib.hpc_rll_tune_set(10, 1)
+cabi.lib.hpc_rll_tune_set(10, 1)

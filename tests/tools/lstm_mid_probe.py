@@ -4,11 +4,12 @@ import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 from hpc_rll.torch_utils.network.rnn import LSTM  # noqa: E402
 
 dev = torch.device("cuda:0")
-import hpc_rll._native as N  # noqa: E402
+import cabi as N  # noqa: E402
 N.check(N.lib.hpc_rll_tune_set(5, int(os.environ.get('JW', '0'))))
 N.check(N.lib.hpc_rll_tune_set(8, int(os.environ.get('WAVE', '1'))))
 SHAPES = [(64, 3, 1792, 384, 3), (64, 16, 512, 512, 1), (64, 64, 512, 512, 1), (64, 256, 512, 512, 2), (32, 64, 256, 256, 1)]

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-import hpc_rll._native as N  # noqa: E402
+import cabi as N  # noqa: E402
 from hpc_rll.torch_utils.network.rnn import LSTM  # noqa: E402
 from oracle import ref_torch as R  # noqa: E402
 from conftest import rel_err  # noqa: E402

@@ -1,5 +1,6 @@
 import sys, os
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"), "di-hpc_amd"))
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"), "tests"))
 import torch
 import hpc_torch_utils_network as U
 dev=torch.device("cuda:0")
@@ -12,7 +13,7 @@ B,N,H,W=4096,64,64,64
 out=torch.empty(B,N,H,W,device=dev)
 import itertools
 for tpb, M in itertools.product((256,512,1024),(16,256)):
-    assert U.N.lib.hpc_rll_tune_set(2, tpb) == 0
+    assert cabi.lib.hpc_rll_tune_set(2, tpb) == 0
     x=torch.randn(B,M,N,device=dev); loc=torch.stack([torch.randint(0,H,(B,M),device=dev),torch.randint(0,W,(B,M),device=dev)],-1)
     for st in ("cover","add"):
         dt=t(lambda: U.ScatterConnectionForward([x,loc],[out],st))

@@ -3,8 +3,10 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import hpc_rl_utils as U
+import cabi  # noqa: E402
 dev = torch.device("cuda:0")
 rows, N = 256 * 16384, int(os.environ.get("N", 128))
 g = torch.Generator(device=dev).manual_seed(0)
@@ -13,7 +15,7 @@ x2 = torch.randn(rows, N, device=dev, generator=g)
 a = torch.randint(0, N, (rows,), device=dev, generator=g)
 lp, ent, c1 = torch.empty(rows, device=dev), torch.empty(rows, device=dev), torch.randn(rows, device=dev)
 grad = torch.empty(rows, N, device=dev)
-lib, s = U.N.lib, U.N.stream_ptr(dev)
+lib, s = cabi.lib, cabi.stream_ptr(dev)
 def t(fn, n=6):
     fn(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -7,8 +7,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 import hpc_rl_utils as U  # noqa: E402
+import cabi  # noqa: E402
 
 T = int(os.environ.get("TUNE_T", 1024))
 B = int(os.environ.get("TUNE_B", 65536))
@@ -19,7 +21,7 @@ r = torch.randn(T, B, device=dev, generator=g)
 ga = torch.randn(T, B, device=dev, generator=g)
 adv, gv, gr = torch.empty_like(r), torch.empty_like(v), torch.empty_like(r)
 coef = U.gae_coef(T, 0.99, 0.97, dev)
-lib, s = U.N.lib, U.N.stream_ptr(dev)
+lib, s = cabi.lib, cabi.stream_ptr(dev)
 BYTES = 12 * T * B + 4 * B
 
 

@@ -3,6 +3,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import hpc_torch_utils_network as U
 dev = torch.device("cuda:0")
@@ -14,7 +15,7 @@ def t(fn, n=5):
 shapes = [("NN rec", 4096, 4096, 1024, "nn"), ("NT dh", 4096, 1024, 4096, "nt"), ("NN xw", 65536, 4096, 1024, "nn"),
           ("TN dW", 1024, 4096, 65536, "tn"), ("NT dx", 65536, 1024, 4096, "nt"), ("NN sq", 4096, 4096, 4096, "nn")]
 for bk in (32, 16):
-    assert U.N.lib.hpc_rll_tune_set(1, bk) == 0
+    assert cabi.lib.hpc_rll_tune_set(1, bk) == 0
     for name, M, N, K, lay in shapes:
         a = torch.randn(M, K, device=dev); b = torch.randn(K, N, device=dev)
         A = a if lay != "tn" else a.t().contiguous().t()
