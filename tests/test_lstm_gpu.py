@@ -3,8 +3,8 @@
 LSTM: golden fixtures recorded from the real reference (hpc_rll.origin.rnn.LSTM, autograd gradients w.r.t. every
 input and parameter, INCLUDING gradients that enter through the returned final states) and the fp64 oracle at the
 reference test shape (tests/test_lstm.py:10-16: S=64, B=3, in=1792, H=384, L=3).
-Tolerances are FIXED and written at each assert: forward 2e-5 / gradients 2e-4 up to 12 recurrent steps, 1e-3 at the
-reference's 192-step test shape (where torch's own fp32 evaluation of the oracle is 3e-4 from fp64).
+Tolerances are FIXED and written at each assert: forward 2e-5 / gradients 2e-4 up to 12 recurrent steps; 2e-3 / 1e-2 at
+the reference's 192-step test shape (where torch's own fp32 evaluation of the oracle is 7.5e-3 from fp64 on dx).
 """
 import numpy as np
 import pytest
@@ -133,20 +133,28 @@ def test_lstm_oracle(S, B, I, H, L):
     gwh = m.wh.grad.cpu().numpy().reshape(L, H, 4 * H)
     for l in range(L):
         got[f"wx{l}"], got[f"wh{l}"] = gwx[l], gwh[l]
-    # FIXED tolerances per shape, max |ref - got| / max(1, |ref|) against the fp64 oracle.
-    # The recurrence through S*L LayerNorms amplifies fp32 rounding: at the reference's test shape (192 LayerNorm-
-    # recurrent steps) torch's own fp32 evaluation of the oracle is 3e-4 away from fp64 (printed below for context;
-    # tests/tools/r02_parity_probe.py -> profiles/r02_parity_probe.json: HIP 1.0e-4 / torch-fp32 1.3e-4 forward at that
-    # shape with the module's default init).  Shapes with <= 12 steps: 2e-5 forward (north_star: 1e-5 rel for returns;
-    # an LSTM output is 2 LayerNorms + 5 transcendental ops per step away from its inputs), 2e-4 gradients.
-    fwd_tol, grad_tol = (1e-3, 1e-3) if S * L >= 192 else (2e-5, 2e-4)
-    worst = {}
-    for k in got:
+    # FIXED tolerances per shape, max |ref - got| / max(1, |ref|) elementwise against the fp64 oracle.
+    # The recurrence through S*L LayerNorms amplifies fp32 rounding.  At the reference's test shape (192 LayerNorm-
+    # recurrent steps, random gamma/beta) torch's OWN fp32 evaluation of the oracle is 7.5e-3 away from fp64 on dx and
+    # the HIP kernels 3.7e-3 (measured, MI355X, this seed; gpurun_out/r02_lstm_oracle_errors.json holds every key of the
+    # last run): bounds 2e-3 forward / 1e-2 gradients there.  Shapes with <= 12 steps: 2e-5 forward (north_star: 1e-5
+    # rel for returns; an LSTM output is 2 LayerNorms + 5 transcendental ops per step away from its inputs), 2e-4 grads.
+    fwd_tol, grad_tol = (2e-3, 1e-2) if S * L >= 192 else (2e-5, 2e-4)
+    worst = {k: (rel_err(o64[k], got[k]), rel_err(o64[k], o32[k])) for k in got}
+    _record_errors(f"lstm_oracle S={S} B={B} I={I} H={H} L={L}", worst)
+    for k, (e, e32) in worst.items():
         tol = fwd_tol if k in ("y", "hn", "cn") else grad_tol
-        e = rel_err(o64[k], got[k])
-        worst[k] = (e, rel_err(o64[k], o32[k]))
-        assert e < tol, (k, e, tol, "fp32 oracle:", worst[k][1])
-    print("lstm_oracle", (S, B, I, H, L), {k: f"{a:.1e} (torch fp32 {b:.1e})" for k, (a, b) in worst.items()})
+        assert e < tol, (k, e, tol, "torch fp32 evaluation of the oracle:", e32)
+
+
+def _record_errors(name, worst):
+    """Append the measured errors (HIP vs fp64, torch-fp32 vs fp64) to gpurun_out/ when running under gpurun."""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "r02_lstm_oracle_errors.json"), "a") as f:
+            f.write(json.dumps({"case": name, "err": {k: {"hip": a, "torch_fp32": b} for k, (a, b) in worst.items()}}) + "\n")
 
 
 def test_lstm_reference_usage_pattern():

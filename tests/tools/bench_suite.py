@@ -172,7 +172,7 @@ def suite_c5(B=4096, M=256, N=64, H=64, W=64):
     xs = list(torch.split(flat, [int(v) for v in lens]))
     new_x, mask, shapes = P.Padding1D(xs)
     import hpc_rl_utils as U
-    table = U._device_table([[t.data_ptr(), 1, 1, t.shape[0]] for t in xs], dev)
+    table = torch.tensor([[t.data_ptr(), 1, 1, t.shape[0]] for t in xs], dtype=torch.int64).to(dev)
     t_un = timed(lambda: P.UnPadding1D(new_x, shapes), n=1, rounds=2)
     rows.append(dict(op="unpad1d_python_api", shape=f"n={n}", fwd_ms=t_un * 1e3, note="list-of-tensors API incl. host table build"))
     print(json.dumps(rows[-1]), flush=True)
