@@ -215,35 +215,44 @@ __global__ __launch_bounds__(256) void packed_table_kernel(const int64_t* __rest
 
 // ------------------------------------------------------------------------------------------------ scatter
 // idx layout per b (int32): [head HW | last HW | next M]
+// One workgroup per b walks the entities in chunks of 256 in ascending m.  Entity m finds its predecessor at the same
+// cell among the earlier lanes of its chunk (LDS scan) or, failing that, in last[cell] as left by the earlier chunks
+// (this workgroup is the only writer of its b); it links next[prev] = m, or becomes head[cell].  last[cell] = max m
+// (integer atomicMax: deterministic).  O(M * 256) instead of the first version's O(M^2) pair scan, 1 KB of LDS
+// whatever M is (M ~ 1e4 entities per map).
 __global__ __launch_bounds__(256) void scatter_index_kernel(const int64_t* __restrict__ location,
                                                             int32_t* __restrict__ idx, int M, int H, int W) {
-    extern __shared__ int32_t s_cell[];  // M cell ids
+    __shared__ int32_t s_cell[256];
     const int b = blockIdx.x;
     const int HW = H * W;
     const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
-    int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
-    int32_t* __restrict__ last = head + HW;
-    int32_t* __restrict__ next = last + HW;
-    for (int m = threadIdx.x; m < M; m += 256) {
-        const long y = loc[2 * m], x = loc[2 * m + 1];
-        // out-of-range locations are dropped (the reference would write out of bounds)
-        s_cell[m] = (y >= 0 && y < H && x >= 0 && x < W) ? (int32_t)(y * W + x) : -1;
-    }
+    int32_t* head = idx + (size_t)b * (2 * HW + M);
+    int32_t* last = head + HW;
+    int32_t* next = last + HW;
     for (int c = threadIdx.x; c < HW; c += 256) { head[c] = -1; last[c] = -1; }
+    for (int m = threadIdx.x; m < M; m += 256) next[m] = -1;
     __syncthreads();
-    for (int m = threadIdx.x; m < M; m += 256) {
-        const int32_t c = s_cell[m];
-        int32_t nx = -1;
-        bool first = true;
-        if (c >= 0) {
-            for (int k = m + 1; k < M; ++k)
-                if (s_cell[k] == c) { nx = k; break; }
-            for (int k = m - 1; k >= 0; --k)
-                if (s_cell[k] == c) { first = false; break; }
-            if (first) head[c] = m;     // exactly one writer per cell
-            if (nx < 0) last[c] = m;    // exactly one writer per cell
+    for (int m0 = 0; m0 < M; m0 += 256) {
+        const int m = m0 + threadIdx.x;
+        int32_t c = -1;
+        if (m < M) {
+            const long y = loc[2 * m], x = loc[2 * m + 1];
+            // out-of-range locations are dropped (the reference would write out of bounds)
+            if (y >= 0 && y < H && x >= 0 && x < W) c = (int32_t)(y * W + x);
         }
-        next[m] = nx;
+        s_cell[threadIdx.x] = c;
+        const int32_t before = c >= 0 ? last[c] : -1;   // largest m of the EARLIER chunks at this cell
+        __syncthreads();
+        if (c >= 0) {
+            int32_t prev = -1;
+            for (int k = (int)threadIdx.x - 1; k >= 0; --k)
+                if (s_cell[k] == c) { prev = m0 + k; break; }
+            if (prev < 0) prev = before;
+            if (prev >= 0) next[prev] = m;   // exactly one writer per slot
+            else head[c] = m;                // exactly one writer per cell
+            atomicMax(&last[c], m);
+        }
+        __syncthreads();   // the next chunk reads last[] (global memory written by this workgroup: barrier + L1 write-through)
     }
 }
 
@@ -337,6 +346,77 @@ __global__ __launch_bounds__(1024) void scatter_out4_kernel(const float* __restr
     }
 }
 
+// LDS-staged output kernel (round 2).  Workgroup = (b, group of NPB channels): x[b, :, n0:n0+NPB] (M rows) and the cell
+// owner table are staged in LDS once, then the workgroup's output -- NPB consecutive planes of out[b], ONE contiguous
+// span of NPB*HW floats -- is cut into 16 contiguous pieces, one per wave, written front to back with 16-byte
+// nontemporal stores: every wave streams tens of KiB of consecutive addresses (tests/tools/micro/writebw.hip: 5.5 TB/s
+// with 64 KiB contiguous per wave against 5.1 with 1 KiB pieces strided by the plane size, which is what
+// scatter_out4_kernel issues).  Per float4 of output: one 16-byte LDS read of the four owners, four 4-byte LDS gathers
+// from the padded x tile (row stride NPB+1: conflict-free for distinct m), `add` walks the chain in ascending m.
+// Needs HW % 4 == 0, 16-byte aligned x/out, HW ints + M*(NPB+1) floats of LDS.
+template <bool ADD>
+__global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __restrict__ x,
+                                                              const int32_t* __restrict__ idx,
+                                                              float* __restrict__ out, int M, int N, int HW, int npb) {
+    extern __shared__ float s_dyn[];
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * npb;
+    const int nn = min(npb, N - n0);                       // channels of this workgroup
+    const int ld = npb + 1;
+    float* xs = s_dyn;                                     // [M][ld]
+    int32_t* s_first = reinterpret_cast<int32_t*>(s_dyn + (((size_t)M * ld + 3) & ~(size_t)3));   // [HW] head (add) / last (cover), 16-byte aligned
+    int32_t* s_next = s_first + HW;                        // [M]   (add only)
+    const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
+    const int32_t* __restrict__ first_g = ADD ? head : head + HW;
+    const int32_t* __restrict__ next_g = head + 2 * HW;
+    const float* __restrict__ xb = x + (size_t)b * M * N + n0;
+    // ---- stage: owner table (16-byte loads), chain links, the x tile (float4 along the channels when aligned)
+    for (int c = threadIdx.x; c < HW; c += 1024) s_first[c] = first_g[c];
+    if (ADD)
+        for (int m = threadIdx.x; m < M; m += 1024) s_next[m] = next_g[m];
+    if ((nn & 3) == 0 && (N & 3) == 0 && (n0 & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const int q = nn >> 2;                             // float4 per row
+        for (int e = threadIdx.x; e < M * q; e += 1024) {
+            const int m = e / q, j = e - m * q;
+            const vfloat4 t = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(xb + (size_t)m * N) + j);
+            float* d = xs + m * ld + 4 * j;
+            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+        }
+    } else {
+        for (int e = threadIdx.x; e < M * nn; e += 1024) {
+            const int m = e / nn, j = e - m * nn;
+            xs[m * ld + j] = xb[(size_t)m * N + j];
+        }
+    }
+    __syncthreads();
+    // ---- stream the span: wave w writes float4 units [w*per, (w+1)*per) of the nn*HW/4 units of this workgroup
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hw4 = HW >> 2;
+    const long units = (long)nn * hw4;
+    const long per = (units + 15) / 16;
+    const long u0 = wave * per, u1 = min(units, u0 + per);
+    vfloat4* __restrict__ ob = reinterpret_cast<vfloat4*>(out + ((size_t)b * N + n0) * HW);
+    for (long u = u0 + lane; u < u1; u += 64) {
+        const int n = (int)(u / hw4);
+        const int cell = (int)(u - (long)n * hw4) << 2;
+        const int4 f = *reinterpret_cast<const int4*>(s_first + cell);
+        const int32_t fi[4] = {f.x, f.y, f.z, f.w};
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = 0.f;
+            if (fi[c] >= 0) {
+                a = xs[fi[c] * ld + n];
+                if (ADD)
+                    for (int32_t m = s_next[fi[c]]; m >= 0; m = s_next[m]) a += xs[m * ld + n];
+            }
+            v[c] = a;
+        }
+        const vfloat4 o = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(o, ob + u);
+    }
+}
+
 // backward: workgroup = (b, group of NG channels); stage NG planes of grad_out in LDS, gather per entity.
 // The planes are one contiguous span of grad_out: staged with nontemporal float4 loads, 1024 threads and up to
 // 128 KB per workgroup so that every thread has several 16-byte loads in flight (a pure read streams at 7 TB/s on this
@@ -390,7 +470,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __
 }  // namespace
 }  // namespace hpc_rll
 
-namespace hpc_rll { int g_scatter_threads = 1024; int g_scatter_bwd_lds_kb = 64; }
+namespace hpc_rll { int g_scatter_threads = 1024; int g_scatter_bwd_lds_kb = 64; int g_scatter_lds_fwd = 1; int g_scatter_npb = 0; }
 using namespace hpc_rll;
 
 extern "C" int hpc_rll_pad_forward(const int64_t* table, float* new_x, int32_t* mask, int64_t n, int m0, int m1,
@@ -590,14 +670,34 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     const long HW = (long)H * W;
     if ((size_t)B * N * HW == 0) return HPC_RLL_OK;
     if (!out || !ws || (M > 0 && (!x || !location))) return HPC_RLL_EINVAL;
-    if (HW >= (1L << 31) || (size_t)M * sizeof(int32_t) > 64 * 1024 || B > 65535) return HPC_RLL_EUNSUPPORTED;
+    if (HW >= (1L << 31) || B > 65535) return HPC_RLL_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(scatter_index_kernel, dim3(B), dim3(256), (size_t)M * sizeof(int32_t), st, location, ws, M, H,
-                       W);
+    hipLaunchKernelGGL(scatter_index_kernel, dim3(B), dim3(256), 0, st, location, ws, M, H, W);
     int rc = last_error();
     if (rc) return rc;
     const bool v4 = (HW % 4) == 0 && (N % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    // LDS-staged streaming kernel: the owner table (HW ints) and an M x NPB tile of x must fit in LDS with room for
+    // three workgroups per CU (so that one workgroup's staging overlaps the others' stores)
+    if (g_scatter_lds_fwd && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0 && B <= 65535 &&
+        (size_t)HW * 4 <= 32 * 1024) {
+        const size_t fixed = (size_t)HW * 4 + (add ? (size_t)M * 4 : 0);
+        int npb = 0;
+        static const int kNpb[5] = {64, 32, 16, 8, 4};
+        for (int i = 0; i < 5 && !npb; ++i) {
+            const int c = g_scatter_npb ? g_scatter_npb : kNpb[i];
+            if (c <= 64 && c >= 1 && (size_t)M * (c + 1) * 4 + 16 + fixed <= 52 * 1024) npb = c;
+            if (g_scatter_npb) break;
+        }
+        if (npb > N) npb = (N + 3) / 4 * 4;
+        if (npb >= 1 && (size_t)M * (npb + 1) * 4 + 16 + fixed <= 52 * 1024) {
+            const size_t lds = (((size_t)M * (npb + 1) + 3) & ~(size_t)3) * 4 + fixed;
+            const dim3 grid((N + npb - 1) / npb, B);
+            if (add) hipLaunchKernelGGL(scatter_out_lds_kernel<true>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb);
+            else hipLaunchKernelGGL(scatter_out_lds_kernel<false>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb);
+            return last_error();
+        }
+    }
     const int tpb = (v4 && HW >= 4096) ? g_scatter_threads : 256;   // threads per block of the 4-wide kernel
     const int cell_blocks = (int)((HW + (v4 ? 4 * tpb - 1 : 255)) / (v4 ? 4 * tpb : 256));
     // enough workgroups to cover the chip: split the channel axis when B * cell_blocks is small

@@ -53,9 +53,9 @@ struct TdLambdaOp {
 #pragma unroll
         for (int k = 0; k < V; ++k) carry[k] = vt.v[k];
     }
-    template <int V> __device__ void load(Row<V>& row, int t, long col, bool ok) const {
+    template <int V> __device__ void load(Row<V>& row, int t, long col, bool ok, bool next_in_regs) const {
         row.v0 = ldz<V>(value + (size_t)t * B + col, ok);
-        row.v1 = ldz<V>(value + (size_t)(t + 1) * B + col, ok);
+        if (!next_in_regs) row.v1 = ldz<V>(value + (size_t)(t + 1) * B + col, ok);
         row.r = ldz<V>(reward + (size_t)t * B + col, ok);
         if (weight_mode == 2) row.w = ldz<V>(weight + (size_t)t * B + col, ok);
         else if (weight_mode == 1) row.w = ldz<V>(weight + col, ok);
@@ -64,6 +64,7 @@ struct TdLambdaOp {
             for (int k = 0; k < V; ++k) row.w.v[k] = 1.f;
         }
     }
+    template <int V> __device__ void link(Row<V>& row, const Row<V>& nxt) const { row.v1 = nxt.v0; }
     template <int V> __device__ void coeffs(const Row<V>& row, int, float (&a)[V], float (&b)[V]) const {
 #pragma unroll
         for (int k = 0; k < V; ++k) { a[k] = disc; b[k] = fmaf(rest, row.v1.v[k], row.r.v[k]); }
@@ -100,10 +101,11 @@ struct VtraceOp {
 #pragma unroll
         for (int k = 0; k < V; ++k) carry[k] = 0.f;
     }
-    template <int V> __device__ void load(Row<V>& row, int t, long col, bool ok) const {
+    template <int V> __device__ void link(Row<V>& row, const Row<V>& nxt) const { row.v1 = nxt.v0; }
+    template <int V> __device__ void load(Row<V>& row, int t, long col, bool ok, bool next_in_regs) const {
         const size_t o = (size_t)t * B + col;
         row.v0 = ldz<V>(value + o, ok);
-        row.v1 = ldz<V>(value + o + B, ok);
+        if (!next_in_regs) row.v1 = ldz<V>(value + o + B, ok);
         row.r = ldz<V>(reward + o, ok);
         row.lp = ldz<V>(logp_t + o, ok);
         row.h = ldz<V>(ent + o, ok);
@@ -160,13 +162,21 @@ struct UpgoOp {
 #pragma unroll
         for (int k = 0; k < V; ++k) carry[k] = vt.v[k];
     }
-    template <int V> __device__ void load(Row<V>& row, int t, long col, bool ok) const {
+    // row t+1 in registers: V_{t+1} = its v0, r_{t+1} = its r, V_{t+2} = its v1 (already linked: rows are linked from the
+    // end of the chunk backwards); t+1 <= T-1 there, so lam_t is the comparison
+    template <int V> __device__ void link(Row<V>& row, const Row<V>& nxt) const {
+        row.v1 = nxt.v0;
+#pragma unroll
+        for (int k = 0; k < V; ++k) row.lam[k] = (nxt.r.v[k] + nxt.v1.v[k] >= row.v1.v[k]) ? 1.f : 0.f;
+    }
+    template <int V> __device__ void load(Row<V>& row, int t, long col, bool ok, bool next_in_regs) const {
         const size_t o = (size_t)t * B + col;
         row.v0 = ldz<V>(value + o, ok);
-        row.v1 = ldz<V>(value + o + B, ok);
         row.r = ldz<V>(reward + o, ok);
         row.rho = ldz<V>(rho + o, ok);
         row.lp = ldz<V>(logp + o, ok);
+        if (next_in_regs) return;
+        row.v1 = ldz<V>(value + o + B, ok);
         if (t < T - 1) {
             const Pack<V> r1 = ldz<V>(reward + o + B, ok);
             const Pack<V> v2 = ldz<V>(value + o + 2 * (size_t)B, ok);
@@ -217,11 +227,9 @@ extern "C" int hpc_rll_td_lambda_forward(const float* value, const float* reward
     // oracle arithmetic (origin/td.py:239-243): discounts = gamma*lambda ; (gammas - discounts) * V_{t+1}
     const float disc = gamma * lambda;
     TdLambdaOp op{value, reward, weight, weight_mode, grad_buf, T, B, disc, gamma - disc, scale};
-    launch_colscan(op, c, T, B, partials, st);
-    int rc = last_error();
-    if (rc) return rc;
     const float sc = 0.5f * scale;
-    return finalize_sums(partials, (B + 64 * c.v - 1) / (64 * c.v), 1, &sc, loss, st);
+    launch_colscan(op, c, T, B, partials, st, loss, &sc);   // the last workgroup adds the partials: one launch
+    return last_error();
 }
 
 extern "C" int hpc_rll_td_lambda_backward(const float* grad_loss, const float* grad_buf, float* grad_value, int T,
@@ -255,11 +263,9 @@ extern "C" int hpc_rll_vtrace_forward(const float* target_output, const float* b
     const ScanCfg c = scan_cfg(T, B, false);  // V=1: the 7-array row payload would spill at V=2
     VtraceOp op{value, reward, weight, logp_t, logp_b, ent, coef_pg, coef_ent, gv_unit, T, B,
                 gamma, gamma * lambda, rho_clip, c_clip, rho_pg_clip, scale};
-    launch_colscan<VtraceOp, false>(op, c, T, B, partials, st);
-    rc = last_error();
-    if (rc) return rc;
     const float sc[3] = {scale, scale, scale};
-    return finalize_sums(partials, (B + 64 * c.v - 1) / (64 * c.v), 3, sc, losses, st);
+    launch_colscan<VtraceOp, false>(op, c, T, B, partials, st, losses, sc);
+    return last_error();
 }
 
 extern "C" int hpc_rll_vtrace_backward(const float* g_pg, const float* g_value, const float* g_ent,
@@ -302,10 +308,8 @@ extern "C" int hpc_rll_upgo_forward(const float* target_output, const float* rho
     if (rc) return rc;
     const ScanCfg c = scan_cfg(T, B, false);  // V=1 (register budget, see VtraceOp)
     UpgoOp op{value, reward, rho, logp, coef, T, B, scale};
-    launch_colscan<UpgoOp, false>(op, c, T, B, partials, st);
-    rc = last_error();
-    if (rc) return rc;
-    return finalize_sums(partials, (B + 64 * c.v - 1) / (64 * c.v), 1, &scale, loss, st);
+    launch_colscan<UpgoOp, false>(op, c, T, B, partials, st, loss, &scale);
+    return last_error();
 }
 
 extern "C" int hpc_rll_upgo_backward(const float* g, const float* target_output, const int64_t* action,

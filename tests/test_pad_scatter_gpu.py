@@ -177,3 +177,30 @@ def test_scatter_deterministic_and_full_write():
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1])
     assert not torch.isnan(outs[0]).any()
+
+
+@pytest.mark.parametrize("B,M,N,H,W", [(3, 3000, 8, 32, 32), (2, 1030, 6, 10, 6), (5, 257, 12, 16, 16), (2, 64, 70, 8, 8),
+                                       (1, 9000, 4, 64, 64)])
+def test_scatter_many_entities_and_both_forward_kernels(B, M, N, H, W):
+    """(a) the index kernel links the per-cell chains chunk by chunk, so M is no longer bounded by
+    LDS or an O(M^2) scan -- thousands of entities per map, heavy collisions; (b) the LDS-staged streaming forward
+    kernel (tune key 17 = 1, several channel-group widths) and the round-1 kernel (key 17 = 0) both equal the CPU
+    oracle bit for bit, cover and add, incl. out-of-range locations, M % 4 != 0, N % 4 != 0."""
+    import hpc_torch_utils_network as NW
+    from oracle import ref_torch as R
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((B, M, N)).astype(np.float32)
+    loc = np.stack([rng.integers(0, H, (B, M)), rng.integers(0, W, (B, M))], -1).astype(np.int64)
+    dx, dloc = torch.from_numpy(x).to(DEV), torch.from_numpy(loc).to(DEV)
+    try:
+        for typ in ("cover", "add"):
+            ref = R.scatter_connection(torch.from_numpy(x), torch.from_numpy(loc), H, W, typ).numpy()
+            for lds, npb in ((0, 0), (1, 0), (1, 4), (1, 16)):
+                NW.tune_set(17, lds)
+                NW.tune_set(18, npb)
+                out = torch.full((B, N, H, W), float("nan"), device=DEV)
+                NW.ScatterConnectionForward([dx, dloc], [out], typ)
+                assert np.array_equal(out.cpu().numpy(), ref), (typ, lds, npb)
+    finally:
+        NW.tune_set(17, 1)
+        NW.tune_set(18, 0)
