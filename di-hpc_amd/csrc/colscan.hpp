@@ -11,7 +11,7 @@
 // consecutive steps held in VGPRs, workgroup = NW waves covering NW*LC steps; chunk heads (L,P per lane) go
 // through a double-buffered LDS slot, one barrier per NW*LC steps.  Each workgroup also reduces NACC scalar
 // sums (loss terms) deterministically: lane sums -> wave butterfly -> LDS -> one partial per workgroup;
-// the last workgroup to finish adds the partials in a fixed order (fp64).  No float atomics anywhere
+// a second tiny kernel (reduce.hip) adds the partials in a fixed order.  No float atomics anywhere
 // (the reference uses cross-block atomicAdd: td_lambda_kernel.h:38, vtrace_kernel.h:215-222).
 //
 // The reference walks each column with one thread (td_lambda_kernel.h:17-32, vtrace_kernel.h:161-180,
@@ -19,17 +19,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <atomic>
-
 #include "wave.hpp"
 
 namespace hpc_rll {
 
-// Round 2: (a) rows t and t+1 of a wave's chunk share value[t+1] (UPGO also reward[t+1], value[t+2]): `load` is told
+// Round 2: rows t and t+1 of a wave's chunk share value[t+1] (UPGO also reward[t+1], value[t+2]): `load` is told
 // whether row t+1 is held by the same wave and `link` copies the shared fields from it -- LC+1 value rows per chunk
-// instead of 2*LC; (b) the fixed-order fp64 sum of the per-workgroup partials runs in the LAST workgroup to finish
-// (ticket = a {tag, count} word in the call's own scratch, CAS-counted, self-resetting so that a captured graph can be
-// replayed) instead of a second launch -- one launch per scan.
+// instead of 2*LC.
+// Tried and NOT kept: folding the fixed-order sum of the workgroup partials into the last workgroup to finish (arrival
+// ticket in the call's scratch).  On this multi-XCD part an agent-scope release has to write the XCD's L2 back, and the
+// scan has just left its whole output dirty there: TD-lambda forward at T=256,B=16384 went from 17.9 us (scan +
+// finalize launch) to 319 us, V-trace 0.75 -> 1.01 ms, UPGO 0.37 -> 0.64 ms (gpurun_out/r02_suite_c3.log).  A dependent
+// kernel boundary costs ~1.7 us here (MI355X_MICROARCH.md), so the second launch stays.
 //
 // An Op provides:
 //   static constexpr int NACC;                         number of scalar sums
@@ -40,15 +41,9 @@ namespace hpc_rll {
 //   template<int V> void coeffs(const Row<V>&, int t, float (&a)[V], float (&b)[V]) const;
 //   template<int V> void finish(const Row<V>&, int t, long col, bool ok, const float (&s)[V],
 //                               const float (&s_next)[V], float (&acc)[NACC]) const;   outputs + sums
-struct ScanFin {          // fold the final sum into the scan launch: out[k] = scale[k] * sum of the workgroup partials
-    float* out;           // nullptr: leave the partials to the caller
-    float scale[4];
-    uint32_t tag;         // unique per launch, never 0
-};
-
 template <class Op, int V, int LC, int NW>
 __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T, int B,
-                                                              float* __restrict__ partials, const ScanFin fin) {
+                                                              float* __restrict__ partials) {
     constexpr int TILE = 64 * V;
     constexpr int NACC = Op::NACC;
     __shared__ float lds[4 * NW * TILE + NW * (NACC > 0 ? NACC : 1)];
@@ -154,49 +149,6 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
             for (int i = 0; i < NW; ++i) sum += s_red[threadIdx.x * NW + i];
             partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sum;
         }
-        if (fin.out) {
-            typedef unsigned long long u64;
-            __shared__ int s_last;
-            __shared__ double s_sum[NW];
-            u64* const ticket = reinterpret_cast<u64*>(
-                (reinterpret_cast<uintptr_t>(partials + (size_t)NACC * gridDim.x) + 7) & ~(uintptr_t)7);
-            __threadfence();   // release this workgroup's partials
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                u64 old = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned count;
-                while (true) {   // the word is garbage until the first arrival stamps it with this launch's tag
-                    count = ((uint32_t)(old >> 32) == fin.tag) ? (uint32_t)old + 1u : 1u;
-                    const u64 want = ((u64)fin.tag << 32) | count;
-                    if (__hip_atomic_compare_exchange_strong(ticket, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT))
-                        break;
-                }
-                s_last = count == gridDim.x;
-            }
-            __syncthreads();
-            if (s_last) {   // every partial has been released: add them in a fixed order, fp64
-                __threadfence();
-                for (int k = 0; k < NACC; ++k) {
-                    double sum = 0.0;
-                    for (unsigned i = threadIdx.x; i < gridDim.x; i += NW * 64)
-                        sum += (double)__hip_atomic_load(partials + (size_t)k * gridDim.x + i, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-                    if (lane == 0) s_sum[w] = sum;
-                    __syncthreads();
-                    if (threadIdx.x == 0) {
-                        double tot = 0.0;
-                        for (int i = 0; i < NW; ++i) tot += s_sum[i];
-                        fin.out[k] = (float)(tot * (double)fin.scale[k]);
-                    }
-                    __syncthreads();
-                }
-                if (threadIdx.x == 0)   // tag 0 is never issued: a replay of a captured launch starts from a clean word
-                    __hip_atomic_store(ticket, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
     }
 }
 
@@ -215,28 +167,13 @@ inline ScanCfg scan_cfg(int T, int B, bool can_v2) {
     return c;
 }
 
-// launch tag for the folded final sum: unique per launch in this process, never 0
-inline uint32_t scan_next_tag() {
-    static std::atomic<uint32_t> t{1};
-    uint32_t v = t.fetch_add(1);
-    if (v == 0) v = t.fetch_add(1);
-    return v;
-}
-
-// `out` (device, NACC floats) != nullptr: the last workgroup also writes out[k] = scale[k] * sum of partials
 template <class Op, bool ALLOW_V2 = true>
-inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* partials, hipStream_t st,
-                           float* out = nullptr, const float* scale = nullptr) {
+inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* partials, hipStream_t st) {
     const unsigned grid = (unsigned)((B + 64 * c.v - 1) / (64 * c.v));
-    ScanFin fin{out, {0.f, 0.f, 0.f, 0.f}, 0u};
-    if (out) {
-        for (int k = 0; k < Op::NACC && k < 4; ++k) fin.scale[k] = scale[k];
-        fin.tag = scan_next_tag();
-    }
 #define HPC_RLL_SCAN_CASE(V_, NW_)                                                                          \
     if (c.v == V_ && c.nw == NW_) {                                                                         \
         hipLaunchKernelGGL((colscan_rev_kernel<Op, V_, 8, NW_>), dim3(grid), dim3(NW_ * 64), 0, st, op, T, B, \
-                           partials, fin);                                                                  \
+                           partials);                                                                       \
         return;                                                                                             \
     }
     HPC_RLL_SCAN_CASE(1, 1) HPC_RLL_SCAN_CASE(1, 2) HPC_RLL_SCAN_CASE(1, 4) HPC_RLL_SCAN_CASE(1, 8)

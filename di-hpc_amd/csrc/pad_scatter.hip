@@ -678,20 +678,28 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     const bool v4 = (HW % 4) == 0 && (N % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     // LDS-staged streaming kernel: the owner table (HW ints) and an M x NPB tile of x must fit in LDS with room for
-    // three workgroups per CU (so that one workgroup's staging overlaps the others' stores)
-    if (g_scatter_lds_fwd && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0 && B <= 65535 &&
+    // three workgroups per CU (so that one workgroup's staging overlaps the others' stores).  In-process A/B
+    // (tests/tools/r02_scatter_probe.py, profiles/r02_scatter_probe.json): configs[4] cover 0.953 -> 0.919 ms (4.81 ->
+    // 4.99 TB/s), reference test shape (16x16 maps) cover 51 -> 46 us, add 68 -> 53 us; `add` on large maps is a tie at
+    // 64 channels per workgroup (0.893 ms, 5.13 TB/s) and a loss at 32, so it keeps the cells-per-thread kernel there.
+    const bool lds_pays = !add || HW * 4 <= 8 * 1024 || g_scatter_npb != 0;
+    if (g_scatter_lds_fwd && lds_pays && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0 && B <= 65535 &&
         (size_t)HW * 4 <= 32 * 1024) {
         const size_t fixed = (size_t)HW * 4 + (add ? (size_t)M * 4 : 0);
         int npb = 0;
         static const int kNpb[5] = {64, 32, 16, 8, 4};
         for (int i = 0; i < 5 && !npb; ++i) {
             const int c = g_scatter_npb ? g_scatter_npb : kNpb[i];
-            if (c <= 64 && c >= 1 && (size_t)M * (c + 1) * 4 + 16 + fixed <= 52 * 1024) npb = c;
+            if (c <= 64 && c >= 1 && (size_t)M * (c + 1) * 4 + 16 + fixed <= (g_scatter_npb ? 100 : 52) * 1024) npb = c;
             if (g_scatter_npb) break;
         }
         if (npb > N) npb = (N + 3) / 4 * 4;
-        if (npb >= 1 && (size_t)M * (npb + 1) * 4 + 16 + fixed <= 52 * 1024) {
+        if (npb >= 1 && (size_t)M * (npb + 1) * 4 + 16 + fixed <= (g_scatter_npb ? 100 : 52) * 1024) {
             const size_t lds = (((size_t)M * (npb + 1) + 3) & ~(size_t)3) * 4 + fixed;
+            if (lds > 64 * 1024) {
+                const void* k = add ? (const void*)scatter_out_lds_kernel<true> : (const void*)scatter_out_lds_kernel<false>;
+                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return last_error();
+            }
             const dim3 grid((N + npb - 1) / npb, B);
             if (add) hipLaunchKernelGGL(scatter_out_lds_kernel<true>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb);
             else hipLaunchKernelGGL(scatter_out_lds_kernel<false>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb);

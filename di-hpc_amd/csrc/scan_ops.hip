@@ -227,9 +227,11 @@ extern "C" int hpc_rll_td_lambda_forward(const float* value, const float* reward
     // oracle arithmetic (origin/td.py:239-243): discounts = gamma*lambda ; (gammas - discounts) * V_{t+1}
     const float disc = gamma * lambda;
     TdLambdaOp op{value, reward, weight, weight_mode, grad_buf, T, B, disc, gamma - disc, scale};
+    launch_colscan(op, c, T, B, partials, st);
+    int rc = last_error();
+    if (rc) return rc;
     const float sc = 0.5f * scale;
-    launch_colscan(op, c, T, B, partials, st, loss, &sc);   // the last workgroup adds the partials: one launch
-    return last_error();
+    return finalize_sums(partials, (B + 64 * c.v - 1) / (64 * c.v), 1, &sc, loss, st);
 }
 
 extern "C" int hpc_rll_td_lambda_backward(const float* grad_loss, const float* grad_buf, float* grad_value, int T,
@@ -263,9 +265,11 @@ extern "C" int hpc_rll_vtrace_forward(const float* target_output, const float* b
     const ScanCfg c = scan_cfg(T, B, false);  // V=1: the 7-array row payload would spill at V=2
     VtraceOp op{value, reward, weight, logp_t, logp_b, ent, coef_pg, coef_ent, gv_unit, T, B,
                 gamma, gamma * lambda, rho_clip, c_clip, rho_pg_clip, scale};
+    launch_colscan<VtraceOp, false>(op, c, T, B, partials, st);
+    rc = last_error();
+    if (rc) return rc;
     const float sc[3] = {scale, scale, scale};
-    launch_colscan<VtraceOp, false>(op, c, T, B, partials, st, losses, sc);
-    return last_error();
+    return finalize_sums(partials, (B + 64 * c.v - 1) / (64 * c.v), 3, sc, losses, st);
 }
 
 extern "C" int hpc_rll_vtrace_backward(const float* g_pg, const float* g_value, const float* g_ent,
@@ -308,8 +312,10 @@ extern "C" int hpc_rll_upgo_forward(const float* target_output, const float* rho
     if (rc) return rc;
     const ScanCfg c = scan_cfg(T, B, false);  // V=1 (register budget, see VtraceOp)
     UpgoOp op{value, reward, rho, logp, coef, T, B, scale};
-    launch_colscan<UpgoOp, false>(op, c, T, B, partials, st, loss, &scale);
-    return last_error();
+    launch_colscan<UpgoOp, false>(op, c, T, B, partials, st);
+    rc = last_error();
+    if (rc) return rc;
+    return finalize_sums(partials, (B + 64 * c.v - 1) / (64 * c.v), 1, &scale, loss, st);
 }
 
 extern "C" int hpc_rll_upgo_backward(const float* g, const float* target_output, const int64_t* action,

@@ -3,8 +3,8 @@
 LSTM: golden fixtures recorded from the real reference (hpc_rll.origin.rnn.LSTM, autograd gradients w.r.t. every
 input and parameter, INCLUDING gradients that enter through the returned final states) and the fp64 oracle at the
 reference test shape (tests/test_lstm.py:10-16: S=64, B=3, in=1792, H=384, L=3).
-Tolerances are FIXED and written at each assert: forward 2e-5 / gradients 2e-4 up to 12 recurrent steps; 2e-3 / 1e-2 at
-the reference's 192-step test shape (where torch's own fp32 evaluation of the oracle is 7.5e-3 from fp64 on dx).
+Tolerances are FIXED and written at each assert (relative to each tensor's own scale): forward 2e-5 / gradients 2e-4 up
+to 12 recurrent steps; 5e-4 / 5e-3 at the reference's 192-step test shape.
 """
 import numpy as np
 import pytest
@@ -133,14 +133,23 @@ def test_lstm_oracle(S, B, I, H, L):
     gwh = m.wh.grad.cpu().numpy().reshape(L, H, 4 * H)
     for l in range(L):
         got[f"wx{l}"], got[f"wh{l}"] = gwx[l], gwh[l]
-    # FIXED tolerances per shape, max |ref - got| / max(1, |ref|) elementwise against the fp64 oracle.
-    # The recurrence through S*L LayerNorms amplifies fp32 rounding.  At the reference's test shape (192 LayerNorm-
-    # recurrent steps, random gamma/beta) torch's OWN fp32 evaluation of the oracle is 7.5e-3 away from fp64 on dx and
-    # the HIP kernels 3.7e-3 (measured, MI355X, this seed; gpurun_out/r02_lstm_oracle_errors.json holds every key of the
-    # last run): bounds 2e-3 forward / 1e-2 gradients there.  Shapes with <= 12 steps: 2e-5 forward (north_star: 1e-5
-    # rel for returns; an LSTM output is 2 LayerNorms + 5 transcendental ops per step away from its inputs), 2e-4 grads.
-    fwd_tol, grad_tol = (2e-3, 1e-2) if S * L >= 192 else (2e-5, 2e-4)
-    worst = {k: (rel_err(o64[k], got[k]), rel_err(o64[k], o32[k])) for k in got}
+    # FIXED tolerances per shape against the fp64 oracle.  Metric: max |ref - got| / max |ref| of the
+    # tensor (a per-tensor scale: weight gradients here reach 1e3 while most of their entries are < 1, so an elementwise
+    # max(1,|ref|) denominator compares noise in the small entries against 1 -- it reads 9e-2 on dwh0 for the HIP kernels
+    # and 1.8e-1 for torch's own fp32 evaluation of the oracle at the reference's test shape).
+    # The recurrence through S*L LayerNorms amplifies fp32 rounding: at the reference's test shape (192 LayerNorm-
+    # recurrent steps) bounds 5e-4 forward / 5e-3 gradients; torch's own fp32 evaluation of the oracle is recorded next
+    # to the HIP error in gpurun_out/r02_lstm_oracle_errors.json (it is about 2x further from fp64 than the kernels on
+    # every tensor).  Shapes with <= 12 steps: 2e-5 forward (north_star: 1e-5 rel for returns; an LSTM output is
+    # 2 LayerNorms + 5 transcendental ops per step away from its inputs), 2e-4 gradients.
+    fwd_tol, grad_tol = (5e-4, 5e-3) if S * L >= 192 else (2e-5, 2e-4)
+
+    def nerr(ref, val):
+        ref = np.asarray(ref, dtype=np.float64)
+        scale = float(np.max(np.abs(ref)))
+        assert scale > 0.0
+        return float(np.max(np.abs(ref - np.asarray(val, dtype=np.float64)))) / scale
+    worst = {k: (nerr(o64[k], got[k]), nerr(o64[k], o32[k])) for k in got}
     _record_errors(f"lstm_oracle S={S} B={B} I={I} H={H} L={L}", worst)
     for k, (e, e32) in worst.items():
         tol = fwd_tol if k in ("y", "hn", "cn") else grad_tol
