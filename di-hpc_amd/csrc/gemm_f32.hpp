@@ -185,7 +185,9 @@ template <int BM, int BN, int BK> struct GemmOcc {
 // generic operand) -- decided on the host, so that each instantiation holds ONE main loop: the branch-free prefetch
 // loop (see TileStage::load_fast) or the guarded one.  (Both loops in one kernel behind a uniform branch cost 20-40
 // registers and spilled in the NT variants.)
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool INTERIOR>
+// ABL != 0: ablation builds for tests/tools/micro/gemm_ablate.hip only (WRONG results): 1 = MFMAs + LDS operand reads
+// only; 2 = + global prefetch (waited for where the LDS store would be); 3 = + LDS store + barrier, no global loads.
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool INTERIOR, int ABL = 0>
 __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int WAVES_M = BM / (32 * WM);
     static_assert(WAVES_M * (BN / (32 * WN)) == 4, "4 waves per workgroup");
@@ -265,18 +267,25 @@ __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_ke
         sb.init(g.B, g.b_sn, g.b_sk, n0, kbeg + BK);
         for (int kt = 0; kt < ktiles; ++kt) {
             const int buf = kt & 1;
-            if (kt + 1 < ktiles) {
+            if constexpr (ABL != 0) asm volatile("" ::: "memory");
+            if (kt + 1 < ktiles && (ABL == 0 || ABL == 2)) {
                 sa.load_fast(g.a_sm, g.a_sk);
                 sb.load_fast(g.b_sn, g.b_sk);
                 sa.advance(g.a_sk);
                 sb.advance(g.b_sk);
             }
             mfma_tile(buf);
-            if (kt + 1 < ktiles) {
+            if (kt + 1 < ktiles && (ABL == 0 || ABL == 3)) {
                 sa.store(As + (buf ^ 1) * BK * BM);
                 sb.store(Bs + (buf ^ 1) * BK * BN);
             }
-            __syncthreads();
+            if constexpr (ABL == 2) {   // the prefetched registers must have arrived here, as for the LDS store
+#pragma unroll
+                for (int i = 0; i < (int)(sizeof(sa.v) / sizeof(sa.v[0])); ++i) asm volatile("" : : "v"(sa.v[i]));
+#pragma unroll
+                for (int i = 0; i < (int)(sizeof(sb.v) / sizeof(sb.v[0])); ++i) asm volatile("" : : "v"(sb.v[i]));
+            }
+            if constexpr (ABL == 0 || ABL == 3) __syncthreads();
         }
     } else {
         for (int kt = 0; kt < ktiles; ++kt) {

@@ -4,7 +4,7 @@ LSTM: golden fixtures recorded from the real reference (hpc_rll.origin.rnn.LSTM,
 input and parameter, INCLUDING gradients that enter through the returned final states) and the fp64 oracle at the
 reference test shape (tests/test_lstm.py:10-16: S=64, B=3, in=1792, H=384, L=3).
 Tolerances are FIXED and written at each assert (relative to each tensor's own scale): forward 2e-5 / gradients 2e-4 up
-to 12 recurrent steps; 5e-4 / 5e-3 at the reference's 192-step test shape.
+to 12 recurrent steps; 3e-4 at the reference's 192-step test shape (measured <= 8.8e-5).
 """
 import numpy as np
 import pytest
@@ -138,16 +138,16 @@ def test_lstm_oracle(S, B, I, H, L):
     # max(1,|ref|) denominator compares noise in the small entries against 1 -- it reads 9e-2 on dwh0 for the HIP kernels
     # and 1.8e-1 for torch's own fp32 evaluation of the oracle at the reference's test shape).
     # The recurrence through S*L LayerNorms amplifies fp32 rounding: at the reference's test shape (192 LayerNorm-
-    # recurrent steps) bounds 5e-4 forward / 5e-3 gradients; torch's own fp32 evaluation of the oracle is recorded next
-    # to the HIP error in gpurun_out/r02_lstm_oracle_errors.json (it is about 2x further from fp64 than the kernels on
-    # every tensor).  Shapes with <= 12 steps: 2e-5 forward (north_star: 1e-5 rel for returns; an LSTM output is
-    # 2 LayerNorms + 5 transcendental ops per step away from its inputs), 2e-4 gradients.
-    fwd_tol, grad_tol = (5e-4, 5e-3) if S * L >= 192 else (2e-5, 2e-4)
+    # recurrent steps) the HIP kernels measure <= 8.8e-5 on every tensor (torch's own fp32 evaluation of the oracle:
+    # <= 3.2e-4; both recorded per tensor in profiles/r02_lstm_oracle_errors.json): bounds 3e-4 forward and gradients.
+    # Shapes with <= 12 steps: 2e-5 forward (north_star: 1e-5 rel for returns; an LSTM output is 2 LayerNorms +
+    # 5 transcendental ops per step away from its inputs), 2e-4 gradients.
+    fwd_tol, grad_tol = (3e-4, 3e-4) if S * L >= 192 else (2e-5, 2e-4)
 
     def nerr(ref, val):
         ref = np.asarray(ref, dtype=np.float64)
-        scale = float(np.max(np.abs(ref)))
-        assert scale > 0.0
+        # floor: a LayerNorm over H = 1 element has an exactly-zero input gradient, the reference is rounding noise
+        scale = max(float(np.max(np.abs(ref))), 1e-3)
         return float(np.max(np.abs(ref - np.asarray(val, dtype=np.float64)))) / scale
     worst = {k: (nerr(o64[k], got[k]), nerr(o64[k], o32[k])) for k in got}
     _record_errors(f"lstm_oracle S={S} B={B} I={I} H={H} L={L}", worst)
