@@ -10,18 +10,25 @@
 //   NT  dY @ W^T       A(m,k) = A[m*lda + k]   B(k,n) = W[n*ldb + k]
 //   TN  X^T @ dY       A(m,k) = X[k*lda + m]   B(k,n) = B[k*ldb + n]
 //
-// Tiling: workgroup = 4 waves, block tile BM x BN x 32; each wave owns WM x WN MFMA blocks of 32 x 32.
-// Operand tiles live in LDS k-major (As[k][m], Bs[k][n]) so the MFMA operand fetch
-//     a = As[k0 + (lane>>5)][m0 + (lane&31)]
-// is a conflict-free ds_read_b32 (the two 32-lane halves are separate LDS lane groups).  Staging per operand:
-//   * contiguous along m/n : float4 global loads along m, one ds_write_b128 each;
-//   * contiguous along k   : four float4 loads along k from four consecutive rows, a 4x4 register transpose, four
-//     ds_write_b128 along m;
+// Tiling: workgroup = 4 waves, block tile BM x BN x BK (BK = 16 or 32); each wave owns WM x WN MFMA blocks of 32 x 32.
+//
+// LDS layout (round 2).  An operand tile is stored ROW-major -- one row per m (A) / n (B), BK floats, no padding -- with
+// the k axis PERMUTED inside the row: [k = 0,2,4,..,BK-2 | k = 1,3,..,BK-1].  Lane (x = lane & 31, h = lane >> 5) of the
+// 32x32x2 MFMA consumes k = 2s + h at step s, i.e. exactly the h-th half of its row, in order: one ds_read_b128 feeds
+// FOUR consecutive MFMA steps (the first version fetched one ds_read_b32 per operand and step from k-major tiles; an
+// ablation build with nothing but those reads and the MFMAs stopped at 136 TFLOP/s = 87 % of peak,
+// profiles/r02_gemm_ablate_before.txt -- every instruction a wave issues between two of its MFMAs delays the next one).
+// The arithmetic order along k is unchanged, so results are bit-identical to the first version.  The 16-byte chunks of
+// a row are XOR-swizzled with the row index ((x>>2)&3 for 64-byte rows, (x>>1)&7 for 128-byte rows), which makes the
+// b128 operand reads of 16 consecutive rows hit 16 different bank quads; the swizzle of rows x and x+32 is the same, so
+// a wave's WM (WN) blocks share one address register and differ by an immediate offset.
+// Staging per operand (register prefetch of the next k-tile + LDS double buffer, one barrier per k-tile):
+//   * contiguous along k   : float4 global loads along k; the even / odd k's of each float4 go out as two 8-byte writes;
+//   * contiguous along m/n : four float4 loads from four k-rows of equal parity (k, k+2, k+4, k+6), a 4x4 register
+//     transpose, four 16-byte writes (one per row);
 //   * anything else        : guarded scalar loads (odd sizes / unaligned pointers).
-// The 16-byte slots of a k-row are XOR-swizzled with (k>>2)&7 so that both the b128 writes (8 lanes = 8 different
-// k-rows or 8 consecutive slots) and the b32 reads (32 consecutive m) are bank-conflict free without padding.
-// The next tile's global loads are issued into registers before the current tile's MFMAs and written to the other
-// LDS buffer afterwards (register prefetch + LDS double buffer, one barrier per k-tile).
+// When both tiles together are 256 4x4 blocks or fewer, A is staged by the first waves and B by the others (one block
+// per thread); otherwise every thread stages its share of both.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -45,28 +52,38 @@ struct GemmArgs {
 
 enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2 };
 
-// LDS address (in floats) of element (k, x) of a k-major tile with X columns (X % 32 == 0) and BK k-rows.  The 16-byte
-// slot index is XOR-ed with a function of k chosen so that the 8 lanes of a ds_write_b128 group (BK/4 k-groups x
-// 8/(BK/4) consecutive slots) hit 8 different slots, while 32 consecutive x of one k-row stay a permutation of 8 slots.
-template <int X, int BK> __device__ __forceinline__ int lds_idx(int k, int x) {
-    const int sw = (BK == 32) ? ((k >> 2) & 7) : (((k >> 2) & 3) << 1);
-    return k * X + ((((x >> 2) ^ sw) << 2) | (x & 3));
+// LDS address (in floats) of position pp (0..BK-1) of the PERMUTED row x of a tile with BK floats per row.
+template <int BK> __device__ __forceinline__ int lds_sw(int x) { return BK == 16 ? ((x >> 2) & 3) : ((x >> 1) & 7); }
+template <int BK> __device__ __forceinline__ int lds_pos(int x, int pp) {
+    return x * BK + ((((pp >> 2) ^ lds_sw<BK>(x)) << 2) | (pp & 3));
 }
+// position of k inside the permuted row: evens first, then odds
+template <int BK> __device__ __forceinline__ int kperm(int k) { return (k & 1) * (BK / 2) + (k >> 1); }
 
-// Stages one operand tile (X rows-of-the-operand by BK k) through registers.
+typedef float gf2 __attribute__((ext_vector_type(2)));
+
+// Stages one operand tile (X rows-of-the-operand by BK k) through registers, using threads [T0, T0+NT) of the workgroup.
 //   MODE kContigMN: element (x,k) at base[x + k*sk]        (unit stride along x)
 //   MODE kContigK : element (x,k) at base[x*sx + k]        (unit stride along k)
 //   MODE kGeneric : element (x,k) at base[x*sx + k*sk], fully guarded
-template <int X, int BK, int MODE>
+// Work unit of the two vector modes: a 4 x 4 block = four float4 loads.
+//   kContigK : block e -> rows xr = 4*(e / KQ) .. +3, k = 4*(e % KQ) .. +3            (KQ = BK/4)
+//   kContigMN: block e -> x = 4*(e / NSET) .. +3, k-set c = e % NSET = four k of equal parity
+//              {par + 2*(4*idx + t), t = 0..3}, par = c / (BK/8), idx = c % (BK/8): positions 4c .. 4c+3 of the row.
+template <int X, int BK, int MODE, int T0, int NT>
 struct TileStage {
-    static constexpr int KQ = BK / 4;                    // float4 per k-row of the tile
+    static constexpr int KQ = BK / 4;                    // float4 per row of the tile (k-contiguous operand)
+    static constexpr int NSET = BK / 4;                  // k-sets (x-contiguous operand)
     static constexpr int NBLK = X * BK / 16;             // 4x4 blocks in the tile
-    static constexpr int NV = (X * BK / 4 + 255) / 256;  // float4 per thread (contiguous along m/n)
-    static constexpr int NB = (NBLK + 255) / 256;        // 4x4 blocks per thread (contiguous along k)
-    static constexpr int NS = X * BK / 256;              // scalars per thread (generic)
-    gf4 v[MODE == kGeneric ? 1 : (MODE == kContigK ? NB * 4 : NV)];
+    static constexpr int NB = (NBLK + NT - 1) / NT;      // blocks per staging thread
+    static constexpr int NS = X * BK / NT;               // scalars per staging thread (generic)
+    static_assert(NT % 64 == 0 && T0 % 64 == 0 && NT % KQ == 0 && (X * BK) % NT == 0, "staging thread set");
+    gf4 v[MODE == kGeneric ? 1 : NB * 4];
     float s[MODE == kGeneric ? NS : 1];
     const float* p;   // this thread's first element of the NEXT k-tile to prefetch (fast path)
+
+    static __device__ __forceinline__ bool active() { return (int)threadIdx.x >= T0 && (int)threadIdx.x < T0 + NT; }
+    static __device__ __forceinline__ int kset_first(int c) { return c / (BK / 8) + 8 * (c % (BK / 8)); }
 
     // Fast path for tiles that lie entirely inside the operand (uniform per workgroup and k-tile): no per-lane
     // bounds test, so no divergent branch around a load.  With the guarded form the compiler had to assume 0..NV
@@ -75,65 +92,70 @@ struct TileStage {
     // prefetch hid nothing of the A latency.  Addresses are one per-thread pointer plus uniform (scalar) offsets,
     // advanced once per k-tile (the guarded form recomputed 64-bit products per load).
     __device__ __forceinline__ void init(const float* __restrict__ base, long sx, long sk, int x0, int k0) {
-        const int tid = threadIdx.x;
-        if (MODE == kContigMN) p = base + (long)(k0 + tid / (X / 4)) * sk + x0 + (tid % (X / 4)) * 4;
-        else if (MODE == kContigK) p = base + (long)(x0 + 4 * (tid / KQ)) * sx + k0 + (tid % KQ) * 4;
+        const int lt = (int)threadIdx.x - T0;
+        if (MODE == kContigMN) p = base + (long)(k0 + kset_first(lt % NSET)) * sk + x0 + 4 * (lt / NSET);
+        else if (MODE == kContigK) p = base + (long)(x0 + 4 * (lt / KQ)) * sx + k0 + (lt % KQ) * 4;
         else p = base;
     }
     __device__ __forceinline__ void advance(long sk) { p += (MODE == kContigMN) ? BK * sk : BK; }
     __device__ __forceinline__ void load_fast(long sx, long sk) {
-        static_assert(MODE == kGeneric || 256 % (X / 4) == 0, "k-rows per pass must be whole");
+        if (!active()) return;
+        const int lt = (int)threadIdx.x - T0;
         if (MODE == kContigMN) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                if (threadIdx.x + i * 256 >= X * BK / 4) break;
-                v[i] = *reinterpret_cast<const gf4*>(p + (long)(i * (256 / (X / 4))) * sk);
+            for (int i = 0; i < NB; ++i) {
+                if (lt + i * NT >= NBLK) break;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    v[i * 4 + t] = *reinterpret_cast<const gf4*>(p + (long)(2 * t) * sk + i * 4 * (NT / NSET));
             }
         } else if (MODE == kContigK) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                if (threadIdx.x + i * 256 >= NBLK) break;
+                if (lt + i * NT >= NBLK) break;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    v[i * 4 + r] = *reinterpret_cast<const gf4*>(p + (long)(i * 4 * (256 / KQ) + r) * sx);
+                    v[i * 4 + r] = *reinterpret_cast<const gf4*>(p + (long)(i * 4 * (NT / KQ) + r) * sx);
             }
         }
     }
 
     __device__ __forceinline__ void load(const float* __restrict__ base, long sx, long sk, int x0, int k0, int XD,
                                          int KD) {
-        const int tid = threadIdx.x;
+        if (!active()) return;
+        const int lt = (int)threadIdx.x - T0;
         if (MODE == kContigMN) {
-            // thread -> (k = e / (X/4), xq = (e % (X/4))*4), e = tid + i*256
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int e = tid + i * 256;
-                if (e >= X * BK / 4) break;
-                const int k = k0 + e / (X / 4), x = x0 + (e % (X / 4)) * 4;
-                gf4 t = {0.f, 0.f, 0.f, 0.f};
-                if (k < KD && x < XD) t = *reinterpret_cast<const gf4*>(base + (long)k * sk + x);
-                v[i] = t;
-            }
-        } else if (MODE == kContigK) {
-            // thread -> 4x4 block: rows x = 4*(e / KQ) .. +3, k = (e % KQ)*4 .. +3 ; NBLK blocks, NB per thread
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int e = tid + i * 256;
+                const int e = lt + i * NT;
+                if (e >= NBLK) break;
+                const int x = x0 + 4 * (e / NSET), kf = k0 + kset_first(e % NSET);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    gf4 w = {0.f, 0.f, 0.f, 0.f};
+                    if (kf + 2 * t < KD && x < XD) w = *reinterpret_cast<const gf4*>(base + (long)(kf + 2 * t) * sk + x);
+                    v[i * 4 + t] = w;
+                }
+            }
+        } else if (MODE == kContigK) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = lt + i * NT;
                 if (e >= NBLK) break;
                 const int xr = x0 + 4 * (e / KQ), k = k0 + (e % KQ) * 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int x = xr + r;
                     x = x < XD ? x : XD - 1;   // clamp: rows beyond the edge are never stored to C
-                    gf4 t = {0.f, 0.f, 0.f, 0.f};
-                    if (k < KD) t = *reinterpret_cast<const gf4*>(base + (long)x * sx + k);
-                    v[i * 4 + r] = t;
+                    gf4 w = {0.f, 0.f, 0.f, 0.f};
+                    if (k < KD) w = *reinterpret_cast<const gf4*>(base + (long)x * sx + k);
+                    v[i * 4 + r] = w;
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                const int e = tid + i * 256;
+                const int e = lt + i * NT;
                 const int k = k0 + e / X, x = x0 + e % X;
                 s[i] = (k < KD && x < XD) ? base[(long)x * sx + (long)k * sk] : 0.f;
             }
@@ -141,31 +163,39 @@ struct TileStage {
     }
 
     __device__ __forceinline__ void store(float* __restrict__ tile) const {
-        const int tid = threadIdx.x;
+        if (!active()) return;
+        const int lt = (int)threadIdx.x - T0;
         if (MODE == kContigMN) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int e = tid + i * 256;
-                if (e >= X * BK / 4) break;
-                *reinterpret_cast<gf4*>(tile + lds_idx<X, BK>(e / (X / 4), (e % (X / 4)) * 4)) = v[i];
+            for (int i = 0; i < NB; ++i) {
+                const int e = lt + i * NT;
+                if (e >= NBLK) break;
+                const int c = e % NSET, x = 4 * (e / NSET);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const gf4 w = {v[i * 4 + 0][j], v[i * 4 + 1][j], v[i * 4 + 2][j], v[i * 4 + 3][j]};
+                    *reinterpret_cast<gf4*>(tile + lds_pos<BK>(x + j, 4 * c)) = w;
+                }
             }
         } else if (MODE == kContigK) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int e = tid + i * 256;
+                const int e = lt + i * NT;
                 if (e >= NBLK) break;
-                const int xr = 4 * (e / KQ), k = (e % KQ) * 4;
+                const int xr = 4 * (e / KQ), kh = (e % KQ) * 2;   // k = 2*kh .. 2*kh+3 -> even slots kh, kh+1 ; odd BK/2 + kh, +1
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    gf4 t = {v[i * 4 + 0][j], v[i * 4 + 1][j], v[i * 4 + 2][j], v[i * 4 + 3][j]};
-                    *reinterpret_cast<gf4*>(tile + lds_idx<X, BK>(k + j, xr)) = t;
+                for (int r = 0; r < 4; ++r) {
+                    const gf4 w = v[i * 4 + r];
+                    const gf2 ev = {w[0], w[2]}, od = {w[1], w[3]};
+                    *reinterpret_cast<gf2*>(tile + lds_pos<BK>(xr + r, kh)) = ev;
+                    *reinterpret_cast<gf2*>(tile + lds_pos<BK>(xr + r, BK / 2 + kh)) = od;
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                const int e = tid + i * 256;
-                tile[lds_idx<X, BK>(e / X, e % X)] = s[i];
+                const int e = lt + i * NT;
+                tile[lds_pos<BK>(e % X, kperm<BK>(e / X))] = s[i];
             }
         }
     }
@@ -187,6 +217,13 @@ template <int BM, int BN, int BK> struct GemmOcc {
 // registers and spilled in the NT variants.)
 // ABL != 0: ablation builds for tests/tools/micro/gemm_ablate.hip only (WRONG results): 1 = MFMAs + LDS operand reads
 // only; 2 = + global prefetch (waited for where the LDS store would be); 3 = + LDS store + barrier, no global loads.
+// Where the time goes (tests/tools/micro/gemm_ablate.hip, profiles/r02_gemm_ablate.txt; 4096^3 NN, full-entropy data,
+// shader clock measured in-run at 2.41 GHz): MFMAs + the b128 operand reads alone 150 TFLOP/s (95 % of the matrix
+// rate; 136 with the first version's b32 reads); + LDS store and barrier 141; + the global prefetch 129 -- the same
+// with one or TWO k-tiles of prefetch in flight (a second register set, tried and removed), with 128x128 or 256x128
+// tiles, with full or half cache lines per load (TN / NT / NN all within 127-130): what the stream costs is not its
+// latency but the ISSUE of the vector-memory instructions beside the MFMAs (~65 cycles of matrix pipe per
+// global_load_dwordx4 of a wave; MI355X_MICROARCH.md quotes ~60 for an LDS-DMA piece).
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool INTERIOR, int ABL = 0>
 __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int WAVES_M = BM / (32 * WM);
@@ -218,8 +255,11 @@ __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_ke
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    TileStage<BM, BK, AMODE> sa;
-    TileStage<BN, BK, BMODE> sb;
+    // who stages what: both tiles together <= 256 blocks -> disjoint wave sets, one block per thread
+    constexpr int NBA = BM * BK / 16, NBB = BN * BK / 16;
+    constexpr bool SPLIT = NBA + NBB <= 256 && NBA % 64 == 0 && NBB % 64 == 0;
+    TileStage<BM, BK, AMODE, 0, SPLIT ? NBA : 256> sa;
+    TileStage<BN, BK, BMODE, SPLIT ? NBA : 0, SPLIT ? NBB : 256> sb;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -241,25 +281,36 @@ __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_ke
     sa.store(As);
     sb.store(Bs);
     __syncthreads();
-    const int am = wm * 32 * WM + (lane & 31);
-    const int bn = wn * 32 * WN + (lane & 31);
+    // operand fetch: lane (x = lane & 31, h = lane >> 5) reads the h-th half of its permuted row, 16 bytes = 4 MFMA steps
+    // at a time; block i of the wave sits 32 rows further (same swizzle): an immediate offset
+    constexpr int NQ = BK / 8;   // 16-byte chunks per half row
+    int a_off[NQ], b_off[NQ];
+    {
+        const int am = wm * 32 * WM + (lane & 31), bn = wn * 32 * WN + (lane & 31), hh = (lane >> 5) * (BK / 2);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            a_off[q] = lds_pos<BK>(am, hh + 4 * q);
+            b_off[q] = lds_pos<BK>(bn, hh + 4 * q);
+        }
+    }
     // One k-tile of MFMAs out of LDS buffer `buf`.
-    auto mfma_tile = [&](int buf) {
+    auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
         const float* __restrict__ as = As + buf * BK * BM;
         const float* __restrict__ bs = Bs + buf * BK * BN;
 #pragma unroll
-        for (int ks = 0; ks < BK; ks += 2) {
-            const int kr = ks + (lane >> 5);
-            float a[WM], b[WN];
+        for (int q = 0; q < NQ; ++q) {
+            gf4 a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = as[lds_idx<BM, BK>(kr, am + i * 32)];
+            for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const gf4*>(as + a_off[q] + i * 32 * BK);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = bs[lds_idx<BN, BK>(kr, bn + j * 32)];
+            for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const gf4*>(bs + b_off[q] + j * 32 * BK);
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
         }
     };
     if constexpr (INTERIOR) {
