@@ -529,11 +529,15 @@ extern "C" int hpc_rll_packed_table(const int64_t* lengths, int64_t n, int64_t b
 // already sorted by numel.  Outputs: group_shapes (<= group rows of dim ints), positions (<= group+1 ints).
 // Returns the number of groups (>= 1) or a negative error.
 namespace {
-// 1-D lists sorted by length: cost(k,i) = len[i-1] * (i-k) satisfies the quadrangle inequality, so the smallest optimal
-// split point is monotone in i and each DP layer is a divide-and-conquer in O(n log n) instead of O(n^2)
-// (the reference's O(group * n^2) DP with stack VLAs breaks long before n ~ 1e6).  Ties resolve to
-// the smallest split point, exactly like the quadratic DP.
-void dc_layer(const int32_t* len, const int64_t* prev, int64_t* cur, int32_t* arg, int lo, int hi, int klo, int khi,
+// Lists sorted by element count: cost(k,i) = key[i-1] * (i-k) with key nondecreasing satisfies the quadrangle
+// inequality, so the smallest optimal split point is monotone in i and each DP layer is a divide-and-conquer in
+// O(n log n) instead of O(n^2) (the reference's O(group * n^2) DP with stack VLAs breaks long before
+// n ~ 1e6).  Ties resolve to the smallest split point, exactly like the quadratic DP.
+//   rank 1: key = the length                 -> the exact padded-element count (padding.cu:44-108)
+//   rank 2/3 (long lists only): key = numel  -> the cost model of hpc_rll/origin/padding.py:16-17 (arr[end] * count);
+//     the per-dimension maxima of padding.cu are not monotone in a numel-sorted list, their exact DP stays quadratic
+//     and is kept for n <= 512.  The group SHAPES are always the true per-dimension maxima.
+void dc_layer(const int64_t* key, const int64_t* prev, int64_t* cur, int32_t* arg, int lo, int hi, int klo, int khi,
               int64_t INF) {
     if (lo > hi) return;
     const int mid = (lo + hi) >> 1;
@@ -542,13 +546,13 @@ void dc_layer(const int32_t* len, const int64_t* prev, int64_t* cur, int32_t* ar
     const int kend = khi < mid - 1 ? khi : mid - 1;
     for (int k = klo; k <= kend; ++k) {
         if (prev[k] >= INF) continue;
-        const int64_t c = prev[k] + (int64_t)len[mid - 1] * (mid - k);
+        const int64_t c = prev[k] + key[mid - 1] * (int64_t)(mid - k);
         if (c < best) { best = c; bk = k; }
     }
     cur[mid] = best;
     arg[mid] = bk;
-    dc_layer(len, prev, cur, arg, lo, mid - 1, klo, best >= INF ? khi : bk, INF);
-    dc_layer(len, prev, cur, arg, mid + 1, hi, best >= INF ? klo : bk, khi, INF);
+    dc_layer(key, prev, cur, arg, lo, mid - 1, klo, best >= INF ? khi : bk, INF);
+    dc_layer(key, prev, cur, arg, mid + 1, hi, best >= INF ? klo : bk, khi, INF);
 }
 }  // namespace
 
@@ -559,15 +563,26 @@ extern "C" int hpc_rll_oracle_split_group(const int32_t* sizes, int n, int dim, 
     const int64_t INF = INT64_MAX / 4;
     std::vector<int32_t> pos((size_t)(n + 1) * (M + 1), 0);
     auto P = [&](int i, int j) -> int32_t& { return pos[(size_t)i * (M + 1) + j]; };
-    bool sorted1d = (dim == 1);
-    for (int i = 1; sorted1d && i < n; ++i) sorted1d = sizes[i] >= sizes[i - 1];
-    if (sorted1d && n > 512) {
+    // long lists: monotone DP on the element count (see dc_layer); needs the documented precondition "sorted by numel"
+    std::vector<int64_t> key;
+    bool sorted = n > 512;
+    if (sorted) {
+        key.resize(n);
+        for (int i = 0; i < n; ++i) {
+            int64_t e = 1;
+            for (int d = 0; d < dim; ++d) e *= sizes[(size_t)i * dim + d];
+            key[i] = e;
+            if (i && key[i] < key[i - 1]) { sorted = false; break; }
+        }
+    }
+    if (!sorted && n > 20000) return HPC_RLL_EUNSUPPORTED;   // the quadratic DP would take hours: sort the list first
+    if (sorted) {
         std::vector<int64_t> prev(n + 1, INF), cur(n + 1, INF);
         std::vector<int32_t> arg(n + 1, 0);
         prev[0] = 0;
         for (int j = 1; j <= M; ++j) {
             std::fill(cur.begin(), cur.end(), INF);
-            dc_layer(sizes, prev.data(), cur.data(), arg.data(), 1, n, 0, n - 1, INF);
+            dc_layer(key.data(), prev.data(), cur.data(), arg.data(), 1, n, 0, n - 1, INF);
             for (int i = 1; i <= n; ++i) P(i, j) = arg[i];
             prev.swap(cur);
         }

@@ -98,3 +98,34 @@ def test_pad_and_unpad_host_tables():
             U._unpad_table(bad, lim, rank)
     tab, numel, offs, _ = (t.numpy() for t in U._unpad_table([], (4,), 1))   # empty list
     assert tab.shape == (0, 4) and offs.tolist() == [0]
+
+
+@pytest.mark.parametrize("rank,n,group", [(2, 700, 5), (3, 1200, 4), (2, 100000, 8)])
+def test_long_multi_dim_lists_split_in_n_log_n(rank, n, group):
+    """rank-2/3 lists beyond 512 tensors no longer need the O(group * n^2) table.  They take
+    the monotone divide-and-conquer DP on the element count, i.e. the cost model of the reference's OWN python oracle
+    (hpc_rll/origin/padding.py:16-17: arr[end] * count over the numel-sorted list): the positions must equal that
+    oracle's, the group shapes are the true per-dimension maxima, and 100k tensors finish in seconds."""
+    import time
+    import hpc_rl_utils as U
+    rng = np.random.default_rng(rank * 1000 + n)
+    shapes = [tuple(int(v) for v in rng.integers(1, 12, rank)) for _ in range(n)]
+    shapes.sort(key=lambda s: int(np.prod(s)))
+    xs = [torch.empty(s) for s in shapes]
+    t0 = time.time()
+    res = U.oracle_split_group(xs, group)
+    assert time.time() - t0 < 30
+    pos = res[-1]
+    assert pos[0] == 0 and pos[-1] == n and all(p < q for p, q in zip(pos, pos[1:]))
+    for k, shape in enumerate(res[:-1]):
+        grp = shapes[pos[k]:pos[k + 1]]
+        assert shape == [max(s[d] for s in grp) for d in range(rank)]
+    if n <= 2000:      # the python restatement of origin.oracle_split_group on the numels (quadratic: small n only)
+        assert pos == R.oracle_split_group([int(np.prod(s)) for s in shapes], group)
+
+
+def test_unsorted_long_list_is_refused_not_quadratic():
+    import hpc_rl_utils as U
+    xs = [torch.empty(3, (i * 7919) % 50 + 1) for i in range(20001)]      # not sorted by numel
+    with pytest.raises(RuntimeError):
+        U.oracle_split_group(xs, 4)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 output of the headline bench (gpurun_out/prof_r01/{trace,fetch,write}) into the committed
+"""Turn the raw rocprofv3 output of the headline bench (gpurun_out/prof_<tag>/{trace,fetch,write}, collected by
+tests/tools/collect_profiles.sh) into the committed
 summaries under profiles/: kernel stats of `python bench.py`, per-launch HBM traffic from the PMC passes (FETCH_SIZE
 and WRITE_SIZE collected in separate runs; FETCH_SIZE x2 per MI355X_MICROARCH.md, checked against the calibration copy
 inside the same run), and profiles/gae_traffic.json which bench.py reads for roofline.traffic."""
@@ -11,8 +12,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src = os.path.join(ROOT, "gpurun_out", "prof_r01")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 out = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(out, f"{tag}_gae_bench_kernel_stats.csv"))
 agg = collections.defaultdict(list)
