@@ -383,10 +383,11 @@ def scatter_connection(x: torch.Tensor, location: torch.Tensor, H: int, W: int, 
         # entity (also the overwritten ones) receives the gradient of its cell -- which is also what
         # the reference's backward kernel does (scatter_connection_kernel.h:91-106).  scatter_add
         # has exactly that backward, so use it as the straight-through gradient carrier.
-        win = torch.full((B, H * W), -1, dtype=torch.long)
+        win = torch.full((B, H * W), -1, dtype=torch.long, device=x.device)
+        rows = torch.arange(B, device=x.device)
         for m in range(M):
-            win[torch.arange(B), cell[:, m]] = m
-        gathered = x.detach()[torch.arange(B).unsqueeze(1), win.clamp(min=0)]
+            win[rows, cell[:, m]] = m
+        gathered = x.detach()[rows.unsqueeze(1), win.clamp(min=0)]
         fwd = torch.where((win >= 0).unsqueeze(-1), gathered, torch.zeros_like(gathered))
         carrier = out.scatter_add(1, cell.unsqueeze(-1).expand(B, M, N), x)
         out = fwd + (carrier - carrier.detach())

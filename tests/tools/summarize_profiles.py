@@ -15,16 +15,48 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 out = os.path.join(ROOT, "profiles")
-shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(out, f"{tag}_gae_bench_kernel_stats.csv"))
+import sqlite3
+
+
+def kernel_stats():
+    """Per-kernel statistics of the --kernel-trace run: rocprofv3 of ROCm 7.2 writes a rocpd SQLite database by default
+    (older builds a trace_kernel_stats.csv, which is copied as is)."""
+    csv_path = os.path.join(src, "trace", "trace_kernel_stats.csv")
+    dst = os.path.join(out, f"{tag}_gae_bench_kernel_stats.csv")
+    if os.path.exists(csv_path):
+        shutil.copy(csv_path, dst)
+        return
+    con = sqlite3.connect(os.path.join(src, "trace", "trace_results.db"))
+    rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                       "group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows)
+    with open(dst, "w") as f:
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
+        for name, calls, tot, avg, mn, mx in rows:
+            short = name if len(name) <= 200 else name[:197] + "..."
+            f.write(f'"{short}",{calls},{tot},{avg:.3f},{100.0 * tot / total:.2f},{mn},{mx}\n')
+
+
+def counter_rows(name):
+    csv_path = os.path.join(src, name, f"{name}_counter_collection.csv")
+    if os.path.exists(csv_path):
+        for r in csv.DictReader(open(csv_path)):
+            yield r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])
+        return
+    con = sqlite3.connect(os.path.join(src, name, f"{name}_results.db"))
+    for k, c, v in con.execute("select kernel_name, counter_name, value from counters_collection"):
+        yield k, c, float(v)
+
+
+kernel_stats()
 agg = collections.defaultdict(list)
 full = {}
 for name in ("fetch", "write"):
-    for r in csv.DictReader(open(os.path.join(src, name, f"{name}_counter_collection.csv"))):
-        k = r["Kernel_Name"]
+    for k, cname, val in counter_rows(name):
         short = ("gae_fwd_kernel" if "gae_fwd_kernel" in k else "gae_bwd_kernel" if "gae_bwd_kernel" in k
                  else "copyBuffer(calibration)" if "copyBuffer" in k else None)
         if short:
-            agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            agg[(short, cname)].append(val)
             full[short] = k.split("(")[0][-60:] if "gae" in k else short
 T, B = 1024, 65536
 alg = 12 * T * B + 4 * B
@@ -44,6 +76,11 @@ for k in ("gae_fwd_kernel", "gae_bwd_kernel"):
 open(os.path.join(out, f"{tag}_gae_pmc_traffic.csv"), "w").write("\n".join(lines) + "\n")
 json.dump({"T": T, "B": B, **traffic, "source": f"profiles/{tag}_gae_pmc_traffic.csv (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md)"},
           open(os.path.join(out, "gae_traffic.json"), "w"), indent=1)
+prof_log = os.path.join(src, "trace.log")
+if os.path.exists(prof_log):   # the bench line printed by the PROFILED command itself (its live kernel timings agree with
+    for line in open(prof_log):   # the trace; un-profiled the same binary runs at a higher clock)
+        if line.startswith('{"metric"'):
+            open(os.path.join(out, f"{tag}_bench_under_rocprof.json"), "w").write(line)
 bench = os.path.join(ROOT, "gpurun_out", "bench.log")
 if os.path.exists(bench):
     open(os.path.join(out, f"{tag}_bench_n1.json"), "w").write(open(bench).read().strip().splitlines()[-1] + "\n")
