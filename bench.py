@@ -227,13 +227,18 @@ def main():
             detail["strong_per_rank_probe"] = {str(n): {"eager": leg(GB // n, False), "graph": leg(GB // n, True)}
                                                for n in (2, 4, 8)}
 
+    # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not
+    # fit one pass and cannot be combined with tracing), so the figure is the committed result of
+    # tests/tools/collect_profiles.sh for this shape (profiles/<round>_gae_pmc_traffic.csv), not a live measurement
     traffic = None
+    traffic_source = None
     tj = os.path.join(ROOT, "profiles", "gae_traffic.json")
     if os.path.exists(tj):
         try:
             rec = json.load(open(tj))
             if rec.get("T") == T and rec.get("B") == B:
                 traffic = rec.get(dom)
+                traffic_source = rec.get("source")
         except Exception:
             traffic = None
 
@@ -258,6 +263,7 @@ def main():
                        "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_launch / t_dom / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bytes_launch / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "fwd_us": t_fwd * 1e6, "bwd_us": t_bwd * 1e6,
                          "fwd_bwd_frac": (2 * bytes_launch) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS},
