@@ -205,10 +205,11 @@ struct TileStage {
 // Resident workgroups per CU the LDS footprint allows (160 KB per CU); the register allocation is steered to match
 // (launch_bounds' second argument = waves per SIMD): at 136 registers the 128x128x16 tile ran 3 workgroups per CU, so
 // a 1024-tile product (the C4 recurrent GEMM) ran as 768 + a 256-workgroup tail at one workgroup per CU.
-template <int BM, int BN, int BK> struct GemmOcc {
+template <int BM, int BN, int BK, int NW = 4> struct GemmOcc {
     static constexpr int lds = 2 * BK * (BM + BN) * 4;
-    // (256x128 tiles hold 128 accumulator registers per lane: two waves per SIMD)
-    static constexpr int value = BM * BN >= 256 * 128 ? 2 : lds <= 36 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : 2;
+    // (256x128 tiles hold 128 accumulator registers per lane: two waves per SIMD; a 16-wave workgroup IS the CU's
+    //  four waves per SIMD: one workgroup per CU)
+    static constexpr int value = NW == 16 ? 1 : BM * BN >= 256 * 128 ? 2 : lds <= 36 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : 2;
 };
 
 // INTERIOR: every tile of the launch lies entirely inside A, B and its K slice (M % BM == N % BN == K % BK == 0, no
@@ -224,10 +225,12 @@ template <int BM, int BN, int BK> struct GemmOcc {
 // tiles, with full or half cache lines per load (TN / NT / NN all within 127-130): what the stream costs is not its
 // latency but the ISSUE of the vector-memory instructions beside the MFMAs (~65 cycles of matrix pipe per
 // global_load_dwordx4 of a wave; MI355X_MICROARCH.md quotes ~60 for an LDS-DMA piece).
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool INTERIOR, int ABL = 0>
-__global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_kernel(const GemmArgs g) {
+// NW: waves per workgroup (4, or 16 for the 256x256 tile: half the vector-memory instructions per MFMA).
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool INTERIOR, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int WAVES_M = BM / (32 * WM);
-    static_assert(WAVES_M * (BN / (32 * WN)) == 4, "4 waves per workgroup");
+    constexpr int NTH = NW * 64;
+    static_assert(WAVES_M * (BN / (32 * WN)) == NW, "waves per workgroup");
     __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
     float* const As = lds;                 // [buf][BK*BM]
     float* const Bs = lds + 2 * BK * BM;   // [buf][BK*BN]
@@ -257,9 +260,9 @@ __global__ __launch_bounds__(256, (GemmOcc<BM, BN, BK>::value)) void gemm_f32_ke
 
     // who stages what: both tiles together <= 256 blocks -> disjoint wave sets, one block per thread
     constexpr int NBA = BM * BK / 16, NBB = BN * BK / 16;
-    constexpr bool SPLIT = NBA + NBB <= 256 && NBA % 64 == 0 && NBB % 64 == 0;
-    TileStage<BM, BK, AMODE, 0, SPLIT ? NBA : 256> sa;
-    TileStage<BN, BK, BMODE, SPLIT ? NBA : 0, SPLIT ? NBB : 256> sb;
+    constexpr bool SPLIT = NBA + NBB <= NTH && NBA % 64 == 0 && NBB % 64 == 0;
+    TileStage<BM, BK, AMODE, 0, SPLIT ? NBA : NTH> sa;
+    TileStage<BN, BK, BMODE, SPLIT ? NBA : 0, SPLIT ? NBB : NTH> sb;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -470,20 +473,26 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     const int bk = g_gemm_bk ? g_gemm_bk
                              : (((am == kContigK && bm == kContigMN) || (g.big && t.bm == 128 && t.bn == 128)) ? 16 : 32);
     extern int g_gemm_tile256;   // tuning knob (hpc_rll_tune_set key 16)
-    if (g_gemm_tile256 && t.bm == 128 && t.bn == 128 && bk == 16 && am != kGeneric && bm != kGeneric &&
-        g.M % 256 == 0 && g.N % 128 == 0 && g.K % 16 == 0 &&
-        (long)(g.M / 256) * (g.N / 128) * (g.splitk > 1 ? g.splitk : 1) >= 512) {
-        // 256x128x16, 128x64 per wave: 6 operand registers per 8 MFMAs instead of 4 per 4 (LDS read traffic -25 %)
-        const dim3 grid(g.N / 128, g.M / 256, g.splitk > 1 ? g.splitk : 1);
-        GemmArgs h = g;
-        h.xcd_swizzle = 0;
-#define HPC_RLL_GEMM256(AM, BMD)                                                                                   \
-        if (am == AM && bm == BMD) {                                                                               \
-            hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 16, 4, 2, AM, BMD, true>), grid, dim3(256), 0, st, h);      \
-            return;                                                                                                \
-        }
-        HPC_RLL_GEMM256(kContigK, kContigMN) HPC_RLL_GEMM256(kContigK, kContigK) HPC_RLL_GEMM256(kContigMN, kContigMN)
+    {
+        // 256x256x16 tiles, 16 waves (one workgroup = a CU's four waves per SIMD): half the vector-memory instructions per
+        // MFMA of the 128x128 tile -- the cost the ablation isolates (profiles/r02_gemm_ablate.txt: 4096^3 128.9 ->
+        // 136.5 TFLOP/s, K=1024 x 65536 rows 128.4 -> 133.7; same k order, bit-identical results).  One workgroup per CU
+        // means coarse rounds: only when the workgroup count is a multiple of the CU count or the tail is negligible.
+        const int sk = g.splitk > 1 ? g.splitk : 1;
+        const long wgs = (long)(g.M / 256) * (g.N / 256) * sk;
+        if (g_gemm_tile256 && am != kGeneric && bm != kGeneric && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 16 == 0 &&
+            (wgs % 256 == 0 || wgs >= 4096)) {
+            const dim3 grid(g.N / 256, g.M / 256, sk);
+            GemmArgs h = g;
+            h.xcd_swizzle = 0;   // measured neutral for this tile (136.5 vs 136.7)
+#define HPC_RLL_GEMM256(AM, BMD)                                                                                          \
+            if (am == AM && bm == BMD) {                                                                                  \
+                hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 16, 2, 2, AM, BMD, true, 0, 16>), grid, dim3(1024), 0, st, h); \
+                return;                                                                                                   \
+            }
+            HPC_RLL_GEMM256(kContigK, kContigMN) HPC_RLL_GEMM256(kContigK, kContigK) HPC_RLL_GEMM256(kContigMN, kContigMN)
 #undef HPC_RLL_GEMM256
+        }
     }
     if (t.bm == 32) launch_gemm_tile<32, 128, 32, 1, 1>(g, am, bm, st);
     else if (t.bm == 128 && t.bn == 128) {

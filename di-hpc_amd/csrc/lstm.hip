@@ -26,7 +26,7 @@
 
 namespace hpc_rll {
 int g_gemm_bk = 0;
-int g_gemm_tile256 = 0;   // 256x128x16 tiles for large interior products (tune key 16; experiment)
+int g_gemm_tile256 = 1;   // 256x256x16 tiles (16 waves) for interior products that fill the chip in whole rounds (tune key 16)
 int g_cell_vec4 = 3;   // smallest ceil(H/256) that takes the 16-byte forward cell kernel (tune key 15; 0 = never)
 int g_gemm_xcd = 1;
 int g_gemm_lat_target = 256;

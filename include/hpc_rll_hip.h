@@ -103,9 +103,10 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * key 11: LSTM backward products against transposed weight copies (large batches) on/off.  key 12: 128x128 tiles
  * for the dh product when it runs as NN.  key 13: workgroups the latency-regime split-K aims for (default 256).
  * key 14: k-tiles (of 32) a slice must keep in the throughput-regime split-K (default 8).  key 15: smallest
- * ceil(H/256) that takes the 16-byte forward cell kernel (default 3, 0 = never).  key 16: 1 = 256x128x16 GEMM
- * tiles (128x64 per wave) for large interior products -- an experiment, measured neutral (C4 LSTM 79.1 / 164.4 vs
- * 79.6 / 163.6 ms), default 0.  key 17: LDS-staged streaming scatter forward kernel on (1, default) / off (0: the
+ * ceil(H/256) that takes the 16-byte forward cell kernel (default 3, 0 = never).  key 16: 1 (default) = 256x256x16 GEMM
+ * tiles with 16 waves per workgroup for interior products whose workgroup count is a multiple of the CU count (or >=
+ * 4096) -- half the vector-memory instructions per MFMA of the 128x128 tile, bit-identical results; 0 = never.
+ * key 17: LDS-staged streaming scatter forward kernel on (1, default) / off (0: the
  * round-1 cells-per-thread kernel).  key 18: channels per workgroup of that kernel (0 = largest of 64/32/16/8/4 whose
  * x tile fits 52 KB of LDS, or a multiple of 4 in 4..64).
  */

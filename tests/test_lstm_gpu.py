@@ -361,3 +361,28 @@ def test_persistent_lstm_survives_a_busy_device(S, B, I, H, L):
     assert NW.async_error() == 0
     for y1, y2 in outs:
         assert torch.equal(y1.detach(), quiet[0]) and torch.equal(y2.detach(), quiet[0])
+
+
+def test_gemm_256_tile_is_bit_identical_to_128_tile():
+    """Tune key 16: interior products whose 256x256 workgroup count fills the chip in whole rounds run 16-wave 256x256x16
+    tiles (half the vector-memory instructions per MFMA); same k order, so NN / NT / TN results must equal the 128x128
+    tiles' bit for bit -- with and without split-K partial slices."""
+    import hpc_torch_utils_network as U
+    g = torch.Generator(device=DEV).manual_seed(0)
+    M, N, K = 4096, 4096, 512
+    a = torch.randn(M, K, device=DEV, generator=g)
+    b = torch.randn(K, N, device=DEV, generator=g)
+    bt = b.t().contiguous()
+    at_ = a.t().contiguous()
+    try:
+        outs = {}
+        for key in (1, 0):
+            U.tune_set(16, key)
+            outs[key] = (U.gemm_f32(a, b), U.gemm_f32(a, bt.t()), U.gemm_f32(at_.t(), b))
+        for x, y in zip(outs[1], outs[0]):
+            assert torch.equal(x, y)
+        assert torch.equal(outs[1][0], outs[1][1]) and torch.equal(outs[1][0], outs[1][2])
+        ref = a.double() @ b.double()
+        assert ((outs[1][0].double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    finally:
+        U.tune_set(16, 1)

@@ -31,7 +31,7 @@ __global__ void clock_probe(long long* out, int ms) {
 
 // LAYOUT 0: NN (A k-contiguous, B n-contiguous)  1: TN (both contiguous along m/n: full 128-byte lines per load)
 //        2: NT (both k-contiguous: 16 floats = HALF a line per row and k-tile at BK = 16)
-template <int BM, int BN, int BK, int WM, int WN, int ABL, int LAYOUT = 0>
+template <int BM, int BN, int BK, int WM, int WN, int ABL, int LAYOUT = 0, int NW = 4>
 static double run(const char* tag, const float* A, const float* B, float* C, int M, int N, int K, int xcd) {
     GemmArgs g{A, B, C, M, N, K, (long)K, 1, (long)N, 1, (long)N, 0};
     if (LAYOUT == 1) { g.a_sm = 1; g.a_sk = M; }
@@ -39,15 +39,15 @@ static double run(const char* tag, const float* A, const float* B, float* C, int
     g.xcd_swizzle = xcd;
     const dim3 grid(N / BN, M / BM, 1);
     auto k = gemm_f32_kernel<BM, BN, BK, WM, WN, (LAYOUT == 1 ? kContigMN : kContigK), (LAYOUT == 2 ? kContigK : kContigMN),
-                             true, ABL>;
+                             true, ABL, NW>;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(256), 0, 0, g);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), 0, 0, g);
     double best = 1e30;
     for (int r = 0; r < 5; ++r) {
         hipEventRecord(e0, 0);
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, grid, dim3(256), 0, 0, g);
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), 0, 0, g);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -60,9 +60,9 @@ static double run(const char* tag, const float* A, const float* B, float* C, int
     static long long* d_clk = nullptr;
     if (!s2) { hipStreamCreate(&s2); hipMalloc(&d_clk, 16); }
     const int reps = (int)(25.0 / best) + 1;
-    for (int i = 0; i < reps / 4 + 1; ++i) hipLaunchKernelGGL(k, grid, dim3(256), 0, 0, g);   // get going first
+    for (int i = 0; i < reps / 4 + 1; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), 0, 0, g);   // get going first
     hipLaunchKernelGGL(clock_probe, dim3(1), dim3(64), 0, s2, d_clk, 15);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(256), 0, 0, g);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), 0, 0, g);
     hipDeviceSynchronize();
     long long h[2];
     hipMemcpy(h, d_clk, 16, hipMemcpyDeviceToHost);
@@ -103,6 +103,13 @@ int main() {
         run<128, 128, 16, 2, 2, 2>("128x128x16 ABL2 +global prefetch", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 3>("128x128x16 ABL3 +lds store+barrier", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 0>("128x128x16 full, no xcd order", A, B, C, M, N, K, 0);
+        run<256, 256, 16, 2, 2, 0, 0, 16>("256x256x16 16 waves full NN", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 0, 0, 16>("256x256x16 16 waves, no xcd order", A, B, C, M, N, K, 0);
+        run<256, 256, 16, 2, 2, 1, 0, 16>("256x256x16 16 waves ABL1", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 3, 0, 16>("256x256x16 16 waves ABL3", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 0, 2, 16>("256x256x16 16 waves NT", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 0, 1, 16>("256x256x16 16 waves TN", A, B, C, M, N, K, 1);
+        run<256, 256, 32, 2, 2, 0, 0, 16>("256x256x32 16 waves full NN", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 0, 1>("128x128x16 full TN (full lines)", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 0, 2>("128x128x16 full NT (half lines)", A, B, C, M, N, K, 1);
         run<128, 128, 32, 2, 2, 0, 2>("128x128x32 full NT (full lines)", A, B, C, M, N, K, 1);
