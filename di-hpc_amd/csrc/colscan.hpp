@@ -41,19 +41,27 @@ namespace hpc_rll {
 //   template<int V> void coeffs(const Row<V>&, int t, float (&a)[V], float (&b)[V]) const;
 //   template<int V> void finish(const Row<V>&, int t, long col, bool ok, const float (&s)[V],
 //                               const float (&s_next)[V], float (&acc)[NACC]) const;   outputs + sums
-template <class Op, int V, int LC, int NW>
+// SUB (V = 1 only): sub-wave tiles for narrow batches -- a wave's 64 lanes are SUB groups of 64/SUB columns and the
+// groups own SUB DIFFERENT chunks of the time axis ("virtual waves", as gae.hip's half-wave tiles): SUB x more
+// workgroups and SUB x more steps per barrier.  At the reference's TD-lambda test shape (T=1024, B=64) the 64-column
+// tiling is ONE workgroup walking 8 barriers.
+template <class Op, int V, int LC, int NW, int SUB = 1>
 __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T, int B,
                                                               float* __restrict__ partials) {
-    constexpr int TILE = 64 * V;
+    static_assert(SUB == 1 || V == 1, "sub-wave tiles hold one column per lane");
+    constexpr int NWV = NW * SUB;                 // virtual waves per workgroup
+    constexpr int TILE = 64 * V / SUB;
     constexpr int NACC = Op::NACC;
-    __shared__ float lds[4 * NW * TILE + NW * (NACC > 0 ? NACC : 1)];
-    float* const s_l0 = lds;                      // [buf][wave][TILE]
-    float* const s_p0 = lds + 2 * NW * TILE;      // [buf][wave][TILE]
-    float* const s_red = lds + 4 * NW * TILE;     // [NACC][NW]
+    __shared__ float lds[4 * NWV * TILE + NW * (NACC > 0 ? NACC : 1)];
+    float* const s_l0 = lds;                      // [buf][virtual wave][TILE]
+    float* const s_p0 = lds + 2 * NWV * TILE;     // [buf][virtual wave][TILE]
+    float* const s_red = lds + 4 * NWV * TILE;    // [NACC][NW]
 
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    const int wr = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cl = SUB == 1 ? lane : (lane & (TILE - 1));          // column lane inside the tile
+    const int w = SUB == 1 ? wr : SUB * wr + lane / TILE;         // (virtual) wave: lane dependent when SUB > 1
+    const long col = (long)blockIdx.x * TILE + (long)cl * V;
     const bool ok = col < (long)B;
 
     float carry[V];
@@ -62,10 +70,10 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
 #pragma unroll
     for (int k = 0; k < (NACC > 0 ? NACC : 1); ++k) acc[k] = 0.f;
 
-    constexpr int SPAN = NW * LC;
+    constexpr int SPAN = NWV * LC;
     const int n_iter = (T + SPAN - 1) / SPAN;
     for (int it = 0; it < n_iter; ++it) {
-        const int t1 = T - (it * NW + (NW - 1 - w)) * LC;
+        const int t1 = T - (it * NWV + (NWV - 1 - w)) * LC;
         const int t0 = t1 - LC;
         const int buf = it & 1;
 
@@ -98,8 +106,8 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            s_l0[(buf * NW + w) * TILE + lane * V + k] = L[0][k];
-            s_p0[(buf * NW + w) * TILE + lane * V + k] = P[0][k];
+            s_l0[(buf * NWV + w) * TILE + cl * V + k] = L[0][k];
+            s_p0[(buf * NWV + w) * TILE + cl * V + k] = P[0][k];
         }
         __syncthreads();
 
@@ -107,15 +115,15 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
 #pragma unroll
         for (int k = 0; k < V; ++k) { A[k] = carry[k]; Aw[k] = 0.f; }
 #pragma unroll
-        for (int u = NW - 1; u >= 0; --u) {
+        for (int u = NWV - 1; u >= 0; --u) {
             if (u == w) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) Aw[k] = A[k];
             }
 #pragma unroll
             for (int k = 0; k < V; ++k)
-                A[k] = fmaf(s_p0[(buf * NW + u) * TILE + lane * V + k], A[k],
-                            s_l0[(buf * NW + u) * TILE + lane * V + k]);
+                A[k] = fmaf(s_p0[(buf * NWV + u) * TILE + cl * V + k], A[k],
+                            s_l0[(buf * NWV + u) * TILE + cl * V + k]);
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) carry[k] = A[k];
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
 #pragma unroll
         for (int k = 0; k < NACC; ++k) {
             const float sum = wave_sum(acc[k]);
-            if (lane == 0) s_red[k * NW + w] = sum;
+            if (lane == 0) s_red[k * NW + wr] = sum;
         }
         __syncthreads();
         if (threadIdx.x < NACC) {
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
     }
 }
 
-struct ScanCfg { int v, lc, nw; };
+struct ScanCfg { int v, lc, nw, sub; };
 
 // V=1 or 2 (the fat rows of V-trace/UPGO do not fit V=4), LC = 8, NW up to 16 for small B.
 inline ScanCfg scan_cfg(int T, int B, bool can_v2) {
@@ -164,12 +172,28 @@ inline ScanCfg scan_cfg(int T, int B, bool can_v2) {
     c.nw = 4;
     while (c.nw < 16 && wgs * c.nw < 2048) c.nw <<= 1;
     while (c.nw > 1 && c.nw > chunks) c.nw >>= 1;
+    // narrow batches: sub-wave tiles while the grid is below one workgroup per CU and barriers remain to be saved
+    c.sub = 1;
+    if (c.v == 1 && c.nw == 16)
+        while (c.sub < 4 && (long)wgs * c.sub < 256 && chunks >= 2 * c.nw * c.sub) c.sub <<= 1;
     return c;
+}
+inline unsigned scan_grid(const ScanCfg& c, int B) {
+    const int tile = 64 * c.v / c.sub;
+    return (unsigned)((B + tile - 1) / tile);
 }
 
 template <class Op, bool ALLOW_V2 = true>
 inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* partials, hipStream_t st) {
-    const unsigned grid = (unsigned)((B + 64 * c.v - 1) / (64 * c.v));
+    const unsigned grid = scan_grid(c, B);
+    if (c.sub == 2 && c.v == 1 && c.nw == 16) {
+        hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 2>), dim3(grid), dim3(1024), 0, st, op, T, B, partials);
+        return;
+    }
+    if (c.sub == 4 && c.v == 1 && c.nw == 16) {
+        hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 4>), dim3(grid), dim3(1024), 0, st, op, T, B, partials);
+        return;
+    }
 #define HPC_RLL_SCAN_CASE(V_, NW_)                                                                          \
     if (c.v == V_ && c.nw == NW_) {                                                                         \
         hipLaunchKernelGGL((colscan_rev_kernel<Op, V_, 8, NW_>), dim3(grid), dim3(NW_ * 64), 0, st, op, T, B, \
@@ -185,10 +209,7 @@ inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* 
 #undef HPC_RLL_SCAN_CASE
 }
 
-inline int scan_num_blocks(int T, int B, bool can_v2) {
-    const ScanCfg c = scan_cfg(T, B, can_v2);
-    return (B + 64 * c.v - 1) / (64 * c.v);
-}
+inline int scan_num_blocks(int T, int B, bool can_v2) { return (int)scan_grid(scan_cfg(T, B, can_v2), B); }
 
 // reduce.hip
 int finalize_sums(const float* partials, int nblocks, int nacc, const float* scales /*host, nacc*/, float* out,

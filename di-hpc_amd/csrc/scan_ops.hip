@@ -231,7 +231,7 @@ extern "C" int hpc_rll_td_lambda_forward(const float* value, const float* reward
     int rc = last_error();
     if (rc) return rc;
     const float sc = 0.5f * scale;
-    return finalize_sums(partials, (B + 64 * c.v - 1) / (64 * c.v), 1, &sc, loss, st);
+    return finalize_sums(partials, (int)scan_grid(c, B), 1, &sc, loss, st);
 }
 
 extern "C" int hpc_rll_td_lambda_backward(const float* grad_loss, const float* grad_buf, float* grad_value, int T,
@@ -243,7 +243,7 @@ extern "C" int hpc_rll_td_lambda_backward(const float* grad_loss, const float* g
 // ------------------------------------------------------------------------------------------------ V-trace
 // ws layout (floats): [coef_pg TB | coef_ent TB | gv_unit TB | logp_t TB | ent TB | logp_b TB | partials]
 extern "C" int64_t hpc_rll_vtrace_workspace_floats(int T, int B) {
-    return 6 * (int64_t)T * B + 8 * (((int64_t)B + 63) / 64 + 1);
+    return 6 * (int64_t)T * B + 8 * (((int64_t)B + 31) / 32 + 1);   // partials: 3 sums x up to ceil(B/16) workgroups
 }
 
 extern "C" int hpc_rll_vtrace_forward(const float* target_output, const float* behaviour_output,
@@ -269,7 +269,7 @@ extern "C" int hpc_rll_vtrace_forward(const float* target_output, const float* b
     rc = last_error();
     if (rc) return rc;
     const float sc[3] = {scale, scale, scale};
-    return finalize_sums(partials, (B + 64 * c.v - 1) / (64 * c.v), 3, sc, losses, st);
+    return finalize_sums(partials, (int)scan_grid(c, B), 3, sc, losses, st);
 }
 
 extern "C" int hpc_rll_vtrace_backward(const float* g_pg, const float* g_value, const float* g_ent,
@@ -315,7 +315,7 @@ extern "C" int hpc_rll_upgo_forward(const float* target_output, const float* rho
     launch_colscan<UpgoOp, false>(op, c, T, B, partials, st);
     rc = last_error();
     if (rc) return rc;
-    return finalize_sums(partials, (B + 64 * c.v - 1) / (64 * c.v), 1, &scale, loss, st);
+    return finalize_sums(partials, (int)scan_grid(c, B), 1, &scale, loss, st);
 }
 
 extern "C" int hpc_rll_upgo_backward(const float* g, const float* target_output, const int64_t* action,
