@@ -95,14 +95,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hpc_rll product path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # TEST HOOKS (tests/test_dist.py runs this file with 2 ranks on a ONE-GPU box, where RCCL refuses two ranks per
+    # device): HPC_RLL_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, HPC_RLL_BENCH_BACKEND=gloo swaps the backend.  The
+    # driver's runs set neither: one rank per GPU over RCCL.
+    one_device = os.environ.get("HPC_RLL_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("HPC_RLL_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", 0 if one_device else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1 or "RANK" in os.environ:   # under torch.distributed.run (also with one rank: same code path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     import hpc_rl_utils as U
@@ -162,7 +170,7 @@ def main():
         mine = time.perf_counter() - t0
         if dist is None:
             return mine, [mine]
-        t = torch.tensor([mine], device=dev, dtype=torch.float64)
+        t = torch.tensor([mine], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank = [x.item() for x in allt]

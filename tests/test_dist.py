@@ -395,3 +395,35 @@ def test_gpu_rccl_backend_on_device_tensors():
     loss, info = PPO(B, N)(ln, f(B, N), act, f(B), f(B), f(B), f(B))
     sum(loss).sum().backward()
     assert [x.item() for x in loss] == rl and list(info) == rinfo and np.array_equal(ln.grad.cpu().numpy(), gln)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_emits_both_scaling_readings(tmp_path):
+    """bench.py under torch.distributed.run with TWO ranks: one JSON line from rank 0 with the
+    headline, per-rank step times, and `scaling_detail` carrying weak AND strong readings (eager and hipGraph) with the
+    world size it saw.  Two ranks share the one GPU of the test box, so the test hooks put both on cuda:0 over gloo
+    (RCCL refuses two ranks per device); the driver's 2/4/8-GPU runs use the same code with one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HPC_RLL_BENCH_ONE_DEVICE="1", HPC_RLL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--B", "4096", "--skip-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["B_per_gpu"] == 4096 and d["config"]["global_B"] == 8192
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["cpu_baseline"] is None
+    assert abs(d["value"] - 1024 * 8192 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    sd = d["scaling_detail"]
+    assert sd["world_size"] == 2 and sd["backend"] == "gloo"
+    for reading, per_gpu in (("weak", 65536), ("strong", 32768)):
+        for launch in ("eager", "graph"):
+            leg = sd[reading][launch]
+            assert leg["B_per_gpu"] == per_gpu and leg["global_B"] == 2 * per_gpu
+            assert len(leg["per_rank_ms_per_step"]) == 2 and len(leg["rounds_ms_per_step"]) == 3 and leg["ms_per_step"] > 0
+    assert sd["strong_per_rank_probe"] is None        # only printed by a single rank
