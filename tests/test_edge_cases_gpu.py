@@ -193,3 +193,64 @@ def test_inplace_change_between_forward_and_backward_is_caught():
         m.wh.add_(0.1)                              # e.g. optimizer.step() before a second backward
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         y.sum().backward()
+
+
+def test_loss_ops_capture_into_a_hip_graph():
+    """Strong scaling ends in the launch-latency regime, where a training step is meant to be replayed from a hipGraph.
+    Every scalar-loss op (forward + backward through the C++ autograd nodes), ScatterConnection and the packed Pad take
+    their outputs and scratch from torch's allocator on the current stream and never synchronise, so a captured step
+    replays bit-identically.  (PPO is the exception by API: it returns python floats, i.e. a host sync.)"""
+    from hpc_rll.rl_utils.padding import Padding1DPacked
+    from hpc_rll.rl_utils.td import QNStepTD, TDLambda
+    from hpc_rll.rl_utils.upgo import UPGO
+    from hpc_rll.rl_utils.vtrace import VTrace
+    from hpc_rll.torch_utils.network.scatter_connection import ScatterConnection
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    T, B, N = 40, 96, 12
+    to, bo = rn(T, B, N).requires_grad_(True), rn(T, B, N)
+    a = torch.randint(0, N, (T, B), device=DEV, generator=g)
+    v, r, rho = rn(T + 1, B).requires_grad_(True), rn(T, B), torch.rand(T, B, device=DEV, generator=g)
+    q, nq = rn(B, N).requires_grad_(True), rn(B, N)
+    qa, qna = torch.randint(0, N, (B,), device=DEV, generator=g), torch.randint(0, N, (B,), device=DEV, generator=g)
+    rew, done, w = rn(3, B), torch.zeros(B, device=DEV), torch.ones(B, device=DEV)
+    x = rn(4, 20, 8).requires_grad_(True)
+    loc = torch.stack([torch.randint(0, 6, (4, 20), device=DEV, generator=g), torch.randint(0, 5, (4, 20), device=DEV, generator=g)], -1)
+    lens = torch.randint(1, 9, (50,), device=DEV, generator=g)
+    flat = rn(int(lens.sum().item()))
+    mods = (TDLambda(T, B), VTrace(T, B, N), UPGO(T, B, N), QNStepTD(3, B, N), ScatterConnection(4, 20, 8, 6, 5, "add"))
+
+    def step():
+        for p in (to, v, q, x):
+            p.grad = None
+        l1 = mods[0](v, r)
+        l2 = mods[1](to, bo, a, v, r)
+        l3 = mods[2](to, rho, a, r, v)
+        l4, _ = mods[3](q, nq, qa, qna, rew, done, w, 0.9)
+        y = mods[4](x, loc)
+        (l1 + sum(l2) + l3 + l4 + (y * y).sum()).sum().backward()
+        px, pm = Padding1DPacked(flat, lens, max_len=8)
+        return l1, l2, l3, l4, y, px, pm
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            eager = step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    flat_e = [t.clone() for t in (eager[0], *eager[1], eager[2], eager[3], eager[4], eager[5], eager[6])]
+    grads_e = [p.grad.clone() for p in (to, v, q, x)]
+    for p in (to, v, q, x):
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    flat_g = (out[0], *out[1], out[2], out[3], out[4], out[5], out[6])
+    for e, c in zip(flat_e, flat_g):
+        assert torch.equal(e, c)
+    for e, p in zip(grads_e, (to, v, q, x)):
+        assert torch.equal(e, p.grad)
