@@ -17,6 +17,7 @@
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <initializer_list>
 #include <mutex>
@@ -113,13 +114,23 @@ inline float loss_scale(std::optional<double> scale, int64_t local_count) {
 // this library's recompute-in-backward kernels need (the logits, ONE workspace).  The forward therefore parks the
 // tensors under the address of one of the reference's own scratch buffers that also appears in the backward list,
 // and the backward picks them up.  An entry lives until the next forward with the same buffer replaces it
-// (backward may run more than once: retain_graph).
+// (backward may run more than once: retain_graph); the table keeps the kCap most recently written entries, so modules
+// that are created and dropped in a loop cannot pin their workspaces for ever.
 class SavedByBuffer {
   public:
-    struct Entry { std::vector<Tensor> tensors; double scalar = 0.0; uint64_t seed = 0; };
+    static constexpr size_t kCap = 256;
+    struct Entry { std::vector<Tensor> tensors; double scalar = 0.0; uint64_t seed = 0; uint64_t stamp = 0; };
     void put(const Tensor& key, Entry e) {
         std::lock_guard<std::mutex> lk(mu_);
+        e.stamp = ++clock_;
         map_[key.data_ptr()] = std::move(e);
+        if (map_.size() > kCap) {   // drop the oldest half (rare: amortised O(1))
+            std::vector<std::pair<uint64_t, void*>> order;
+            order.reserve(map_.size());
+            for (auto& kv : map_) order.emplace_back(kv.second.stamp, kv.first);
+            std::sort(order.begin(), order.end());
+            for (size_t i = 0; i < order.size() / 2; ++i) map_.erase(order[i].second);
+        }
     }
     Entry get(const Tensor& key, const char* what) {
         std::lock_guard<std::mutex> lk(mu_);
@@ -130,6 +141,7 @@ class SavedByBuffer {
     }
   private:
     std::mutex mu_;
+    uint64_t clock_ = 0;
     std::unordered_map<void*, Entry> map_;
 };
 
