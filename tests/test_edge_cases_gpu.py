@@ -239,8 +239,9 @@ def test_loss_ops_capture_into_a_hip_graph():
             eager = step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    flat_e = [t.clone() for t in (eager[0], *eager[1], eager[2], eager[3], eager[4], eager[5], eager[6])]
+    flat_e = [t.detach().clone() for t in (eager[0], *eager[1], eager[2], eager[3], eager[4], eager[5], eager[6])]
     grads_e = [p.grad.clone() for p in (to, v, q, x)]
+    del eager          # drop the eager autograd graph (its AccumulateGrad nodes belong to the side stream)
     for p in (to, v, q, x):
         p.grad = None
     graph = torch.cuda.CUDAGraph()
