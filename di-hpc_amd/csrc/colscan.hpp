@@ -163,6 +163,7 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
 struct ScanCfg { int v, lc, nw, sub; };
 
 // V=1 or 2 (the fat rows of V-trace/UPGO do not fit V=4), LC = 8, NW up to 16 for small B.
+extern int g_scan_wave_target;   // hpc_rll_tune_set key 19: waves a scan launch aims for (fills NW up to 16)
 inline ScanCfg scan_cfg(int T, int B, bool can_v2) {
     ScanCfg c;
     c.v = (can_v2 && (B + 127) / 128 >= 512) ? 2 : 1;
@@ -170,7 +171,7 @@ inline ScanCfg scan_cfg(int T, int B, bool can_v2) {
     const int wgs = (B + 64 * c.v - 1) / (64 * c.v);
     const int chunks = (T + c.lc - 1) / c.lc;
     c.nw = 4;
-    while (c.nw < 16 && wgs * c.nw < 2048) c.nw <<= 1;
+    while (c.nw < 16 && wgs * c.nw < g_scan_wave_target) c.nw <<= 1;
     while (c.nw > 1 && c.nw > chunks) c.nw >>= 1;
     // narrow batches: sub-wave tiles while the grid is below one workgroup per CU and barriers remain to be saved
     c.sub = 1;

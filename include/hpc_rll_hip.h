@@ -108,7 +108,8 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * 4096) -- half the vector-memory instructions per MFMA of the 128x128 tile, bit-identical results; 0 = never.
  * key 17: LDS-staged streaming scatter forward kernel on (1, default) / off (0: the
  * round-1 cells-per-thread kernel).  key 18: channels per workgroup of that kernel (0 = largest of 64/32/16/8/4 whose
- * x tile fits 52 KB of LDS, or a multiple of 4 in 4..64).
+ * x tile fits 52 KB of LDS, or a multiple of 4 in 4..64).  key 19: waves a column-scan launch (TD-lambda, V-trace,
+ * UPGO) aims for when it picks its waves per workgroup (256..16384, default 4096).
  */
 int hpc_rll_tune_set(int key, int value);
 
