@@ -926,6 +926,14 @@ extern "C" int hpc_rll_clear_async_error(void) {
     return HPC_RLL_OK;
 }
 
+// Test hook: polls a persistent kernel waits before giving up, on the CURRENT device (0 = the shipped ~seconds).
+extern "C" int hpc_rll_test_set_persist_spin_limit(int64_t polls) {
+    using namespace hpc_rll;
+    if (polls < 0) return HPC_RLL_EINVAL;
+    const long v = polls == 0 ? kSpinLimit : (long)polls;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_persist_spin_limit), &v, sizeof(v));
+}
+
 // Test hook: launch a kernel that keeps every CU busy for ~`ms` milliseconds on `stream` (tests/test_lstm_gpu.py runs
 // the persistent LSTM on another stream meanwhile).  Not part of the operator set.
 namespace hpc_rll { namespace {
@@ -938,11 +946,12 @@ __global__ __launch_bounds__(1024) void hog_kernel(long long ticks, unsigned* si
     if (x == 0xdeadbeefu && sink) *sink = x;
 }
 } }
-extern "C" int hpc_rll_test_occupy_device(int ms, void* stream) {
+extern "C" int hpc_rll_test_occupy_device(int ms, int blocks, void* stream) {
     using namespace hpc_rll;
-    if (ms < 0 || ms > 2000) return HPC_RLL_EINVAL;
-    const int cus = persist_cu_count();
+    if (ms < 0 || ms > 2000 || blocks < 0) return HPC_RLL_EINVAL;
+    int cus = persist_cu_count();
     if (cus <= 0) return HPC_RLL_EUNSUPPORTED;
+    if (blocks > 0 && blocks < cus) cus = blocks;   // occupy only part of the device (forces partial residency)
     const size_t lds = 96 * 1024;   // one workgroup per CU holds most of its LDS: a persistent kernel cannot co-reside
     if (hipFuncSetAttribute((const void*)hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return last_error();

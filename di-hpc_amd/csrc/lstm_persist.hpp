@@ -54,13 +54,14 @@ constexpr int kPersistMaxB = 4;
 // ---- bounded waits without a trap -------------------------------------------------------------------------------
 __device__ unsigned g_persist_abort = 0;                 // set by the first wave that gives up (sticky)
 __device__ unsigned* g_persist_host_status = nullptr;    // pinned host word, see PersistRuntime
+__device__ long g_persist_spin_limit = kSpinLimit;       // polls before giving up (test hook: hpc_rll_test_set_persist_spin_limit)
 
 // one failed poll round: back off; every 1024 rounds look at the abort word / the limit
 __device__ __forceinline__ void persist_poll_failed(long& spins) {
     if (__builtin_expect(((++spins) & 1023) == 0, 0)) {
         if (__hip_atomic_load(&g_persist_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
             __builtin_amdgcn_endpgm();
-        if (spins >= kSpinLimit) {
+        if (spins >= g_persist_spin_limit) {
             __hip_atomic_store(&g_persist_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned* hs = g_persist_host_status;
             if (hs) __hip_atomic_store(hs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

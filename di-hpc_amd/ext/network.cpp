@@ -325,10 +325,15 @@ PYBIND11_MODULE(hpc_torch_utils_network, m) {
           "sticky status of the persistent small-batch LSTM kernels: 0, or HPC_RLL_ETIMEOUT (-4) once one gave up waiting");
     m.def("clear_async_error", []() { check(hpc_rll_clear_async_error(), "hpc_rll_clear_async_error"); },
           "acknowledge a timeout; the process continues on the step kernels");
-    m.def("_test_occupy_device", [](int ms, const at::Device& dev) {
+    m.def("_test_occupy_device", [](int ms, const at::Device& dev, int blocks) {
         c10::DeviceGuard g(dev);
-        check(hpc_rll_test_occupy_device(ms, stream_of(dev)), "hpc_rll_test_occupy_device");
-    }, "test hook: keep every CU of `dev` busy for ~ms milliseconds on torch's current stream");
+        check(hpc_rll_test_occupy_device(ms, blocks, stream_of(dev)), "hpc_rll_test_occupy_device");
+    }, pybind11::arg("ms"), pybind11::arg("device"), pybind11::arg("blocks") = 0,
+          "test hook: keep `blocks` CUs (0 = all) of `device` busy for ~ms milliseconds on torch's current stream");
+    m.def("_test_set_persist_spin_limit", [](int64_t polls, const at::Device& dev) {
+        c10::DeviceGuard g(dev);
+        check(hpc_rll_test_set_persist_spin_limit(polls), "hpc_rll_test_set_persist_spin_limit");
+    }, "test hook: polls a persistent LSTM kernel waits before giving up (0 = shipped value)");
     m.def("gemm_f32", &gemm_f32, py::arg("a"), py::arg("b"), py::arg("out") = py::none(), py::arg("accumulate") = false);
 
     m.def("lstm", [](const Tensor& x, const Tensor& wx, const Tensor& wh, const Tensor& bias, const Tensor& gamma,

@@ -271,9 +271,11 @@ int hpc_rll_lstm_backward(const float* dy, const float* dhn, const float* dcn, c
  * status without touching the device. */
 int hpc_rll_async_error(void);
 int hpc_rll_clear_async_error(void);
-/* Test hook, not an operator: occupy every compute unit (one 1024-thread workgroup holding 96 KB of LDS per CU) for
- * ~ms milliseconds on `stream`. */
-int hpc_rll_test_occupy_device(int ms, void* stream);
+/* Test hooks, not operators.  occupy_device: hold `blocks` compute units (0 = all; one 1024-thread workgroup with 96 KB
+ * of LDS each) for ~ms milliseconds on `stream`.  set_persist_spin_limit: polls a persistent LSTM kernel of the current
+ * device waits before it gives up (0 = the shipped value, ~seconds). */
+int hpc_rll_test_occupy_device(int ms, int blocks, void* stream);
+int hpc_rll_test_set_persist_spin_limit(int64_t polls);
 /* Exact-fp32 MFMA GEMM used by the LSTM, exposed for tests/benchmarks: C (M,N; row stride ldc) (+)= A * B with
  * A(m,k) = A[m*a_sm + k*a_sk], B(k,n) = B[k*b_sk + n*b_sn]. */
 int hpc_rll_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_sm, int64_t a_sk,

@@ -339,7 +339,7 @@ def test_persistent_lstm_survives_a_busy_device(S, B, I, H, L):
     assert NW.async_error() == 0
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
-        NW._test_occupy_device(150, DEV)
+        NW._test_occupy_device(150, DEV, 0)
     busy = run()
     torch.cuda.synchronize()
     assert NW.async_error() == 0
@@ -386,3 +386,58 @@ def test_gemm_256_tile_is_bit_identical_to_128_tile():
         assert ((outs[1][0].double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
     finally:
         U.tune_set(16, 1)
+
+
+_STARVED = r"""
+import os, sys
+sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+import torch
+import hpc_torch_utils_network as NW
+from hpc_rll.torch_utils.network.rnn import LSTM
+dev = torch.device("cuda:0")
+S, B, I, H, L = 32, 3, 64, 384, 1          # per-layer persistent kernel: 192 workgroups, one per CU (LDS)
+torch.manual_seed(0)
+m = LSTM(S, B, I, H, L).to(dev)
+x = torch.randn(S, B, I, device=dev)
+with torch.no_grad():
+    ref, _ = m(x, None)                     # quiet run on the persistent path
+torch.cuda.synchronize()
+assert NW.async_error() == 0
+NW._test_set_persist_spin_limit(2048, dev)  # give up after ~ms instead of ~seconds
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    NW._test_occupy_device(1500, dev, 160)  # 160 of 256 CUs held for 1.5 s: only part of the 192 workgroups fits
+with torch.no_grad():
+    bad, _ = m(x, None)                     # the resident workgroups give up waiting for the others
+torch.cuda.synchronize()                    # ... and the HIP context is still alive
+assert NW.async_error() == -4, NW.async_error()
+try:
+    with torch.no_grad():
+        m(x, None)
+except RuntimeError as e:
+    assert "gave up waiting" in str(e), str(e)
+else:
+    raise SystemExit("the sticky asynchronous status was not reported")
+NW.clear_async_error()
+assert NW.async_error() == 0
+with torch.no_grad():
+    again, _ = m(x, None)                   # step kernels from now on
+torch.cuda.synchronize()
+err = ((again - ref).abs().max() / ref.abs().max()).item()
+assert err < 1e-5, err
+print("starved-ok", err)
+"""
+
+
+def test_starved_persistent_kernel_reports_instead_of_trapping():
+    """The failure mode itself, provoked on purpose in a SEPARATE process (acknowledging the error switches the persistent
+    paths off for the rest of a process): the wait limit is lowered to ~ms through the test hook and 160 of the 256 CUs
+    are held for 1.5 s on a second stream, so only part of the persistent grid becomes resident.  Those workgroups give
+    up: no trap, the context survives, `async_error()` turns HPC_RLL_ETIMEOUT, the next LSTM call raises RuntimeError,
+    and after `clear_async_error()` the same module runs on the step kernels and reproduces the quiet result."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _STARVED], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "starved-ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
