@@ -949,13 +949,15 @@ __global__ __launch_bounds__(1024) void hog_kernel(long long ticks, unsigned* si
 extern "C" int hpc_rll_test_occupy_device(int ms, int blocks, void* stream) {
     using namespace hpc_rll;
     if (ms < 0 || ms > 2000 || blocks < 0) return HPC_RLL_EINVAL;
-    int cus = persist_cu_count();
+    const int cus = persist_cu_count();
     if (cus <= 0) return HPC_RLL_EUNSUPPORTED;
-    if (blocks > 0 && blocks < cus) cus = blocks;   // occupy only part of the device (forces partial residency)
-    const size_t lds = 96 * 1024;   // one workgroup per CU holds most of its LDS: a persistent kernel cannot co-reside
+    // a 1024-thread workgroup is 16 of a CU's 32 wave slots; with 80 KB of LDS exactly two fit a CU and fill it
+    // completely (waves AND LDS).  blocks = 0: 2 x CUs = the whole device; fewer: the rest of the device stays free.
+    const int n = blocks > 0 ? (blocks < 2 * cus ? blocks : 2 * cus) : 2 * cus;
+    const size_t lds = 80 * 1024;
     if (hipFuncSetAttribute((const void*)hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return last_error();
-    hipLaunchKernelGGL(hog_kernel, dim3(cus), dim3(1024), lds, (hipStream_t)stream, (long long)ms * 100000LL,
+    hipLaunchKernelGGL(hog_kernel, dim3(n), dim3(1024), lds, (hipStream_t)stream, (long long)ms * 100000LL,
                        (unsigned*)nullptr);   // wall_clock64 ticks at 100 MHz
     return last_error();
 }

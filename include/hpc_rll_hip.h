@@ -271,8 +271,8 @@ int hpc_rll_lstm_backward(const float* dy, const float* dhn, const float* dcn, c
  * status without touching the device. */
 int hpc_rll_async_error(void);
 int hpc_rll_clear_async_error(void);
-/* Test hooks, not operators.  occupy_device: hold `blocks` compute units (0 = all; one 1024-thread workgroup with 96 KB
- * of LDS each) for ~ms milliseconds on `stream`.  set_persist_spin_limit: polls a persistent LSTM kernel of the current
+/* Test hooks, not operators.  occupy_device: launch `blocks` workgroups of 1024 threads and 80 KB of LDS (two of them
+ * fill a CU completely; 0 = 2 per CU = the whole device) that spin for ~ms milliseconds on `stream`.  set_persist_spin_limit: polls a persistent LSTM kernel of the current
  * device waits before it gives up (0 = the shipped value, ~seconds). */
 int hpc_rll_test_occupy_device(int ms, int blocks, void* stream);
 int hpc_rll_test_set_persist_spin_limit(int64_t polls);

@@ -315,7 +315,7 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
 @pytest.mark.parametrize("S,B,I,H,L", [(24, 3, 64, 384, 1), (16, 3, 48, 96, 3), (12, 4, 32, 512, 2)])   # per-layer / wavefront / mixed
 def test_persistent_lstm_survives_a_busy_device(S, B, I, H, L):
     """VERDICT r01 item 5.  The persistent kernels need all their workgroups resident at once.  (a) A kernel that holds
-    EVERY compute unit (96 KB of LDS per CU) for ~150 ms runs on a second stream while the B <= 4 LSTM forward+backward
+    EVERY compute unit completely (two 1024-thread workgroups with 80 KB of LDS each per CU) for ~150 ms runs on a second stream while the B <= 4 LSTM forward+backward
     is issued on the main stream: the persistent workgroups cannot co-reside with it, they wait, and the results equal
     the quiet run bit for bit -- no trap (there is none any more), no asynchronous error.  (b) Two LSTMs on two streams at
     once: persistent launches of one process are chained per device, results equal the sequential run."""
@@ -406,7 +406,7 @@ assert NW.async_error() == 0
 NW._test_set_persist_spin_limit(2048, dev)  # give up after ~ms instead of ~seconds
 side = torch.cuda.Stream()
 with torch.cuda.stream(side):
-    NW._test_occupy_device(1500, dev, 160)  # 160 of 256 CUs held for 1.5 s: only part of the 192 workgroups fits
+    NW._test_occupy_device(1500, dev, 480)  # 480 of the 512 half-CU slots held for 1.5 s: room for 128 of the 192 workgroups
 with torch.no_grad():
     bad, _ = m(x, None)                     # the resident workgroups give up waiting for the others
 torch.cuda.synchronize()                    # ... and the HIP context is still alive
@@ -431,8 +431,9 @@ print("starved-ok", err)
 
 def test_starved_persistent_kernel_reports_instead_of_trapping():
     """The failure mode itself, provoked on purpose in a SEPARATE process (acknowledging the error switches the persistent
-    paths off for the rest of a process): the wait limit is lowered to ~ms through the test hook and 160 of the 256 CUs
-    are held for 1.5 s on a second stream, so only part of the persistent grid becomes resident.  Those workgroups give
+    paths off for the rest of a process): the wait limit is lowered to ~ms through the test hook and most of the device
+    (480 of its 512 half-CU slots: waves and LDS) are held for 1.5 s on a second stream, so only part of the persistent grid
+    becomes resident.  Those workgroups give
     up: no trap, the context survives, `async_error()` turns HPC_RLL_ETIMEOUT, the next LSTM call raises RuntimeError,
     and after `clear_async_error()` the same module runs on the step kernels and reproduces the quiet result."""
     import os
