@@ -31,6 +31,11 @@ class BuildNative(build_ext):
 
 
 setup(
+    name="di-hpc-amd",
+    version="0.2.0",
+    description="MI355X (gfx950) native operator library behind the hpc_rll.rl_utils / hpc_rll.torch_utils API",
+    python_requires=">=3.9",
+    install_requires=["torch"],
     package_dir={"": "di-hpc_amd"},
     packages=["hpc_rll", "hpc_rll.rl_utils", "hpc_rll.torch_utils", "hpc_rll.torch_utils.network", "di_hpc_amd"],
     ext_modules=[Extension(m, sources=[]) for m in MODULES],
