@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
+import cabi  # noqa: E402
 import hpc_torch_utils_network as U  # noqa: E402
 dev = torch.device("cuda:0")
 

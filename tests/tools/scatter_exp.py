@@ -2,6 +2,7 @@ import sys, os
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"), "di-hpc_amd"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"), "tests"))
 import torch
+import cabi
 import hpc_torch_utils_network as U
 dev=torch.device("cuda:0")
 def t(fn,n=5):

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
+import cabi
 import hpc_torch_utils_network as U
 dev = torch.device("cuda:0")
 def t(fn, n=5):
