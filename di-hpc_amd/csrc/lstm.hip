@@ -59,6 +59,20 @@ __device__ __forceinline__ void block_allsum(float (&v)[K], float* lds) {
     __syncthreads();
 }
 
+// Gate pre-activation and activations: ONE definition shared by the forward cells and by the backward cells that
+// recompute the gates instead of loading saved ones (the same expression tree, hence the same contraction).
+__device__ __forceinline__ float gate_pre(float x, float mx, float rx, float gx, float bx, float h, float mh, float rh,
+                                          float gh, float bh, float b) {
+    return (x - mx) * rx * gx + bx + (h - mh) * rh * gh + bh + b;
+}
+__device__ __forceinline__ float gate_sigmoid(float a) { return 1.f / (1.f + expf(-a)); }
+
+// Large batches do not SAVE the four activated gates (S*B*4H floats written by the forward, read by the backward: 27 % of
+// the forward cell's bytes and 12 % of the backward cell's at the C4 shape): the backward recomputes them from what it
+// reads anyway (both pre-LayerNorm products, the row statistics, gamma) plus bias / beta, parked in the workspace by the
+// forward.  Shape-only predicate (forward and backward must agree, whatever the tuning knobs say).
+inline bool cell_recompute_gates(int B, int H) { return (long)B * H >= (1L << 19); }
+
 // ------------------------------------------------------------------------------------------------ forward cell
 // one workgroup per batch row; thread t owns hidden units j = t, t+256, ... (JPT of them) x 4 gates x 2 branches.
 template <int JPT>
@@ -172,15 +186,17 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
                 const float bv = kPrefetch ? pbs[kPrefetch ? q : 0][g] : bias[col];
                 const float bxv = kPrefetch ? pbx[kPrefetch ? q : 0][g] : beta[col];
                 const float bhv = kPrefetch ? pbh[kPrefetch ? q : 0][g] : beta[G + col];
-                a[g] = (x[q][g] - mx) * rx * gxv + bxv + (h[q][g] - mh) * rh * ghv + bhv + bv;
+                a[g] = gate_pre(x[q][g], mx, rx, gxv, bxv, h[q][g], mh, rh, ghv, bhv, bv);
             }
-            const float ig = 1.f / (1.f + expf(-a[0]));
-            const float fg = 1.f / (1.f + expf(-a[1]));
-            const float og = 1.f / (1.f + expf(-a[2]));
+            const float ig = gate_sigmoid(a[0]);
+            const float fg = gate_sigmoid(a[1]);
+            const float og = gate_sigmoid(a[2]);
             const float ug = tanhf(a[3]);
             const float c = fg * (kPrefetch ? pc[kPrefetch ? q : 0] : c_prev[(size_t)b * H + j]) + ig * ug;
-            float* gr = gates + (size_t)b * G;
-            gr[j] = ig; gr[H + j] = fg; gr[2 * H + j] = og; gr[3 * H + j] = ug;
+            if (gates) {   // null: the backward recomputes them (cell_recompute_gates)
+                float* gr = gates + (size_t)b * G;
+                gr[j] = ig; gr[H + j] = fg; gr[2 * H + j] = og; gr[3 * H + j] = ug;
+            }
             c_out[(size_t)b * H + j] = c;
             h_out[(size_t)b * H + j] = og * tanhf(c);
         }
@@ -280,24 +296,26 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd4_kernel(
                 const vfloat4 bv = *reinterpret_cast<const vfloat4*>(bias + col);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    act[g][i] = (x[qq][g][i] - mx) * rx * gxv[i] + bxv[i] + (h[qq][g][i] - mh) * rh * ghv[i] + bhv[i] + bv[i];
+                    act[g][i] = gate_pre(x[qq][g][i], mx, rx, gxv[i], bxv[i], h[qq][g][i], mh, rh, ghv[i], bhv[i], bv[i]);
             }
             const vfloat4 cp = *reinterpret_cast<const vfloat4*>(c_prev + (size_t)b * H + u0);
             vfloat4 ig, fg, og, ug, cn, hn;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ig[i] = 1.f / (1.f + expf(-act[0][i]));
-                fg[i] = 1.f / (1.f + expf(-act[1][i]));
-                og[i] = 1.f / (1.f + expf(-act[2][i]));
+                ig[i] = gate_sigmoid(act[0][i]);
+                fg[i] = gate_sigmoid(act[1][i]);
+                og[i] = gate_sigmoid(act[2][i]);
                 ug[i] = tanhf(act[3][i]);
                 cn[i] = fg[i] * cp[i] + ig[i] * ug[i];
                 hn[i] = og[i] * tanhf(cn[i]);
             }
-            float* gr = gates + (size_t)b * G + u0;
-            *reinterpret_cast<vfloat4*>(gr) = ig;
-            *reinterpret_cast<vfloat4*>(gr + H) = fg;
-            *reinterpret_cast<vfloat4*>(gr + 2 * H) = og;
-            *reinterpret_cast<vfloat4*>(gr + 3 * H) = ug;
+            if (gates) {   // null: the backward recomputes them (cell_recompute_gates)
+                float* gr = gates + (size_t)b * G + u0;
+                *reinterpret_cast<vfloat4*>(gr) = ig;
+                *reinterpret_cast<vfloat4*>(gr + H) = fg;
+                *reinterpret_cast<vfloat4*>(gr + 2 * H) = og;
+                *reinterpret_cast<vfloat4*>(gr + 3 * H) = ug;
+            }
             *reinterpret_cast<vfloat4*>(c_out + (size_t)b * H + u0) = cn;
             *reinterpret_cast<vfloat4*>(h_out + (size_t)b * H + u0) = hn;
         }
@@ -312,7 +330,8 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
     int nsplit, long part_stride, const float* dc_in /* may alias dc_prev */,
     const float* __restrict__ gates, const float* __restrict__ c_new, const float* __restrict__ c_prev,
     const float* __restrict__ xw, const float* __restrict__ hw, const float* __restrict__ stats,
-    const float* __restrict__ gamma, float* __restrict__ dgate, float* __restrict__ dxw, float* __restrict__ dhw,
+    const float* __restrict__ gamma, const float* __restrict__ beta /* with bias: read only when gates == null */,
+    const float* __restrict__ bias, float* __restrict__ dgate, float* __restrict__ dxw, float* __restrict__ dhw,
     float* dc_prev, int H) {
     __shared__ float red[16];
     const int b = blockIdx.x;
@@ -349,8 +368,25 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
         const int j = threadIdx.x + q * 256;
         if (j < H) {
             const size_t o = (size_t)b * H + j;
-            const float* gr = gates + (size_t)b * G;
-            const float ig = gr[j], fg = gr[H + j], og = gr[2 * H + j], ug = gr[3 * H + j];
+            float xv[4], hv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                xv[g] = xw[(size_t)b * G + g * H + j];
+                hv[g] = hw[(size_t)b * G + g * H + j];
+            }
+            float ig, fg, og, ug;
+            if (gates) {
+                const float* gr = gates + (size_t)b * G;
+                ig = gr[j]; fg = gr[H + j]; og = gr[2 * H + j]; ug = gr[3 * H + j];
+            } else {   // recompute (cell_recompute_gates): the forward's own expression
+                float a[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = g * H + j;
+                    a[g] = gate_pre(xv[g], mx, rx, gamma[col], beta[col], hv[g], mh, rh, gamma[G + col], beta[G + col], bias[col]);
+                }
+                ig = gate_sigmoid(a[0]); fg = gate_sigmoid(a[1]); og = gate_sigmoid(a[2]); ug = tanhf(a[3]);
+            }
             const float dh = dh_tot[q];
             const float tc = tanhf(c_new[o]);
             const float dc = (dc_in ? dc_in[o] : 0.f) + dh * og * (1.f - tc * tc);
@@ -362,8 +398,8 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = g * H + j;
-                xh[q][g] = (xw[(size_t)b * G + col] - mx) * rx;
-                hh[q][g] = (hw[(size_t)b * G + col] - mh) * rh;
+                xh[q][g] = (xv[g] - mx) * rx;
+                hh[q][g] = (hv[g] - mh) * rh;
                 const float dyx = da[q][g] * gamma[col], dyh = da[q][g] * gamma[G + col];
                 r[0] += dyx; r[1] += dyx * xh[q][g];
                 r[2] += dyh; r[3] += dyh * hh[q][g];
@@ -384,6 +420,125 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
                 dxw[(size_t)b * G + col] = rx * (dyx - r[0] * inv_g - xh[q][g] * r[1] * inv_g);
                 dhw[(size_t)b * G + col] = rh * (dyh - r[2] * inv_g - hh[q][g] * r[3] * inv_g);
             }
+        }
+    }
+}
+
+// The same backward cell with 16-byte memory operations (H % 4 == 0, 16-byte aligned rows; the unit-quad mapping of
+// lstm_cell_fwd4_kernel): every load / store of a wave is one contiguous 1 KiB span.  Same arithmetic per element and
+// the same slice order for dh; the four row sums are accumulated per thread over its quads in a different order than
+// the 4-byte kernel's (fp32 rounding only).
+template <int NQ>
+__global__ __launch_bounds__(256) void lstm_cell_bwd4_kernel(
+    const float* __restrict__ dh_a, const float* __restrict__ dh_b /* nsplit partials, stride part_stride */,
+    int nsplit, long part_stride, const float* dc_in /* may alias dc_prev */,
+    const float* __restrict__ gates, const float* __restrict__ c_new, const float* __restrict__ c_prev,
+    const float* __restrict__ xw, const float* __restrict__ hw, const float* __restrict__ stats,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias,
+    float* __restrict__ dgate, float* __restrict__ dxw, float* __restrict__ dhw, float* dc_prev, int H) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    const int G = 4 * H;
+    const float* st = stats + (size_t)b * 4;
+    const float mx = st[0], rx = st[1], mh = st[2], rh = st[3];
+    const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    vfloat4 da[NQ][4], xh[NQ][4], hh[NQ][4];
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+        const int u0 = ((int)threadIdx.x + qq * 256) * 4;
+        if (u0 >= H) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { da[qq][g] = zero4; xh[qq][g] = zero4; hh[qq][g] = zero4; }
+            continue;
+        }
+        const size_t o = (size_t)b * H + u0;
+        const size_t og0 = (size_t)b * G + u0;
+        // everything this quad needs is requested before the first use
+        vfloat4 xv[4], hv[4], gv[4], gxv[4], ghv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            xv[g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(xw + og0 + g * H));
+            hv[g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(hw + og0 + g * H));
+            gxv[g] = *reinterpret_cast<const vfloat4*>(gamma + g * H + u0);
+            ghv[g] = *reinterpret_cast<const vfloat4*>(gamma + G + g * H + u0);
+            if (gates) gv[g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(gates + og0 + g * H));
+        }
+        const vfloat4 cn = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(c_new + o));
+        const vfloat4 cp = *reinterpret_cast<const vfloat4*>(c_prev + o);
+        const vfloat4 dci = dc_in ? *reinterpret_cast<const vfloat4*>(dc_in + o) : zero4;
+        vfloat4 dh = dh_a ? *reinterpret_cast<const vfloat4*>(dh_a + o) : zero4;
+        if (dh_b) {
+            for (int z = 0; z < nsplit; z += 4) {   // four slices in flight per round, summed in slice order
+                vfloat4 p[4];
+#pragma unroll
+                for (int zz = 0; zz < 4; ++zz)
+                    p[zz] = (z + zz < nsplit) ? *reinterpret_cast<const vfloat4*>(dh_b + (size_t)(z + zz) * part_stride + o) : zero4;
+#pragma unroll
+                for (int zz = 0; zz < 4; ++zz)
+                    if (z + zz < nsplit) dh += p[zz];
+            }
+        }
+        if (!gates) {   // recompute (cell_recompute_gates): the forward's own expression
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const vfloat4 bxv = *reinterpret_cast<const vfloat4*>(beta + g * H + u0);
+                const vfloat4 bhv = *reinterpret_cast<const vfloat4*>(beta + G + g * H + u0);
+                const vfloat4 bv = *reinterpret_cast<const vfloat4*>(bias + g * H + u0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float a = gate_pre(xv[g][i], mx, rx, gxv[g][i], bxv[i], hv[g][i], mh, rh, ghv[g][i], bhv[i], bv[i]);
+                    gv[g][i] = g < 3 ? gate_sigmoid(a) : tanhf(a);
+                }
+            }
+        }
+        vfloat4 dcp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ig = gv[0][i], fg = gv[1][i], og = gv[2][i], ug = gv[3][i];
+            const float tc = tanhf(cn[i]);
+            const float dc = dci[i] + dh[i] * og * (1.f - tc * tc);
+            da[qq][0][i] = dc * ug * ig * (1.f - ig);
+            da[qq][1][i] = dc * cp[i] * fg * (1.f - fg);
+            da[qq][2][i] = dh[i] * tc * og * (1.f - og);
+            da[qq][3][i] = dc * ig * (1.f - ug * ug);
+            dcp[i] = dc * fg;
+        }
+        *reinterpret_cast<vfloat4*>(dc_prev + o) = dcp;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xh[qq][g][i] = (xv[g][i] - mx) * rx;
+                hh[qq][g][i] = (hv[g][i] - mh) * rh;
+                const float dyx = da[qq][g][i] * gxv[g][i], dyh = da[qq][g][i] * ghv[g][i];
+                r[0] += dyx; r[1] += dyx * xh[qq][g][i];
+                r[2] += dyh; r[3] += dyh * hh[qq][g][i];
+            }
+            __builtin_nontemporal_store(da[qq][g], reinterpret_cast<vfloat4*>(dgate + og0 + g * H));
+        }
+    }
+    block_allsum<4>(r, red);
+    const float inv_g = 1.f / (float)G;
+    const float a0 = r[0] * inv_g, a1 = r[1] * inv_g, a2 = r[2] * inv_g, a3 = r[3] * inv_g;
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+        const int u0 = ((int)threadIdx.x + qq * 256) * 4;
+        if (u0 >= H) continue;
+        const size_t og0 = (size_t)b * G + u0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const vfloat4 gxv = *reinterpret_cast<const vfloat4*>(gamma + g * H + u0);
+            const vfloat4 ghv = *reinterpret_cast<const vfloat4*>(gamma + G + g * H + u0);
+            vfloat4 ox, oh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dyx = da[qq][g][i] * gxv[i], dyh = da[qq][g][i] * ghv[i];
+                ox[i] = rx * (dyx - a0 - xh[qq][g][i] * a1);
+                oh[i] = rh * (dyh - a2 - hh[qq][g][i] * a3);
+            }
+            __builtin_nontemporal_store(ox, reinterpret_cast<vfloat4*>(dxw + og0 + g * H));
+            *reinterpret_cast<vfloat4*>(dhw + og0 + g * H) = oh;   // read next by this step's dh product: keep it cached
         }
     }
 }
@@ -515,13 +670,32 @@ inline void launch_cell_fwd(int H, int B, hipStream_t st, const float* xw, const
                            stats);
 }
 
-template <class... Args>
-inline void launch_cell_bwd(int H, int B, hipStream_t st, Args... a) {
+inline void launch_cell_bwd(int H, int B, hipStream_t st, const float* dh_a, const float* dh_b, int nsplit,
+                            long part_stride, const float* dc_in, const float* gates, const float* c_new,
+                            const float* c_prev, const float* xw, const float* hw, const float* stats,
+                            const float* gamma, const float* beta, const float* bias, float* dgate, float* dxw,
+                            float* dhw, float* dc_prev) {
     const int jpt = (H + 255) / 256;
-    if (jpt <= 1) hipLaunchKernelGGL(lstm_cell_bwd_kernel<1>, dim3(B), dim3(256), 0, st, a..., H);
-    else if (jpt <= 2) hipLaunchKernelGGL(lstm_cell_bwd_kernel<2>, dim3(B), dim3(256), 0, st, a..., H);
-    else if (jpt <= 4) hipLaunchKernelGGL(lstm_cell_bwd_kernel<4>, dim3(B), dim3(256), 0, st, a..., H);
-    else hipLaunchKernelGGL(lstm_cell_bwd_kernel<8>, dim3(B), dim3(256), 0, st, a..., H);
+    if (g_cell_vec4 && jpt >= g_cell_vec4 && (H % 4) == 0 && H <= 2048 && (part_stride % 4) == 0 && cell_al16(dh_a) &&
+        cell_al16(dh_b) && cell_al16(dc_in) && cell_al16(gates) && cell_al16(c_new) && cell_al16(c_prev) && cell_al16(xw) &&
+        cell_al16(hw) && cell_al16(gamma) && cell_al16(beta) && cell_al16(bias) && cell_al16(dgate) && cell_al16(dxw) &&
+        cell_al16(dhw) && cell_al16(dc_prev)) {
+        if (H <= 1024)
+            hipLaunchKernelGGL(lstm_cell_bwd4_kernel<1>, dim3(B), dim3(256), 0, st, dh_a, dh_b, nsplit, part_stride, dc_in,
+                               gates, c_new, c_prev, xw, hw, stats, gamma, beta, bias, dgate, dxw, dhw, dc_prev, H);
+        else
+            hipLaunchKernelGGL(lstm_cell_bwd4_kernel<2>, dim3(B), dim3(256), 0, st, dh_a, dh_b, nsplit, part_stride, dc_in,
+                               gates, c_new, c_prev, xw, hw, stats, gamma, beta, bias, dgate, dxw, dhw, dc_prev, H);
+        return;
+    }
+#define HPC_RLL_CELL_BWD(J)                                                                                             \
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel<J>, dim3(B), dim3(256), 0, st, dh_a, dh_b, nsplit, part_stride, dc_in, gates, \
+                       c_new, c_prev, xw, hw, stats, gamma, beta, bias, dgate, dxw, dhw, dc_prev, H)
+    if (jpt <= 1) HPC_RLL_CELL_BWD(1);
+    else if (jpt <= 2) HPC_RLL_CELL_BWD(2);
+    else if (jpt <= 4) HPC_RLL_CELL_BWD(4);
+    else HPC_RLL_CELL_BWD(8);
+#undef HPC_RLL_CELL_BWD
 }
 
 }  // namespace
@@ -535,6 +709,7 @@ namespace {
 struct LayerWs { float *xw, *hw, *gates, *c, *hseq, *stats, *xin_next; };
 struct Ws {
     LayerWs layer[16];
+    float *pstash;   // bias (L,4H) then ln_beta (L,2,4H), parked by the forward for a gate-recomputing backward
     float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg, *wpart, *dwave, *whT, *wxT;
     size_t total;
 };
@@ -546,12 +721,13 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     for (int l = 0; l < L; ++l) {
         w.layer[l].xw = take(SB * G);
         w.layer[l].hw = take(SB * G);
-        w.layer[l].gates = take(SB * G);
+        w.layer[l].gates = cell_recompute_gates(B, H) ? nullptr : take(SB * G);   // not saved at large batch
         w.layer[l].c = take(SB * H);
         w.layer[l].hseq = take(SB * H);
         w.layer[l].stats = take(SB * 4);
         w.layer[l].xin_next = (dropout && l < L - 1) ? take(SB * H) : w.layer[l].hseq;
     }
+    w.pstash = take(cell_recompute_gates(B, H) ? (size_t)L * 3 * G : 0);
     w.dgate = take(SB * G);
     w.dxw = take(SB * G);
     w.dhw = take(SB * G);
@@ -623,6 +799,11 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
     hipStream_t st = (hipStream_t)stream;
     const size_t SB = (size_t)S * B, G = 4 * (size_t)H, BH = (size_t)B * H;
     const Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
+    if (S > 0 && cell_recompute_gates(B, H)) {   // the backward recomputes the gates: it needs bias and beta (not in its list)
+        int rc = copy_async(w.pstash, bias, (size_t)L * G, st);
+        if (!rc) rc = copy_async(w.pstash + (size_t)L * G, ln_beta, (size_t)L * 2 * G, st);
+        if (rc) return rc;
+    }
     size_t wx_off = 0;
     WaveCfg wc{};
     if (S > 0 && wave_fwd_ok(S, B, H, L, &wc, st)) {   // all layers in one launch, as a wavefront (lstm_wave.hpp)
@@ -703,8 +884,8 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
                             (const float*)(sk > 1 ? w.hw_part : hw_s), sk, (long)((size_t)B * G), hw_s,
                             bias + (size_t)l * G,
                             ln_gamma + (size_t)l * 2 * G, ln_beta + (size_t)l * 2 * G, c_prev,
-                            lw.gates + (size_t)s * B * G, lw.c + (size_t)s * BH, lw.hseq + (size_t)s * BH,
-                            lw.stats + (size_t)s * B * 4);
+                            lw.gates ? lw.gates + (size_t)s * B * G : (float*)nullptr, lw.c + (size_t)s * BH,
+                            lw.hseq + (size_t)s * BH, lw.stats + (size_t)s * B * 4);
         }
         int rc = last_error();
         if (rc) return rc;
@@ -863,11 +1044,13 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
             launch_cell_bwd(H, B, st, d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dh_parts,
                             (long)BH, dc_carry,
-                            (const float*)(lw.gates + (size_t)s * B * G), (const float*)(lw.c + (size_t)s * BH),
+                            lw.gates ? (const float*)(lw.gates + (size_t)s * B * G) : (const float*)nullptr,
+                            (const float*)(lw.c + (size_t)s * BH),
                             c_prev, (const float*)(lw.xw + (size_t)s * B * G),
                             (const float*)(lw.hw + (size_t)s * B * G), (const float*)(lw.stats + (size_t)s * B * 4),
-                            gamma_l, w.dgate + (size_t)s * B * G, w.dxw + (size_t)s * B * G,
-                            w.dhw + (size_t)s * B * G, w.dc);
+                            gamma_l, (const float*)(w.pstash + (size_t)L * G + (size_t)l * 2 * G),
+                            (const float*)(w.pstash + (size_t)l * G), w.dgate + (size_t)s * B * G,
+                            w.dxw + (size_t)s * B * G, w.dhw + (size_t)s * B * G, w.dc);
             // dh_prev (B,H) = dHW_s (B,G) @ Wh^T, as an NN product against the transposed copy
             GemmArgs g{w.dhw + (size_t)s * B * G, nn_dh ? (const float*)w.whT : wh_l, w.dh, B, H, (int)G, (long)G, 1,
                        nn_dh ? (long)H : 1, nn_dh ? 1 : (long)G, (long)H, 0, sk_dh, (long)BH, (nn_dh && g_lstm_dh_big) ? 1 : 0};

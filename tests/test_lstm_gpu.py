@@ -95,7 +95,10 @@ def test_lstm_golden(golden):
             assert rel_err(g[f"c{i}_grad_wh{l}"], gwh[l]) < tol
 
 
-@pytest.mark.parametrize("S,B,I,H,L", [(64, 3, 1792, 384, 3), (6, 200, 64, 128, 2), (3, 40, 20, 600, 1), (2, 5, 9, 1100, 1), (1, 1, 1, 1, 1)])
+@pytest.mark.parametrize("S,B,I,H,L", [(64, 3, 1792, 384, 3), (6, 200, 64, 128, 2), (3, 40, 20, 600, 1), (2, 5, 9, 1100, 1), (1, 1, 1, 1, 1),
+                                       # B*H >= 2^19: the gates are not saved, the backward recomputes them --
+                                       # 4-byte cells / 16-byte cells, two layers / 16-byte cells with two quads per thread
+                                       (3, 2048, 32, 256, 1), (2, 512, 48, 1024, 2), (2, 520, 16, 1028, 1)])
 def test_lstm_oracle(S, B, I, H, L):
     rng = np.random.default_rng(S + H)
     gain = 1.0 / np.sqrt(H)
