@@ -35,6 +35,7 @@ int g_lstm_dh_big = 1;   // experiments (tune key 12)
 int g_lstm_nn_bwd = 1;   // backward products against transposed weight copies (hpc_rll_tune_set key 11)
 int g_gemm_big_tile128 = 1;
 int g_gemm_big_target = 768;   // workgroups the split-K of the weight-gradient GEMMs aims for
+int g_cell_rows_wgs = 512;     // workgroups of the row-walking backward cell (tune key 20; 0 = one row per workgroup + colreduce)
 namespace {
 
 constexpr float kLnEps = 1e-5f;
@@ -427,68 +428,99 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
 // The same backward cell with 16-byte memory operations (H % 4 == 0, 16-byte aligned rows; the unit-quad mapping of
 // lstm_cell_fwd4_kernel): every load / store of a wave is one contiguous 1 KiB span.  Same arithmetic per element and
 // the same slice order for dh; the four row sums are accumulated per thread over its quads in a different order than
-// the 4-byte kernel's (fp32 rounding only).
-template <int NQ>
-__global__ __launch_bounds__(256) void lstm_cell_bwd4_kernel(
-    const float* __restrict__ dh_a, const float* __restrict__ dh_b /* nsplit partials, stride part_stride */,
-    int nsplit, long part_stride, const float* dc_in /* may alias dc_prev */,
-    const float* __restrict__ gates, const float* __restrict__ c_new, const float* __restrict__ c_prev,
-    const float* __restrict__ xw, const float* __restrict__ hw, const float* __restrict__ stats,
-    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias,
-    float* __restrict__ dgate, float* __restrict__ dxw, float* __restrict__ dhw, float* dc_prev, int H) {
-    __shared__ float red[16];
-    const int b = blockIdx.x;
-    const int G = 4 * H;
-    const float* st = stats + (size_t)b * 4;
-    const float mx = st[0], rx = st[1], mh = st[2], rh = st[3];
+// the 4-byte kernel's (fp32 rounding only).  Split into a LOAD half (issues every per-row memory read of a thread's
+// quads, no use) and a COMPUTE half, so that a workgroup that walks several rows can request row b+1 before it
+// computes row b.
+struct CellBwdArgs {
+    const float *dh_a, *dh_b;   // dh = dh_a + sum of nsplit partials of dh_b (stride part_stride), either may be null
+    int nsplit;
+    long part_stride;
+    const float* dc_in;         // may alias dc_prev
+    const float *gates /* null: recompute */, *c_new, *c_prev, *xw, *hw, *stats, *gamma, *beta, *bias;
+    float *dgate, *dxw, *dhw, *dc_prev;
+    int H;
+};
+template <int NQ, bool SAVED /* gates are loaded, not recomputed */> struct CellBwdRow {
+    vfloat4 xv[NQ][4], hv[NQ][4], gv[SAVED ? NQ : 1][SAVED ? 4 : 1], cn[NQ], cp[NQ], dci[NQ], dh[NQ];
+    float mx, rx, mh, rh;
+};
+template <int NQ, bool SAVED>
+__device__ __forceinline__ void cell_bwd4_load(const CellBwdArgs& a, int b, CellBwdRow<NQ, SAVED>& r) {
+    const int H = a.H, G = 4 * H;
     const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    vfloat4 da[NQ][4], xh[NQ][4], hh[NQ][4];
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* st = a.stats + (size_t)b * 4;
+    r.mx = st[0]; r.rx = st[1]; r.mh = st[2]; r.rh = st[3];
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+        const int u0 = ((int)threadIdx.x + qq * 256) * 4;
+        const int uu = u0 < H ? u0 : 0;   // idle quads re-read quad 0 (no divergent branch around a load), results unused
+        const size_t o = (size_t)b * H + uu;
+        const size_t og0 = (size_t)b * G + uu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            r.xv[qq][g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.xw + og0 + g * H));
+            r.hv[qq][g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.hw + og0 + g * H));
+            if (SAVED) r.gv[SAVED ? qq : 0][SAVED ? g : 0] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.gates + og0 + g * H));
+        }
+        r.cn[qq] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.c_new + o));
+        r.cp[qq] = *reinterpret_cast<const vfloat4*>(a.c_prev + o);
+        r.dci[qq] = a.dc_in ? *reinterpret_cast<const vfloat4*>(a.dc_in + o) : zero4;
+        r.dh[qq] = a.dh_a ? *reinterpret_cast<const vfloat4*>(a.dh_a + o) : zero4;
+    }
+}
+// ACC: instead of storing the gate adjoint `da` for a later column-reduction pass over (S*B, 4H), the workgroup adds
+// da, da*xhat_x, da*xhat_h of its row to per-column accumulators in LDS (`acc`, 3 x 4H floats, every column owned by
+// exactly one thread: no synchronisation) -- see lstm_cell_bwd4_rows_kernel.
+template <int NQ, bool SAVED, bool ACC>
+__device__ __forceinline__ void cell_bwd4_compute(const CellBwdArgs& a, int b, const CellBwdRow<NQ, SAVED>& r, float* red,
+                                                  float* acc) {
+    const int H = a.H, G = 4 * H;
+    const float mx = r.mx, rx = r.rx, mh = r.mh, rh = r.rh;
+    const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    vfloat4 da[NQ][4];   // (the normalised operands xhat are recomputed from the row's x / h where needed: registers)
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qq = 0; qq < NQ; ++qq) {
         const int u0 = ((int)threadIdx.x + qq * 256) * 4;
         if (u0 >= H) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { da[qq][g] = zero4; xh[qq][g] = zero4; hh[qq][g] = zero4; }
+            for (int g = 0; g < 4; ++g) da[qq][g] = zero4;
             continue;
         }
         const size_t o = (size_t)b * H + u0;
         const size_t og0 = (size_t)b * G + u0;
-        // everything this quad needs is requested before the first use
-        vfloat4 xv[4], hv[4], gv[4], gxv[4], ghv[4];
+        vfloat4 gxv[4], ghv[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            xv[g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(xw + og0 + g * H));
-            hv[g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(hw + og0 + g * H));
-            gxv[g] = *reinterpret_cast<const vfloat4*>(gamma + g * H + u0);
-            ghv[g] = *reinterpret_cast<const vfloat4*>(gamma + G + g * H + u0);
-            if (gates) gv[g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(gates + og0 + g * H));
+            gxv[g] = *reinterpret_cast<const vfloat4*>(a.gamma + g * H + u0);
+            ghv[g] = *reinterpret_cast<const vfloat4*>(a.gamma + G + g * H + u0);
         }
-        const vfloat4 cn = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(c_new + o));
-        const vfloat4 cp = *reinterpret_cast<const vfloat4*>(c_prev + o);
-        const vfloat4 dci = dc_in ? *reinterpret_cast<const vfloat4*>(dc_in + o) : zero4;
-        vfloat4 dh = dh_a ? *reinterpret_cast<const vfloat4*>(dh_a + o) : zero4;
-        if (dh_b) {
-            for (int z = 0; z < nsplit; z += 4) {   // four slices in flight per round, summed in slice order
-                vfloat4 p[4];
+        vfloat4 dh = r.dh[qq];
+        // split-K partials of dh (written by the product just before this launch: cache hits), four in flight, slice order
+        for (int z = 0; a.dh_b && z < a.nsplit; z += 4) {
+            vfloat4 p[4];
 #pragma unroll
-                for (int zz = 0; zz < 4; ++zz)
-                    p[zz] = (z + zz < nsplit) ? *reinterpret_cast<const vfloat4*>(dh_b + (size_t)(z + zz) * part_stride + o) : zero4;
+            for (int zz = 0; zz < 4; ++zz)
+                p[zz] = (z + zz < a.nsplit) ? *reinterpret_cast<const vfloat4*>(a.dh_b + (size_t)(z + zz) * a.part_stride + o) : zero4;
 #pragma unroll
-                for (int zz = 0; zz < 4; ++zz)
-                    if (z + zz < nsplit) dh += p[zz];
-            }
+            for (int zz = 0; zz < 4; ++zz)
+                if (z + zz < a.nsplit) dh += p[zz];
         }
-        if (!gates) {   // recompute (cell_recompute_gates): the forward's own expression
+        vfloat4 gv[4];
+        if (SAVED) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gv[g] = r.gv[SAVED ? qq : 0][SAVED ? g : 0];
+        } else {   // recompute (cell_recompute_gates): the forward's own expression
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const vfloat4 bxv = *reinterpret_cast<const vfloat4*>(beta + g * H + u0);
-                const vfloat4 bhv = *reinterpret_cast<const vfloat4*>(beta + G + g * H + u0);
-                const vfloat4 bv = *reinterpret_cast<const vfloat4*>(bias + g * H + u0);
+                const vfloat4 bxv = *reinterpret_cast<const vfloat4*>(a.beta + g * H + u0);
+                const vfloat4 bhv = *reinterpret_cast<const vfloat4*>(a.beta + G + g * H + u0);
+                const vfloat4 bv = *reinterpret_cast<const vfloat4*>(a.bias + g * H + u0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float a = gate_pre(xv[g][i], mx, rx, gxv[g][i], bxv[i], hv[g][i], mh, rh, ghv[g][i], bhv[i], bv[i]);
-                    gv[g][i] = g < 3 ? gate_sigmoid(a) : tanhf(a);
+                    const float pre = gate_pre(r.xv[qq][g][i], mx, rx, gxv[g][i], bxv[i], r.hv[qq][g][i], mh, rh, ghv[g][i],
+                                               bhv[i], bv[i]);
+                    gv[g][i] = g < 3 ? gate_sigmoid(pre) : tanhf(pre);
                 }
             }
         }
@@ -496,31 +528,41 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd4_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float ig = gv[0][i], fg = gv[1][i], og = gv[2][i], ug = gv[3][i];
-            const float tc = tanhf(cn[i]);
-            const float dc = dci[i] + dh[i] * og * (1.f - tc * tc);
+            const float tc = tanhf(r.cn[qq][i]);
+            const float dc = r.dci[qq][i] + dh[i] * og * (1.f - tc * tc);
             da[qq][0][i] = dc * ug * ig * (1.f - ig);
-            da[qq][1][i] = dc * cp[i] * fg * (1.f - fg);
+            da[qq][1][i] = dc * r.cp[qq][i] * fg * (1.f - fg);
             da[qq][2][i] = dh[i] * tc * og * (1.f - og);
             da[qq][3][i] = dc * ig * (1.f - ug * ug);
             dcp[i] = dc * fg;
         }
-        *reinterpret_cast<vfloat4*>(dc_prev + o) = dcp;
+        *reinterpret_cast<vfloat4*>(a.dc_prev + o) = dcp;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            vfloat4 xh, hh;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                xh[qq][g][i] = (xv[g][i] - mx) * rx;
-                hh[qq][g][i] = (hv[g][i] - mh) * rh;
+                xh[i] = (r.xv[qq][g][i] - mx) * rx;
+                hh[i] = (r.hv[qq][g][i] - mh) * rh;
                 const float dyx = da[qq][g][i] * gxv[g][i], dyh = da[qq][g][i] * ghv[g][i];
-                r[0] += dyx; r[1] += dyx * xh[qq][g][i];
-                r[2] += dyh; r[3] += dyh * hh[qq][g][i];
+                s[0] += dyx; s[1] += dyx * xh[i];
+                s[2] += dyh; s[3] += dyh * hh[i];
             }
-            __builtin_nontemporal_store(da[qq][g], reinterpret_cast<vfloat4*>(dgate + og0 + g * H));
+            if (ACC) {
+                vfloat4* a0 = reinterpret_cast<vfloat4*>(acc + g * H + u0);
+                vfloat4* a1 = reinterpret_cast<vfloat4*>(acc + G + g * H + u0);
+                vfloat4* a2 = reinterpret_cast<vfloat4*>(acc + 2 * G + g * H + u0);
+                *a0 += da[qq][g];
+                *a1 += da[qq][g] * xh;
+                *a2 += da[qq][g] * hh;
+            } else {
+                __builtin_nontemporal_store(da[qq][g], reinterpret_cast<vfloat4*>(a.dgate + og0 + g * H));
+            }
         }
     }
-    block_allsum<4>(r, red);
+    block_allsum<4>(s, red);
     const float inv_g = 1.f / (float)G;
-    const float a0 = r[0] * inv_g, a1 = r[1] * inv_g, a2 = r[2] * inv_g, a3 = r[3] * inv_g;
+    const float a0 = s[0] * inv_g, a1 = s[1] * inv_g, a2 = s[2] * inv_g, a3 = s[3] * inv_g;
 #pragma unroll
     for (int qq = 0; qq < NQ; ++qq) {
         const int u0 = ((int)threadIdx.x + qq * 256) * 4;
@@ -528,19 +570,60 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd4_kernel(
         const size_t og0 = (size_t)b * G + u0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const vfloat4 gxv = *reinterpret_cast<const vfloat4*>(gamma + g * H + u0);
-            const vfloat4 ghv = *reinterpret_cast<const vfloat4*>(gamma + G + g * H + u0);
+            const vfloat4 gxv = *reinterpret_cast<const vfloat4*>(a.gamma + g * H + u0);
+            const vfloat4 ghv = *reinterpret_cast<const vfloat4*>(a.gamma + G + g * H + u0);
             vfloat4 ox, oh;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float dyx = da[qq][g][i] * gxv[i], dyh = da[qq][g][i] * ghv[i];
-                ox[i] = rx * (dyx - a0 - xh[qq][g][i] * a1);
-                oh[i] = rh * (dyh - a2 - hh[qq][g][i] * a3);
+                ox[i] = rx * (dyx - a0 - (r.xv[qq][g][i] - mx) * rx * a1);
+                oh[i] = rh * (dyh - a2 - (r.hv[qq][g][i] - mh) * rh * a3);
             }
-            __builtin_nontemporal_store(ox, reinterpret_cast<vfloat4*>(dxw + og0 + g * H));
-            *reinterpret_cast<vfloat4*>(dhw + og0 + g * H) = oh;   // read next by this step's dh product: keep it cached
+            __builtin_nontemporal_store(ox, reinterpret_cast<vfloat4*>(a.dxw + og0 + g * H));
+            *reinterpret_cast<vfloat4*>(a.dhw + og0 + g * H) = oh;   // read next by this step's dh product: keep it cached
         }
     }
+}
+
+template <int NQ, bool SAVED>
+__global__ __launch_bounds__(256) void lstm_cell_bwd4_kernel(const CellBwdArgs a) {
+    __shared__ float red[16];
+    CellBwdRow<NQ, SAVED> r;
+    cell_bwd4_load<NQ, SAVED>(a, blockIdx.x, r);
+    cell_bwd4_compute<NQ, SAVED, false>(a, blockIdx.x, r, red, nullptr);
+}
+
+// Workgroup w walks the batch rows [w*B/nwg, (w+1)*B/nwg) one after the other and keeps the three per-column sums the
+// parameter gradients need (sum da -> dbias, dbeta ; sum da*xhat_x -> dgamma_x ; sum da*xhat_h -> dgamma_h) in LDS,
+// carried from step to step through `colacc` (nwg, 3, 4H) -- read at the start of the launch (`acc_init` = 0), written
+// at its end; lstm_colfinal_kernel adds the nwg rows once per layer.  Against storing `da` per step and reducing
+// (S*B, 4H) x 3 operands afterwards this removes S*B*4H floats of stores per step and a 3 x S*B*4H pass per layer
+// (C4: 64 MB per step and 26 GB = 4.05 ms per layer).  Fixed summation order (rows ascending inside a workgroup, steps
+// descending, workgroups ascending): deterministic, no atomics.  Measured at C4 (tests/tools/r02_lstm_cellrows_probe.py,
+// backward, ms): one row per workgroup + reduction pass 144.3; 512 workgroups x 8 rows 140.9; 768 (5-6 rows: uneven)
+// 144.6; 1024 x 4 rows (1.33 rounds of the chip) 142.6; requesting row b+1 before computing row b needs > 256 registers
+// and spills (147.3).  At B = 1024..2048 the row walk loses 2-3 % (too few rows per workgroup to pay for the
+// accumulator round trip), so it starts at 8 rows per workgroup; B = 8192: H = 1024 36.2 -> 35.5 ms (S = 16), H = 512
+// 43.1 -> 43.5 (S = 32, L = 2), so it starts at H = 768.
+__global__ __launch_bounds__(256) void lstm_cell_bwd4_rows_kernel(const CellBwdArgs a, float* __restrict__ colacc,
+                                                                  int acc_init, int B) {
+    __shared__ float red[16];
+    extern __shared__ __attribute__((aligned(16))) float acc[];   // [3][4H]
+    const int G = 4 * a.H;
+    float* mine = colacc + (size_t)blockIdx.x * 3 * G;
+    const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int r0 = (int)((long)blockIdx.x * B / gridDim.x), r1 = (int)((long)(blockIdx.x + 1) * B / gridDim.x);
+    for (int i = threadIdx.x * 4; i < 3 * G; i += 1024)
+        *reinterpret_cast<vfloat4*>(acc + i) = acc_init ? zero4 : *reinterpret_cast<const vfloat4*>(mine + i);
+    __syncthreads();   // (the owner of a column in the row function is another thread than here unless H % 256 == 0)
+    for (int b = r0; b < r1; ++b) {
+        CellBwdRow<1, false> r;   // (this path always recomputes the gates: cell_rows_shape)
+        cell_bwd4_load<1, false>(a, b, r);
+        cell_bwd4_compute<1, false, true>(a, b, r, red, acc);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x * 4; i < 3 * G; i += 1024)
+        *reinterpret_cast<vfloat4*>(mine + i) = *reinterpret_cast<const vfloat4*>(acc + i);
 }
 
 // ------------------------------------------------------------------------------------------------ column reductions
@@ -670,32 +753,38 @@ inline void launch_cell_fwd(int H, int B, hipStream_t st, const float* xw, const
                            stats);
 }
 
-inline void launch_cell_bwd(int H, int B, hipStream_t st, const float* dh_a, const float* dh_b, int nsplit,
-                            long part_stride, const float* dc_in, const float* gates, const float* c_new,
-                            const float* c_prev, const float* xw, const float* hw, const float* stats,
-                            const float* gamma, const float* beta, const float* bias, float* dgate, float* dxw,
-                            float* dhw, float* dc_prev) {
+inline void launch_cell_bwd(int B, hipStream_t st, const CellBwdArgs& a) {
+    const int H = a.H;
     const int jpt = (H + 255) / 256;
-    if (g_cell_vec4 && jpt >= g_cell_vec4 && (H % 4) == 0 && H <= 2048 && (part_stride % 4) == 0 && cell_al16(dh_a) &&
-        cell_al16(dh_b) && cell_al16(dc_in) && cell_al16(gates) && cell_al16(c_new) && cell_al16(c_prev) && cell_al16(xw) &&
-        cell_al16(hw) && cell_al16(gamma) && cell_al16(beta) && cell_al16(bias) && cell_al16(dgate) && cell_al16(dxw) &&
-        cell_al16(dhw) && cell_al16(dc_prev)) {
-        if (H <= 1024)
-            hipLaunchKernelGGL(lstm_cell_bwd4_kernel<1>, dim3(B), dim3(256), 0, st, dh_a, dh_b, nsplit, part_stride, dc_in,
-                               gates, c_new, c_prev, xw, hw, stats, gamma, beta, bias, dgate, dxw, dhw, dc_prev, H);
-        else
-            hipLaunchKernelGGL(lstm_cell_bwd4_kernel<2>, dim3(B), dim3(256), 0, st, dh_a, dh_b, nsplit, part_stride, dc_in,
-                               gates, c_new, c_prev, xw, hw, stats, gamma, beta, bias, dgate, dxw, dhw, dc_prev, H);
+    if (g_cell_vec4 && jpt >= g_cell_vec4 && (H % 4) == 0 && H <= 2048 && (a.part_stride % 4) == 0 && cell_al16(a.dh_a) &&
+        cell_al16(a.dh_b) && cell_al16(a.dc_in) && cell_al16(a.gates) && cell_al16(a.c_new) && cell_al16(a.c_prev) &&
+        cell_al16(a.xw) && cell_al16(a.hw) && cell_al16(a.gamma) && cell_al16(a.beta) && cell_al16(a.bias) &&
+        cell_al16(a.dgate) && cell_al16(a.dxw) && cell_al16(a.dhw) && cell_al16(a.dc_prev)) {
+        if (H <= 1024 && a.gates) hipLaunchKernelGGL((lstm_cell_bwd4_kernel<1, true>), dim3(B), dim3(256), 0, st, a);
+        else if (H <= 1024) hipLaunchKernelGGL((lstm_cell_bwd4_kernel<1, false>), dim3(B), dim3(256), 0, st, a);
+        else if (a.gates) hipLaunchKernelGGL((lstm_cell_bwd4_kernel<2, true>), dim3(B), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lstm_cell_bwd4_kernel<2, false>), dim3(B), dim3(256), 0, st, a);
         return;
     }
-#define HPC_RLL_CELL_BWD(J)                                                                                             \
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel<J>, dim3(B), dim3(256), 0, st, dh_a, dh_b, nsplit, part_stride, dc_in, gates, \
-                       c_new, c_prev, xw, hw, stats, gamma, beta, bias, dgate, dxw, dhw, dc_prev, H)
+#define HPC_RLL_CELL_BWD(J)                                                                                               \
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel<J>, dim3(B), dim3(256), 0, st, a.dh_a, a.dh_b, a.nsplit, a.part_stride, a.dc_in, \
+                       a.gates, a.c_new, a.c_prev, a.xw, a.hw, a.stats, a.gamma, a.beta, a.bias, a.dgate, a.dxw, a.dhw,      \
+                       a.dc_prev, H)
     if (jpt <= 1) HPC_RLL_CELL_BWD(1);
     else if (jpt <= 2) HPC_RLL_CELL_BWD(2);
     else if (jpt <= 4) HPC_RLL_CELL_BWD(4);
     else HPC_RLL_CELL_BWD(8);
 #undef HPC_RLL_CELL_BWD
+}
+
+// Large-batch backward cells with the parameter-gradient column sums folded in (lstm_cell_bwd4_rows_kernel).
+constexpr int kCellRowsMaxWgs = 1024;
+inline bool cell_rows_shape(int B, int H) {
+    return cell_recompute_gates(B, H) && H % 4 == 0 && H >= 768 && H <= 1024 && g_cell_rows_wgs > 0 && B >= 8 * g_cell_rows_wgs;
+}
+inline void launch_cell_bwd_rows(int B, int nwg, hipStream_t st, const CellBwdArgs& a, float* colacc, int acc_init) {
+    const size_t lds = (size_t)3 * 4 * a.H * sizeof(float);
+    hipLaunchKernelGGL(lstm_cell_bwd4_rows_kernel, dim3(nwg), dim3(256), lds, st, a, colacc, acc_init, B);
 }
 
 }  // namespace
@@ -740,7 +829,7 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     const size_t widest = SB * (size_t)(I > H ? I : H);
     w.dseq_a = take(widest);
     w.dseq_b = take(widest);
-    w.colpart = take((size_t)kColChunks * 3 * G);
+    w.colpart = take((size_t)(kCellRowsMaxWgs > kColChunks ? kCellRowsMaxWgs : kColChunks) * 3 * G);
     w.whT = take((size_t)H * G);                          // Wh^T of the layer being processed (backward)
     w.wxT = take((size_t)(I > H ? I : H) * G);            // Wx^T of that layer
     {   // persistent small-batch paths: {value, tag} exchange words (per-layer kernels / layer wavefront)
@@ -939,7 +1028,8 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
     const XchgLayout xl = xchg_layout(B, H);
     if (persist && hipMemsetAsync(w.xchg, 0, xl.total_words * sizeof(u64), st) != hipSuccess) return last_error();
     // weight / parameter gradients of layer l from its gate-gradient buffers, and (if `dxin`) d(layer input)
-    auto layer_grads = [&](int l, const float* p_dgate, const float* p_dxw, const float* p_dhw, float* dxin) {
+    auto layer_grads = [&](int l, const float* p_dgate, const float* p_dxw, const float* p_dhw, float* dxin,
+                           int summed_chunks = 0 /* > 0: colpart already holds that many rows of column sums */) {
         const int in_l = l == 0 ? I : H;
         const LayerWs& lw = w.layer[l];
         const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
@@ -992,10 +1082,12 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
                                    (const float*)w.wpart, skd, (long)(SB * in_l), dxin);
         }
         {
-            const int chunks = (int)(SB < (size_t)kColChunks * 8 ? (SB + 7) / 8 : kColChunks);
-            hipLaunchKernelGGL(lstm_colreduce_kernel, dim3((unsigned)((G + 63) / 64), chunks), dim3(256), 0, st,
-                               (const float*)p_dgate, (const float*)lw.xw, (const float*)lw.hw,
-                               (const float*)lw.stats, (long)SB, (int)G, w.colpart);
+            const int chunks = summed_chunks > 0 ? summed_chunks
+                                                 : (int)(SB < (size_t)kColChunks * 8 ? (SB + 7) / 8 : kColChunks);
+            if (summed_chunks <= 0)
+                hipLaunchKernelGGL(lstm_colreduce_kernel, dim3((unsigned)((G + 63) / 64), chunks), dim3(256), 0, st,
+                                   (const float*)p_dgate, (const float*)lw.xw, (const float*)lw.hw,
+                                   (const float*)lw.stats, (long)SB, (int)G, w.colpart);
             hipLaunchKernelGGL(lstm_colfinal_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st,
                                (const float*)w.colpart, chunks, (int)G, dbias + (size_t)l * G,
                                dln_gamma + (size_t)l * 2 * G, dln_beta + (size_t)l * 2 * G);
@@ -1040,17 +1132,21 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             persist_prof_report("bwd", l, S, st);
         }
         if (!persist && nn_dh) launch_transpose(wh_l, w.whT, H, (int)G, st);   // (H, G) -> (G, H): B(k=g, n=h) = whT[g*H + h]
+        // large batches: the cell walks several rows per workgroup and keeps the bias / gamma / beta column sums (no
+        // dgate buffer, no reduction pass) -- 16-byte accesses, so every base pointer must be 16-byte aligned
+        const int rows_wgs = (!persist && cell_rows_shape(B, H) && cell_al16(d_out) &&
+                              cell_al16(dhn) && cell_al16(dcn) && cell_al16(c0) && cell_al16(ws) && cell_al16(ln_gamma))
+                                 ? (B < g_cell_rows_wgs ? B : g_cell_rows_wgs) : 0;
         for (int s = S - 1; s >= 0 && !persist; --s) {
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
-            launch_cell_bwd(H, B, st, d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dh_parts,
-                            (long)BH, dc_carry,
-                            lw.gates ? (const float*)(lw.gates + (size_t)s * B * G) : (const float*)nullptr,
-                            (const float*)(lw.c + (size_t)s * BH),
-                            c_prev, (const float*)(lw.xw + (size_t)s * B * G),
-                            (const float*)(lw.hw + (size_t)s * B * G), (const float*)(lw.stats + (size_t)s * B * 4),
-                            gamma_l, (const float*)(w.pstash + (size_t)L * G + (size_t)l * 2 * G),
-                            (const float*)(w.pstash + (size_t)l * G), w.dgate + (size_t)s * B * G,
-                            w.dxw + (size_t)s * B * G, w.dhw + (size_t)s * B * G, w.dc);
+            const CellBwdArgs ca{d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dh_parts, (long)BH, dc_carry,
+                                 lw.gates ? (const float*)(lw.gates + (size_t)s * B * G) : (const float*)nullptr,
+                                 lw.c + (size_t)s * BH, c_prev, lw.xw + (size_t)s * B * G, lw.hw + (size_t)s * B * G,
+                                 lw.stats + (size_t)s * B * 4, gamma_l, w.pstash + (size_t)L * G + (size_t)l * 2 * G,
+                                 w.pstash + (size_t)l * G, w.dgate + (size_t)s * B * G, w.dxw + (size_t)s * B * G,
+                                 w.dhw + (size_t)s * B * G, w.dc, H};
+            if (rows_wgs) launch_cell_bwd_rows(B, rows_wgs, st, ca, w.colpart, s == S - 1 ? 1 : 0);
+            else launch_cell_bwd(B, st, ca);
             // dh_prev (B,H) = dHW_s (B,G) @ Wh^T, as an NN product against the transposed copy
             GemmArgs g{w.dhw + (size_t)s * B * G, nn_dh ? (const float*)w.whT : wh_l, w.dh, B, H, (int)G, (long)G, 1,
                        nn_dh ? (long)H : 1, nn_dh ? 1 : (long)G, (long)H, 0, sk_dh, (long)BH, (nn_dh && g_lstm_dh_big) ? 1 : 0};
@@ -1067,7 +1163,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             if ((rc = copy_async(dc0 + (size_t)l * BH, w.dc, BH, st))) return rc;
         }
         float* dxin = l == 0 ? dx : seq_bufs[flip];
-        layer_grads(l, w.dgate, w.dxw, w.dhw, dxin);
+        layer_grads(l, w.dgate, w.dxw, w.dhw, dxin, rows_wgs);
         if (l > 0) {
             if (dropout_p > 0.f) {   // backward of the dropout between layer l-1 and l: same mask, same scale
                 const long n = (long)(SB * H);

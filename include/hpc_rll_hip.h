@@ -109,7 +109,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * key 17: LDS-staged streaming scatter forward kernel on (1, default) / off (0: the
  * round-1 cells-per-thread kernel).  key 18: channels per workgroup of that kernel (0 = largest of 64/32/16/8/4 whose
  * x tile fits 52 KB of LDS, or a multiple of 4 in 4..64).  key 19: waves a column-scan launch (TD-lambda, V-trace,
- * UPGO) aims for when it picks its waves per workgroup (256..16384, default 4096).
+ * UPGO) aims for when it picks its waves per workgroup (256..16384, default 4096).  key 20: workgroups of the large-batch
+ * LSTM backward cell (768 <= H <= 1024) that walks >= 8 batch rows per workgroup and keeps the bias / gamma / beta column sums (64..1024,
+ * default 512 = two per CU; 0 = always one row per workgroup + a separate column-reduction pass).
  */
 int hpc_rll_tune_set(int key, int value);
 

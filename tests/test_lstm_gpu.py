@@ -98,7 +98,10 @@ def test_lstm_golden(golden):
 @pytest.mark.parametrize("S,B,I,H,L", [(64, 3, 1792, 384, 3), (6, 200, 64, 128, 2), (3, 40, 20, 600, 1), (2, 5, 9, 1100, 1), (1, 1, 1, 1, 1),
                                        # B*H >= 2^19: the gates are not saved, the backward recomputes them --
                                        # 4-byte cells / 16-byte cells, two layers / 16-byte cells with two quads per thread
-                                       (3, 2048, 32, 256, 1), (2, 512, 48, 1024, 2), (2, 520, 16, 1028, 1)])
+                                       (3, 2048, 32, 256, 1), (2, 512, 48, 1024, 2), (2, 520, 16, 1028, 1),
+                                       # B >= 4096, 768 <= H <= 1024: backward cells walk 8 rows per workgroup and keep
+                                       # the bias / gamma / beta column sums across steps and layers
+                                       (3, 4096, 16, 768, 2)])
 def test_lstm_oracle(S, B, I, H, L):
     rng = np.random.default_rng(S + H)
     gain = 1.0 / np.sqrt(H)
