@@ -26,11 +26,15 @@ namespace hpc_rll {
 // Round 2: rows t and t+1 of a wave's chunk share value[t+1] (UPGO also reward[t+1], value[t+2]): `load` is told
 // whether row t+1 is held by the same wave and `link` copies the shared fields from it -- LC+1 value rows per chunk
 // instead of 2*LC.
-// Tried and NOT kept: folding the fixed-order sum of the workgroup partials into the last workgroup to finish (arrival
-// ticket in the call's scratch).  On this multi-XCD part an agent-scope release has to write the XCD's L2 back, and the
-// scan has just left its whole output dirty there: TD-lambda forward at T=256,B=16384 went from 17.9 us (scan +
-// finalize launch) to 319 us, V-trace 0.75 -> 1.01 ms, UPGO 0.37 -> 0.64 ms (gpurun_out/r02_suite_c3.log).  A dependent
-// kernel boundary costs ~1.7 us here (MI355X_MICROARCH.md), so the second launch stays.
+// The fixed-order sum of the workgroup partials is folded into the LAST workgroup to finish (ScanFold): one launch per
+// forward instead of scan + finalize (a dependent kernel boundary costs ~1.7 us here, MI355X_MICROARCH.md, the
+// finalize kernel itself ~3).  First attempt, NOT kept: arrival ticket behind `__threadfence()` -- on this multi-XCD
+// part an agent-scope RELEASE writes the XCD's whole L2 back, and the scan has just left its output dirty there:
+// TD-lambda forward at T=256,B=16384 went from 17.9 us to 319 us, V-trace 0.75 -> 1.01 ms.  What runs now needs no
+// release: the partial is written with a relaxed AGENT-scope atomic store (write-through to the memory side), the
+// thread waits for that one store (`s_waitcnt vmcnt(0)`), the workgroup barriers, and only then takes the ticket with a
+// relaxed agent-scope atomic; the last workgroup reads the partials with agent-scope atomic loads (which bypass its
+// XCD's L2).  Nothing else of the workgroup's output has to be visible to another workgroup.
 //
 // An Op provides:
 //   static constexpr int NACC;                         number of scalar sums
@@ -45,9 +49,13 @@ namespace hpc_rll {
 // groups own SUB DIFFERENT chunks of the time axis ("virtual waves", as gae.hip's half-wave tiles): SUB x more
 // workgroups and SUB x more steps per barrier.  At the reference's TD-lambda test shape (T=1024, B=64) the 64-column
 // tiling is ONE workgroup walking 8 barriers.
+// Where the last workgroup leaves the NACC sums (x scale[k]); out == nullptr: partials only (the caller finalises).
+// `ticket` is zero before the launch and is left at zero by it.
+struct ScanFold { float* out; unsigned* ticket; float scale[4]; };
+
 template <class Op, int V, int LC, int NW, int SUB = 1>
 __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T, int B,
-                                                              float* __restrict__ partials) {
+                                                              float* __restrict__ partials, const ScanFold fold) {
     static_assert(SUB == 1 || V == 1, "sub-wave tiles hold one column per lane");
     constexpr int NWV = NW * SUB;                 // virtual waves per workgroup
     constexpr int TILE = 64 * V / SUB;
@@ -155,7 +163,40 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
         if (threadIdx.x < NACC) {
             float sum = 0.f;
             for (int i = 0; i < NW; ++i) sum += s_red[threadIdx.x * NW + i];
-            partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sum;
+            float* slot = partials + (size_t)threadIdx.x * gridDim.x + blockIdx.x;
+            if (fold.out) {
+                __hip_atomic_store(slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this store has reached the memory side
+            } else {
+                *slot = sum;
+            }
+        }
+        if (fold.out) {
+            __shared__ int s_last;
+            __shared__ double s_fin[NW];
+            __syncthreads();   // every partial of this workgroup is out
+            if (threadIdx.x == 0)
+                s_last = __hip_atomic_fetch_add(fold.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+            __syncthreads();
+            if (s_last) {   // uniform: the last workgroup to arrive adds all partials, fixed order, fp64
+                for (int k = 0; k < NACC; ++k) {
+                    double s = 0.0;
+                    for (unsigned i = threadIdx.x; i < gridDim.x; i += NW * 64)
+                        s += (double)__hip_atomic_load(partials + (size_t)k * gridDim.x + i, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+                    if (lane == 0) s_fin[wr] = s;
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        double tot = 0.0;
+                        for (int i = 0; i < NW; ++i) tot += s_fin[i];
+                        fold.out[k] = (float)(tot * (double)fold.scale[k]);
+                    }
+                    __syncthreads();
+                }
+                if (threadIdx.x == 0) __hip_atomic_store(fold.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -185,20 +226,21 @@ inline unsigned scan_grid(const ScanCfg& c, int B) {
 }
 
 template <class Op, bool ALLOW_V2 = true>
-inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* partials, hipStream_t st) {
+inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* partials, hipStream_t st,
+                           const ScanFold& fold = ScanFold{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f}}) {
     const unsigned grid = scan_grid(c, B);
     if (c.sub == 2 && c.v == 1 && c.nw == 16) {
-        hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 2>), dim3(grid), dim3(1024), 0, st, op, T, B, partials);
+        hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 2>), dim3(grid), dim3(1024), 0, st, op, T, B, partials, fold);
         return;
     }
     if (c.sub == 4 && c.v == 1 && c.nw == 16) {
-        hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 4>), dim3(grid), dim3(1024), 0, st, op, T, B, partials);
+        hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 4>), dim3(grid), dim3(1024), 0, st, op, T, B, partials, fold);
         return;
     }
 #define HPC_RLL_SCAN_CASE(V_, NW_)                                                                          \
     if (c.v == V_ && c.nw == NW_) {                                                                         \
         hipLaunchKernelGGL((colscan_rev_kernel<Op, V_, 8, NW_>), dim3(grid), dim3(NW_ * 64), 0, st, op, T, B, \
-                           partials);                                                                       \
+                           partials, fold);                                                                 \
         return;                                                                                             \
     }
     HPC_RLL_SCAN_CASE(1, 1) HPC_RLL_SCAN_CASE(1, 2) HPC_RLL_SCAN_CASE(1, 4) HPC_RLL_SCAN_CASE(1, 8)

@@ -12,10 +12,24 @@
 // (categorical.hip) instead of three saved (T,B,N) buffers.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "colscan.hpp"
 #include "hpc_rll_hip.h"
 
 namespace hpc_rll {
+
+int g_scan_fold = 1;   // fold the loss finalisation into the scan launch (tune key 21; 0 = scan + finalize kernels)
+
+// Arrival tickets of the folded finalisation (colscan.hpp: ScanFold).  Zero at module load; every launch leaves its
+// ticket at zero.  A ticket must never be shared by two launches that can run concurrently:
+//   * eager launches: one ticket per (device, stream) -- launches on one stream run one after the other;
+//   * launches recorded into a hipGraph (a captured kernel keeps its ticket address, and graphs can be replayed on
+//     any stream): a ticket of their own each, never handed out again.
+// When a pool is exhausted the caller gets nullptr and runs scan + finalize as two launches.
+constexpr int kStreamTickets = 1024, kGraphTickets = 3072;
+__device__ unsigned g_scan_tickets[kStreamTickets + kGraphTickets];
 
 int categorical_forward(const float* logits, const int64_t* action, float* logp, float* ent, long rows, int N,
                         hipStream_t st);
@@ -29,6 +43,54 @@ inline int last_error() {
     return e == hipSuccess ? HPC_RLL_OK : (int)e;
 }
 inline bool al8(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
+struct TicketPool {
+    std::mutex mu;
+    struct Dev {
+        unsigned* base = nullptr;
+        bool tried = false;
+        int next_stream = 0, next_graph = 0;
+        std::unordered_map<hipStream_t, int> by_stream;
+    } dev[64];
+};
+inline unsigned* scan_ticket(hipStream_t st) {
+    if (!g_scan_fold) return nullptr;
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    static TicketPool pool;
+    std::lock_guard<std::mutex> lk(pool.mu);
+    TicketPool::Dev& dv = pool.dev[d];
+    if (!dv.tried) {
+        dv.tried = true;
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_scan_tickets)) == hipSuccess) dv.base = (unsigned*)p;
+        else (void)hipGetLastError();
+    }
+    if (!dv.base) return nullptr;
+    if (cs != hipStreamCaptureStatusNone)
+        return dv.next_graph < kGraphTickets ? dv.base + kStreamTickets + dv.next_graph++ : nullptr;
+    auto it = dv.by_stream.find(st);
+    if (it != dv.by_stream.end()) return dv.base + it->second;
+    if (dv.next_stream >= kStreamTickets) return nullptr;
+    dv.by_stream.emplace(st, dv.next_stream);
+    return dv.base + dv.next_stream++;
+}
+// scan launch + finalisation of its NACC sums into `out` (x scale[k]): one launch when a ticket is available
+template <class Op, bool ALLOW_V2>
+inline int scan_and_finalize(const Op& op, const ScanCfg& c, int T, int B, float* partials, int nacc, const float* scale,
+                             float* out, hipStream_t st) {
+    ScanFold fold{nullptr, scan_ticket(st), {0.f, 0.f, 0.f, 0.f}};
+    if (fold.ticket && nacc <= 4) {
+        fold.out = out;
+        for (int k = 0; k < nacc; ++k) fold.scale[k] = scale[k];
+    }
+    launch_colscan<Op, ALLOW_V2>(op, c, T, B, partials, st, fold);
+    const int rc = last_error();
+    if (rc || fold.out) return rc;
+    return finalize_sums(partials, (int)scan_grid(c, B), nacc, scale, out, st);
+}
 
 template <int V> __device__ __forceinline__ Pack<V> ldz(const float* p, bool ok) {
     if (ok) return load_pack<V>(p);
@@ -227,11 +289,8 @@ extern "C" int hpc_rll_td_lambda_forward(const float* value, const float* reward
     // oracle arithmetic (origin/td.py:239-243): discounts = gamma*lambda ; (gammas - discounts) * V_{t+1}
     const float disc = gamma * lambda;
     TdLambdaOp op{value, reward, weight, weight_mode, grad_buf, T, B, disc, gamma - disc, scale};
-    launch_colscan(op, c, T, B, partials, st);
-    int rc = last_error();
-    if (rc) return rc;
     const float sc = 0.5f * scale;
-    return finalize_sums(partials, (int)scan_grid(c, B), 1, &sc, loss, st);
+    return scan_and_finalize<TdLambdaOp, true>(op, c, T, B, partials, 1, &sc, loss, st);
 }
 
 extern "C" int hpc_rll_td_lambda_backward(const float* grad_loss, const float* grad_buf, float* grad_value, int T,
@@ -265,11 +324,8 @@ extern "C" int hpc_rll_vtrace_forward(const float* target_output, const float* b
     const ScanCfg c = scan_cfg(T, B, false);  // V=1: the 7-array row payload would spill at V=2
     VtraceOp op{value, reward, weight, logp_t, logp_b, ent, coef_pg, coef_ent, gv_unit, T, B,
                 gamma, gamma * lambda, rho_clip, c_clip, rho_pg_clip, scale};
-    launch_colscan<VtraceOp, false>(op, c, T, B, partials, st);
-    rc = last_error();
-    if (rc) return rc;
     const float sc[3] = {scale, scale, scale};
-    return finalize_sums(partials, (int)scan_grid(c, B), 3, sc, losses, st);
+    return scan_and_finalize<VtraceOp, false>(op, c, T, B, partials, 3, sc, losses, st);
 }
 
 extern "C" int hpc_rll_vtrace_backward(const float* g_pg, const float* g_value, const float* g_ent,
@@ -312,10 +368,7 @@ extern "C" int hpc_rll_upgo_forward(const float* target_output, const float* rho
     if (rc) return rc;
     const ScanCfg c = scan_cfg(T, B, false);  // V=1 (register budget, see VtraceOp)
     UpgoOp op{value, reward, rho, logp, coef, T, B, scale};
-    launch_colscan<UpgoOp, false>(op, c, T, B, partials, st);
-    rc = last_error();
-    if (rc) return rc;
-    return finalize_sums(partials, (int)scan_grid(c, B), 1, &scale, loss, st);
+    return scan_and_finalize<UpgoOp, false>(op, c, T, B, partials, 1, &scale, loss, st);
 }
 
 extern "C" int hpc_rll_upgo_backward(const float* g, const float* target_output, const int64_t* action,

@@ -94,7 +94,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
                                  const float* g_logp, const float* coef_ent, const float* g_ent,
                                  float* grad_logits, int64_t rows, int N, void* stream);
 
-/* Tuning knobs for experiments.  key 0: resident 256-thread blocks per CU targeted by the categorical row kernels
+/* Tuning knobs for experiments (a measurement / test hook, not a serving API): process-global plain ints, not
+ * synchronised -- set them while no other thread is launching work, and never between an LSTM forward and its backward
+ * (the workspace layout depends on the split-K knobs).  key 0: resident 256-thread blocks per CU targeted by the categorical row kernels
  * (1..64).  key 1: k-depth of the fp32 GEMM tiles (16, 32, or 0 = chosen by operand layout).  key 2: threads per
  * block of the scatter output kernel (256/512/1024).  key 3: persistent small-batch LSTM path on (1) / off (0).
  * key 4: replicas of every exchange word of that path (1..32).  key 5: minimum hidden units per workgroup there.
@@ -111,7 +113,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * x tile fits 52 KB of LDS, or a multiple of 4 in 4..64).  key 19: waves a column-scan launch (TD-lambda, V-trace,
  * UPGO) aims for when it picks its waves per workgroup (256..16384, default 4096).  key 20: workgroups of the large-batch
  * LSTM backward cell (768 <= H <= 1024) that walks >= 8 batch rows per workgroup and keeps the bias / gamma / beta column sums (64..1024,
- * default 512 = two per CU; 0 = always one row per workgroup + a separate column-reduction pass).
+ * default 512 = two per CU; 0 = always one row per workgroup + a separate column-reduction pass).  key 21: 1 (default) =
+ * the column scans (TD-lambda, V-trace, UPGO) finalise their loss sums in the last workgroup of the scan launch; 0 = a
+ * separate finalize launch (identical results: the same fixed-order fp64 sum of the same partials).
  */
 int hpc_rll_tune_set(int key, int value);
 

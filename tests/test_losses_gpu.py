@@ -399,3 +399,42 @@ def test_losses_are_deterministic():
         outs.append([x.detach().cpu().numpy() for x in (*ls, to.grad, v.grad)])
     for x, y in zip(*outs):
         assert np.array_equal(x, y)
+
+
+def test_folded_finalisation_under_concurrency():
+    """The column scans leave their loss sums to the LAST workgroup of the scan launch (csrc/colscan.hpp: ScanFold, an
+    arrival ticket per stream, relaxed agent-scope atomics, no release fence).  Stress it where it could fail: many
+    workgroups (B = 8192 columns -> 128+ partials spread over all XCDs), four streams launching concurrently with
+    different data, hundreds of back-to-back launches per stream -- every loss must equal the one the separate
+    finalize launch (tune key 21 = 0) computes from the same partials, and the ticket must be back at zero (the next
+    launch on the stream works)."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.td import TDLambda
+    from hpc_rll.rl_utils.vtrace import VTrace
+    T, B, N = 24, 8192, 4
+    g = torch.Generator(device=DEV).manual_seed(5)
+    nstream, reps = 4, 150
+    data = [(torch.randn(T + 1, B, device=DEV, generator=g), torch.randn(T, B, device=DEV, generator=g),
+             torch.randn(T, B, N, device=DEV, generator=g), torch.randn(T, B, N, device=DEV, generator=g),
+             torch.randint(0, N, (T, B), device=DEV, generator=g)) for _ in range(nstream)]
+    td, vt = TDLambda(T, B), VTrace(T, B, N)
+    try:
+        U.tune_set(21, 0)
+        with torch.no_grad():
+            want = [torch.stack([td(v, r), *vt(to, bo, a, v, r)]).cpu() for v, r, to, bo, a in data]
+        U.tune_set(21, 1)
+        streams = [torch.cuda.Stream() for _ in range(nstream)]
+        got = [[] for _ in range(nstream)]
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for _ in range(reps):
+                for i, s in enumerate(streams):
+                    v, r, to, bo, a = data[i]
+                    with torch.cuda.stream(s):
+                        got[i].append(torch.stack([td(v, r), *vt(to, bo, a, v, r)]))
+        torch.cuda.synchronize()
+    finally:
+        U.tune_set(21, 1)
+    for i in range(nstream):
+        allv = torch.stack(got[i]).cpu()
+        assert torch.equal(allv, want[i].expand_as(allv)), (i, (allv - want[i]).abs().max())
