@@ -21,7 +21,7 @@
 namespace hpc_rll {
 
 int onehot_scatter(const float* g, const float* buf, const int64_t* action, float* grad, long B, int N, int K,
-                   hipStream_t st);
+                   hipStream_t st, int planes = 1);
 
 namespace {
 
@@ -177,6 +177,200 @@ __global__ __launch_bounds__(256) void qrdqn_fwd_kernel(
     });
 }
 
+// ------------------------------------------------------------------------------------------------ large batches
+// The three wave-per-sample kernels above are written for the reference's test shapes (a handful of samples).  At
+// B ~ 10^5 they are what sets the time, and they leave most of the machine idle:
+//   * C51 recomputes the projection of ALL n_atom source atoms in every target lane (n_atom^2 / 64 projections per lane:
+//     a division, floor, ceil each);
+//   * IQN / QR-DQN use tau of the 64 lanes and re-load the tau' targets from memory in every lane's inner loop.
+// Below: the same arithmetic in the same order per element (results identical up to the order of the final per-sample
+// sum), with
+//   * C51 (n_atom <= 64): lane j projects source atom j ONCE; a target lane then visits only the contiguous run of
+//     sources that can reach it (found by binary search over the monotone floor positions), fetching them with
+//     ds_bpermute -- ~5 sources instead of n_atom, each ~10 instructions instead of ~30;
+//   * IQN / QR-DQN (tau, tau' <= 64): a sample is held by a GROUP of G = 2^k >= max(tau, tau') lanes, 64/G samples per
+//     wave; lane j of the group builds target j once, the pair loop fetches it with one ds_bpermute.
+template <int G> __device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+// 4 waves x 64/G samples per workgroup; workgroup partial = the per-sample contributions added in sample order.
+template <int G, class F>
+__device__ __forceinline__ void group_per_sample(int B, float* __restrict__ partials, F&& body) {
+    constexpr int SPW = 64 / G;
+    __shared__ float red[4 * SPW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gl = lane % G, gs = lane / G;
+    const long b = ((long)blockIdx.x * 4 + w) * SPW + gs;
+    const float contrib = body(b, b < (long)B, gl, gs * G);   // every lane runs the body (it shuffles): loads are guarded
+    if (gl == 0) red[w * SPW + gs] = b < (long)B ? contrib : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * SPW; ++i) s += red[i];
+        partials[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void dist_nstep_fwd64_kernel(
+    const float* __restrict__ dist, const float* __restrict__ next_dist, const int64_t* __restrict__ action,
+    const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
+    const float* __restrict__ weight, float* __restrict__ td_err, float* __restrict__ buf,
+    float* __restrict__ partials, int nstep, int B, int N, int n_atom, float gamma, float gamma_n, float v_min,
+    float v_max, float dz, float scale) {
+    wave_per_sample(B, partials, [&](int b, int lane) -> float {
+        float R = 0.f, f = 1.f;
+        for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
+        const float nd_scale = (1.f - done[b]) * gamma_n;
+        const float* __restrict__ p = dist + ((size_t)b * N + action[b]) * n_atom;
+        const float* __restrict__ pn = next_dist + ((size_t)b * N + next_action[b]) * n_atom;
+        const float w = weight ? weight[b] : 1.f;
+        // source atom j = lane (the expressions of dist_nstep_fwd_kernel, evaluated once per source)
+        const int j = lane < n_atom ? lane : n_atom - 1;
+        const float step = (v_max - v_min) / (float)(n_atom - 1);
+        const float sup = (j < n_atom / 2) ? (v_min + step * (float)j) : (v_max - step * (float)(n_atom - 1 - j));
+        float tz = __fadd_rn(R, __fmul_rn(nd_scale, sup));
+        tz = fminf(fmaxf(tz, v_min), v_max);
+        const float bp = __fdiv_rn(__fsub_rn(tz, v_min), dz);
+        const float lo = floorf(bp), up = ceilf(bp);
+        const int i_lo = __builtin_bit_cast(int, (int)lo), i_up = (int)up;
+        const int f_pn = __builtin_bit_cast(int, pn[j]);
+        const int f_al = __builtin_bit_cast(int, up - bp), f_au = __builtin_bit_cast(int, bp - lo);
+        float proj = 0.f;   // target atom k = lane: sources in order, the floor hit before the ceil hit of each source
+        if (nd_scale == 0.f) {
+            // terminal sample (done = 1): tz = R for every source, so all of next_dist's mass lands on the SAME two atoms
+            // and every lane holds the same i_lo / i_up / weights: one broadcast + two masked fmas per source
+            const float al = up - bp, au = bp - lo;
+            const bool hit_lo = lane == (int)lo, hit_up = lane == (int)up;
+            for (int s = 0; s < n_atom; ++s) {
+                const float s_pn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(f_pn, s));
+                if (hit_lo) proj = fmaf(s_pn, al, proj);
+                if (hit_up) proj = fmaf(s_pn, au, proj);
+            }
+        } else if (nd_scale > 0.f) {
+            // every step from j to floor(bp_j) is monotone (correctly rounded mul / add / div by positive numbers,
+            // clamp, floor), so i_lo is non-decreasing over the source lanes and the sources that can touch target k
+            // (floor = k, or floor = k-1 with ceil = k) are ONE contiguous run [first j: i_lo >= k-1, first j: i_lo > k):
+            // two 7-step binary searches through ds_bpermute, then a loop as long as the longest run of the wave
+            // (1/nd_scale + 2 sources).
+            int b0 = 0, e0 = n_atom, b1 = 0, e1 = n_atom;
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const int m0 = (b0 + e0) >> 1, m1 = (b1 + e1) >> 1;
+                const int v0 = __shfl(i_lo, m0 < n_atom ? m0 : n_atom - 1, 64);
+                const int v1 = __shfl(i_lo, m1 < n_atom ? m1 : n_atom - 1, 64);
+                if (b0 < e0) { if (v0 < lane - 1) b0 = m0 + 1; else e0 = m0; }
+                if (b1 < e1) { if (v1 <= lane) b1 = m1 + 1; else e1 = m1; }
+            }
+            const int len = lane < n_atom ? b1 - b0 : 0;
+            const int maxlen = __builtin_amdgcn_readfirstlane((int)wave_max((float)len));
+            for (int c = 0; c < maxlen; ++c) {
+                const int src = b0 + c < n_atom ? b0 + c : n_atom - 1;
+                const int s_lo = __shfl(i_lo, src, 64), s_up = __shfl(i_up, src, 64);
+                const float s_pn = __builtin_bit_cast(float, __shfl(f_pn, src, 64));
+                const float s_al = __builtin_bit_cast(float, __shfl(f_al, src, 64));
+                const float s_au = __builtin_bit_cast(float, __shfl(f_au, src, 64));
+                if (c < len && s_lo == lane) proj = fmaf(s_pn, s_al, proj);
+                if (c < len && s_up == lane) proj = fmaf(s_pn, s_au, proj);
+            }
+        } else {   // done > 1 (not a flag): no monotonicity to use, walk every source
+            for (int s = 0; s < n_atom; ++s) {
+                const int s_lo = __builtin_amdgcn_readlane(i_lo, s), s_up = __builtin_amdgcn_readlane(i_up, s);
+                const float s_pn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(f_pn, s));
+                const float s_al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(f_al, s));
+                const float s_au = __builtin_bit_cast(float, __builtin_amdgcn_readlane(f_au, s));
+                if (s_lo == lane) proj = fmaf(s_pn, s_al, proj);
+                if (s_up == lane) proj = fmaf(s_pn, s_au, proj);
+            }
+        }
+        float ce = 0.f;
+        if (lane < n_atom) {
+            const float pk = p[lane];
+            ce = proj * logf(pk);
+            buf[(size_t)b * n_atom + lane] = -w * proj / pk * scale;
+        }
+        ce = wave_sum(ce);
+        if (lane == 0) td_err[b] = -ce;
+        return -ce * w;
+    });
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void iqn_fwd_group_kernel(
+    const float* __restrict__ q, const float* __restrict__ next_q, const int64_t* __restrict__ action,
+    const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
+    const float* __restrict__ rq, const float* __restrict__ weight, const float* __restrict__ value_gamma,
+    float* __restrict__ td_err, float* __restrict__ buf, float* __restrict__ partials, int tau, int tau_p,
+    int nstep, int B, int N, float gamma, float gamma_n, float kappa, float scale) {
+    group_per_sample<G>(B, partials, [&](long b, bool ok, int gl, int base) -> float {
+        float R = 0.f, f = 1.f, vg = 0.f, w = 0.f, qi = 0.f, rho = 0.f, tgt = 0.f;
+        if (ok) {
+            for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
+            vg = (value_gamma ? value_gamma[b] : gamma_n) * (1.f - done[b]);
+            w = weight ? weight[b] : 1.f;
+            if (gl < tau) {
+                qi = q[((size_t)gl * B + b) * N + action[b]];
+                rho = rq[(size_t)gl * B + b];
+            }
+            if (gl < tau_p) tgt = fmaf(vg, next_q[((size_t)gl * B + b) * N + next_action[b]], R);
+        }
+        const float inv_tp = 1.f / (float)tau_p;
+        float li = 0.f, gi = 0.f;
+        for (int j = 0; j < tau_p; ++j) {
+            const float e = __shfl(tgt, base + j, 64) - qi;
+            const float ae = fabsf(e);
+            const float hub = (ae <= kappa) ? 0.5f * e * e : kappa * (ae - 0.5f * kappa);
+            const float dh = (ae <= kappa) ? e : ((e > 0.f) ? kappa : -kappa);
+            const float qw = fabsf(rho - ((e < 0.f) ? 1.f : 0.f)) / kappa;
+            li = fmaf(qw, hub, li);
+            gi = fmaf(qw, dh, gi);
+        }
+        if (ok && gl < tau) buf[(size_t)b * tau + gl] = -gi * inv_tp * w * scale;   // de/dq = -1
+        const float loss = group_sum<G>(gl < tau ? li : 0.f) * inv_tp;
+        if (ok && gl == 0) td_err[b] = loss;
+        return loss * w;
+    });
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void qrdqn_fwd_group_kernel(
+    const float* __restrict__ q, const float* __restrict__ next_q, const int64_t* __restrict__ action,
+    const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
+    const float* __restrict__ weight, const float* __restrict__ value_gamma, float* __restrict__ td_err,
+    float* __restrict__ buf, float* __restrict__ partials, int tau, int nstep, int B, int N, float gamma,
+    float gamma_n, float tau_value, float scale) {
+    group_per_sample<G>(B, partials, [&](long b, bool ok, int gl, int base) -> float {
+        float R = 0.f, f = 1.f, w = 0.f, qi = 0.f, tgt = 0.f;
+        if (ok) {
+            for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
+            const float vg = (value_gamma ? value_gamma[b] : gamma_n) * (1.f - done[b]);
+            w = weight ? weight[b] : 1.f;
+            if (gl < tau) {
+                qi = q[((size_t)b * N + action[b]) * tau + gl];
+                tgt = fmaf(vg, next_q[((size_t)b * N + next_action[b]) * tau + gl], R);
+            }
+        }
+        const float inv_tau = 1.f / (float)tau;
+        float li = 0.f, gi = 0.f;
+        for (int j = 0; j < tau; ++j) {
+            const float e = __shfl(tgt, base + j, 64) - qi;
+            const float ae = fabsf(e);
+            const float u = (ae < 1.f) ? 0.5f * e * e : ae - 0.5f;       // smooth_l1, beta = 1
+            const float du = (ae < 1.f) ? e : ((e > 0.f) ? 1.f : -1.f);
+            const float qw = fabsf(tau_value - ((e <= 0.f) ? 1.f : 0.f));
+            li = fmaf(qw, u, li);
+            gi = fmaf(qw, du, gi);
+        }
+        if (ok && gl < tau) buf[(size_t)b * tau + gl] = -gi * inv_tau * w * scale;
+        const float loss = group_sum<G>(gl < tau ? li : 0.f) * inv_tau;
+        if (ok && gl == 0) td_err[b] = loss;
+        return loss * w;
+    });
+}
+
+inline int group_lanes(int n) { return n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : 64; }
+
 }  // namespace
 }  // namespace hpc_rll
 
@@ -196,6 +390,11 @@ extern "C" int hpc_rll_dist_nstep_td_forward(const float* dist, const float* nex
     const int blocks = (B + 3) / 4;
     // delta_z is a python double in the oracle, rounded to fp32 when it meets the fp32 tensor
     const float dz = (float)(((double)v_max - (double)v_min) / (double)(n_atom - 1));
+    if (n_atom <= 64)
+        hipLaunchKernelGGL(dist_nstep_fwd64_kernel, dim3(blocks), dim3(256), 0, st, dist, next_n_dist, action,
+                           next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma,
+                           (float)pow((double)gamma, (double)nstep), v_min, v_max, dz, scale);
+    else
     hipLaunchKernelGGL(dist_nstep_fwd_kernel, dim3(blocks), dim3(256), 0, st, dist, next_n_dist, action,
                        next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma,
                        (float)pow((double)gamma, (double)nstep), v_min, v_max, dz, scale);
@@ -224,10 +423,23 @@ extern "C" int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_
     if (!q || !next_n_q || !action || !next_n_action || (nstep && !reward) || !done || !replay_quantiles || !td_err ||
         !buf || !partials)
         return HPC_RLL_EINVAL;
-    const int blocks = (B + 3) / 4;
+    int blocks = (B + 3) / 4;
+    const float gamma_n = (float)pow((double)gamma, (double)nstep);
+    const int gmax = tau > tau_prime ? tau : tau_prime;
+    if (gmax <= 64) {
+        const int G = group_lanes(gmax);
+        blocks = (B + 4 * (64 / G) - 1) / (4 * (64 / G));
+#define HPC_RLL_IQN_G(G_)                                                                                               \
+        if (G == G_)                                                                                                    \
+            hipLaunchKernelGGL(iqn_fwd_group_kernel<G_>, dim3(blocks), dim3(256), 0, st, q, next_n_q, action,            \
+                               next_n_action, reward, done, replay_quantiles, weight, value_gamma, td_err, buf, partials, \
+                               tau, tau_prime, nstep, B, N, gamma, gamma_n, kappa, scale);
+        HPC_RLL_IQN_G(8) HPC_RLL_IQN_G(16) HPC_RLL_IQN_G(32) HPC_RLL_IQN_G(64)
+#undef HPC_RLL_IQN_G
+    } else
     hipLaunchKernelGGL(iqn_fwd_kernel, dim3(blocks), dim3(256), 0, st, q, next_n_q, action, next_n_action, reward,
                        done, replay_quantiles, weight, value_gamma, td_err, buf, partials, tau, tau_prime, nstep, B, N,
-                       gamma, (float)pow((double)gamma, (double)nstep), kappa, scale);
+                       gamma, gamma_n, kappa, scale);
     int rc = last_error();
     if (rc) return rc;
     return finalize_sums(partials, blocks, 1, &scale, loss, st);
@@ -238,6 +450,9 @@ extern "C" int hpc_rll_iqn_nstep_td_backward(const float* grad_loss, const float
     if (tau <= 0 || B < 0 || N <= 0) return HPC_RLL_EINVAL;
     if (B == 0) return HPC_RLL_OK;
     if (!grad_loss || !buf || !action || !grad_q) return HPC_RLL_EINVAL;
+    // (tau, B, N) = tau planes of one-hot rows: the 16-byte kernel of sample_ops.hip when the rows allow it
+    const int rc = onehot_scatter(grad_loss, buf, action, grad_q, B, N, 1, (hipStream_t)stream, tau);
+    if (rc != HPC_RLL_EUNSUPPORTED) return rc;
     long blocks = ((long)tau * B * N + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(iqn_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad_loss, buf,
@@ -255,10 +470,22 @@ extern "C" int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_
     if (B == 0) return (int)hipMemsetAsync(loss, 0, sizeof(float), st);
     if (!q || !next_n_q || !action || !next_n_action || (nstep && !reward) || !done || !td_err || !buf || !partials)
         return HPC_RLL_EINVAL;
-    const int blocks = (B + 3) / 4;
+    int blocks = (B + 3) / 4;
+    const float gamma_n = (float)pow((double)gamma, (double)nstep);
+    if (tau <= 64) {
+        const int G = group_lanes(tau);
+        blocks = (B + 4 * (64 / G) - 1) / (4 * (64 / G));
+#define HPC_RLL_QR_G(G_)                                                                                              \
+        if (G == G_)                                                                                                  \
+            hipLaunchKernelGGL(qrdqn_fwd_group_kernel<G_>, dim3(blocks), dim3(256), 0, st, q, next_n_q, action,        \
+                               next_n_action, reward, done, weight, value_gamma, td_err, buf, partials, tau, nstep, B, N, \
+                               gamma, gamma_n, tau_value, scale);
+        HPC_RLL_QR_G(8) HPC_RLL_QR_G(16) HPC_RLL_QR_G(32) HPC_RLL_QR_G(64)
+#undef HPC_RLL_QR_G
+    } else
     hipLaunchKernelGGL(qrdqn_fwd_kernel, dim3(blocks), dim3(256), 0, st, q, next_n_q, action, next_n_action, reward,
                        done, weight, value_gamma, td_err, buf, partials, tau, nstep, B, N, gamma,
-                       (float)pow((double)gamma, (double)nstep), tau_value, scale);
+                       gamma_n, tau_value, scale);
     int rc = last_error();
     if (rc) return rc;
     return finalize_sums(partials, blocks, 1, &scale, loss, st);

@@ -141,12 +141,59 @@ __global__ __launch_bounds__(256) void onehot_scatter_kernel(const float* __rest
     }
 }
 
+// The same gradient with 16-byte stores and no per-element division (the 4-byte kernel above spends a 64-bit divide
+// and a dependent action load on every float it writes: 3.5 TB/s on a pure write stream).  The output is rows of
+// L = N*K floats (one per sample; PLANES > 1: `planes` stacked (B, N) planes with K = 1, the IQN layout (tau, B, N),
+// plane = blockIdx.y), all zero except the K floats at [a*K, a*K + K).  A workgroup takes `rb` consecutive samples =
+// rb*L/4 quads; quad -> (sample, column) by a multiply-high with a host-made reciprocal (exact for the ranges used).
+__global__ __launch_bounds__(256) void onehot_rows4_kernel(const float* __restrict__ g, const float* __restrict__ buf,
+                                                           const int64_t* __restrict__ action, float* __restrict__ grad,
+                                                           long B, int N, int K, int rb, unsigned l4, unsigned magic) {
+    const float u = g[0];
+    const long b0 = (long)blockIdx.x * rb;
+    const int nb = (int)(B - b0 < rb ? B - b0 : rb);
+    const unsigned quads = (unsigned)nb * l4;
+    const int plane = blockIdx.y, planes = gridDim.y;
+    const long L = (long)l4 * 4;
+    float* __restrict__ out = grad + ((long)plane * B + b0) * L;
+    const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned q = threadIdx.x; q < quads; q += 256) {
+        const unsigned r = rb > 1 ? (l4 == 1 ? q : __umulhi(q, magic)) : 0u;
+        const int col = (int)(q - r * l4) * 4;
+        const long b = b0 + r;
+        const long a = action[b];
+        const int lo = (a >= 0 && a < (long)N) ? (int)a * K : -K - 4;   // an out-of-range action selects nothing
+        vfloat4 v = zero4;
+        if (col + 4 > lo && col < lo + K) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = col + j - lo;
+                if (k >= 0 && k < K) v[j] = u * (planes > 1 ? buf[b * planes + plane] : buf[b * K + k]);
+            }
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(out + (long)q * 4));
+    }
+}
+
 }  // namespace
 
+// planes > 1: grad is (planes, B, N) and buf is (B, planes) (K must be 1); else grad is (B, N, K), buf (B, K).
 int onehot_scatter(const float* g, const float* buf, const int64_t* action, float* grad, long B, int N, int K,
-                   hipStream_t st) {
-    const long total = B * N * K;
+                   hipStream_t st, int planes) {
+    const long total = B * N * K * (planes > 1 ? planes : 1);
     if (total == 0) return HPC_RLL_OK;
+    const long L = (long)N * K;
+    if (L % 4 == 0 && L / 4 < (1L << 20) && (reinterpret_cast<uintptr_t>(grad) & 15) == 0 && (planes <= 1 || K == 1) &&
+        planes <= 65535) {
+        const unsigned l4 = (unsigned)(L / 4);
+        const int rb = l4 >= 4096 ? 1 : (int)(4096 / l4);          // ~16 quads per thread
+        const unsigned magic = (unsigned)(((1ull << 32) + l4 - 1) / l4);   // q / l4 == umulhi(q, magic) for q < 2^32 / l4
+        const long blocks = (B + rb - 1) / rb;
+        hipLaunchKernelGGL(onehot_rows4_kernel, dim3((unsigned)blocks, planes > 1 ? planes : 1), dim3(256), 0, st, g, buf,
+                           action, grad, B, N, K, rb, l4, l4 == 1 ? 0u : magic);
+        return last_error();
+    }
+    if (planes > 1) return HPC_RLL_EUNSUPPORTED;   // (the IQN caller keeps its own 4-byte kernel for this case)
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(onehot_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, buf, action, grad, B, N, K);
@@ -233,5 +280,5 @@ extern "C" int hpc_rll_q_nstep_td_backward(const float* grad_loss, const float* 
     if (B < 0 || N <= 0) return HPC_RLL_EINVAL;
     if (B == 0) return HPC_RLL_OK;
     if (!grad_loss || !grad_buf || !action || !grad_q) return HPC_RLL_EINVAL;
-    return onehot_scatter(grad_loss, grad_buf, action, grad_q, B, N, 1, (hipStream_t)stream);
+    return onehot_scatter(grad_loss, grad_buf, action, grad_q, B, N, 1, (hipStream_t)stream, 1);
 }

@@ -147,6 +147,7 @@ def test_fuzz_td_family():
         loss, per = IQNNStepTDError(tau, taup, T, B, N)(dq, G(nq3), G(a), G(na), G(r), G(done), G(rq), 0.97, 0.8, G(w))
         loss.backward()
         assert rel_err(l64.item(), loss.item()) < 2e-5, ("iqn", tau, taup, T, B, N)
+        assert rel_err(p64.detach().numpy(), per.cpu().numpy()) < 2e-5, ("iqn td_err", tau, taup, T, B, N)
         assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
         q4, nq4 = f32(rng, B, N, tau), f32(rng, B, N, tau)
         q64 = D(q4, True)
@@ -156,7 +157,31 @@ def test_fuzz_td_family():
         loss, per = QRDQNNStepTDError(tau, T, B, N)(dq, G(nq4), G(a), G(na), G(r), G(done), 0.97, G(w))
         loss.backward()
         assert rel_err(l64.item(), loss.item()) < 2e-5, ("qrdqn", tau, T, B, N)
+        assert rel_err(p64.detach().numpy(), per.cpu().numpy()) < 2e-5, ("qrdqn td_err", tau, T, B, N)
         assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+
+
+def test_fuzz_dist_nstep_td():
+    """C51 over random shapes: n_atom on both sides of 64 (one-pass readlane kernel / the general kernel), row lengths
+    N*n_atom that do and do not allow the 16-byte gradient kernel, done = 1 samples (all mass on one atom).  Oracle in
+    fp32 (floor / ceil of the projected position is discontinuous), tolerance as the reference-shape test."""
+    from hpc_rll.rl_utils.td import DistNStepTD
+    rng = np.random.default_rng(9)
+    for T, B, N, n_atom in shapes(rng, (1, 6), (1, 200), (1, 24), (2, 90)):
+        dist = (np.abs(f32(rng, B, N, n_atom)) + 1e-3).astype(np.float32)
+        nd = np.abs(f32(rng, B, N, n_atom))
+        a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+        r, done, w = f32(rng, T, B), (rng.random(B) < 0.3).astype(np.float32), rng.random(B).astype(np.float32)
+        d32 = torch.from_numpy(dist).requires_grad_(True)
+        l32, p32 = R.dist_nstep_td_error(d32, torch.from_numpy(nd), torch.from_numpy(a), torch.from_numpy(na),
+                                         torch.from_numpy(r), torch.from_numpy(done), torch.from_numpy(w), 0.95, -10., 10., n_atom)
+        l32.backward()
+        dd = G(dist, True)
+        loss, per = DistNStepTD(T, B, N, n_atom)(dd, G(nd), G(a), G(na), G(r), G(done), G(w), 0.95, -10., 10.)
+        loss.backward()
+        assert rel_err(l32.item(), loss.item()) < 1e-4, (T, B, N, n_atom)
+        assert rel_err(p32.detach().numpy(), per.cpu().numpy()) < 1e-4, (T, B, N, n_atom)
+        assert rel_err(d32.grad.numpy(), dd.grad.cpu().numpy()) < 1e-4, (T, B, N, n_atom)
 
 
 def test_fuzz_scatter_and_padding():

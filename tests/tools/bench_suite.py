@@ -2,7 +2,7 @@
 """Suite benchmark at the BASELINE.json configs[2..4] shapes (plus the reference test shapes): per-op forward /
 backward time (HIP events on the launch stream, median of interleaved repeats) against the algorithmic-bytes or
 flop roofline.  Not the headline bench (bench.py); these are the numbers DESIGN.md quotes.
-Writes gpurun_out/suite_<tag>.json and .txt.   Usage: bench_suite.py [c3|c4|c5|small|all]"""
+Writes gpurun_out/suite_<tag>.json and .txt.   Usage: bench_suite.py [c3|td|gemm|c4|c5|small|all]"""
 import json
 import os
 import statistics
@@ -131,6 +131,56 @@ def suite_c4(S=128, B=4096, I=1024, H=1024, L=1):
     report("lstm", f"S={S} B={B} I={I} H={H} L={L}", t_f, None, t_b, None, flops_f, flops_b)
 
 
+def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
+    """a5-a7 at a batch where the kernels, not the host, set the time.  These ops GATHER the taken action's entry / atom
+    row / quantile row per sample (everything else of q is never read) and their backward writes a full one-hot-shaped
+    gradient: forward bytes are counted with every gathered piece rounded up to whole 128-byte lines (what HBM has to
+    move), backward bytes = the gradient tensor written + the per-sample unit gradient read."""
+    from hpc_rll.rl_utils.td import DistNStepTD, IQNNStepTDError, QNStepTD, QRDQNNStepTDError
+    g = torch.Generator(device=dev).manual_seed(0)
+    line = lambda nbytes: (nbytes + 127) // 128 * 128  # noqa: E731
+    act = lambda: torch.randint(0, N, (B,), device=dev, generator=g)  # noqa: E731
+    reward = torch.randn(nstep, B, device=dev, generator=g)
+    done = (torch.rand(B, device=dev, generator=g) < 0.1).float()
+    weight = torch.rand(B, device=dev, generator=g)
+    a, na = act(), act()
+    per_sample = 16 + 4 * nstep + 4 + 4 + 4   # actions, rewards, done, weight, td_err
+
+    q = torch.randn(B, N, device=dev, generator=g, requires_grad=True)
+    nq = torch.randn(B, N, device=dev, generator=g)
+    m = QNStepTD(nstep, B, N)
+    t_f, t_b = fwd_bwd(lambda: m(q, nq, a, na, reward, done, weight, 0.99)[0], [q])
+    report("q_nstep_td", f"B={B} N={N} nstep={nstep}", t_f, B * (2 * 128 + per_sample), t_b, B * (4 * N + 4))
+    del q, nq
+
+    d = torch.softmax(torch.randn(B, N, n_atom, device=dev, generator=g), -1).requires_grad_(True)
+    nd = torch.softmax(torch.randn(B, N, n_atom, device=dev, generator=g), -1)
+    m = DistNStepTD(nstep, B, N, n_atom)
+    t_f, t_b = fwd_bwd(lambda: m(d, nd, a, na, reward, done, weight, 0.99, -10.0, 10.0)[0], [d])
+    report("dist_nstep_td", f"B={B} N={N} atoms={n_atom}", t_f, B * (2 * line(4 * n_atom) + 128 + per_sample + 4 * n_atom),
+           t_b, B * (4 * N * n_atom + 4 * n_atom))
+    del d, nd
+
+    Bi = B // 4
+    ai, nai = a[:Bi].contiguous(), na[:Bi].contiguous()
+    qi = torch.randn(tau, Bi, N, device=dev, generator=g, requires_grad=True)
+    nqi = torch.randn(tau, Bi, N, device=dev, generator=g)
+    rq = torch.rand(tau, Bi, device=dev, generator=g)
+    m = IQNNStepTDError(tau, tau, nstep, Bi, N)
+    t_f, t_b = fwd_bwd(lambda: m(qi, nqi, ai, nai, reward[:, :Bi].contiguous(), done[:Bi].contiguous(), rq, 0.99, 1.0,
+                                 weight[:Bi].contiguous())[0], [qi])
+    report("iqn_nstep_td", f"tau=tau'={tau} B={Bi} N={N}", t_f, Bi * (2 * tau * 128 + 8 * tau + per_sample), t_b,
+           Bi * (4 * tau * N + 4 * tau))
+    del qi, nqi
+
+    qq = torch.randn(B, N, tau, device=dev, generator=g, requires_grad=True)
+    nqq = torch.randn(B, N, tau, device=dev, generator=g)
+    m = QRDQNNStepTDError(tau, nstep, B, N)
+    t_f, t_b = fwd_bwd(lambda: m(qq, nqq, a, na, reward, done, 0.99, weight)[0], [qq])
+    report("qrdqn_nstep_td", f"B={B} N={N} tau={tau}", t_f, B * (2 * line(4 * tau) + per_sample + 4 * tau), t_b,
+           B * (4 * N * tau + 4 * tau))
+
+
 def suite_gemm():
     import hpc_torch_utils_network as U
     for (M, N, K) in [(4096, 4096, 4096), (4096, 4096, 1024), (524288, 4096, 1024)]:
@@ -220,6 +270,8 @@ if __name__ == "__main__":
     if which in ("c3", "all"):
         suite_c3()
         suite_ppo()
+    if which in ("td", "all"):
+        suite_td()
     if which in ("gemm", "all"):
         suite_gemm()
     if which in ("c4", "all"):
