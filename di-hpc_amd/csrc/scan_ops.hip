@@ -62,6 +62,7 @@ inline unsigned* scan_ticket(hipStream_t st) {
     static TicketPool pool;
     std::lock_guard<std::mutex> lk(pool.mu);
     TicketPool::Dev& dv = pool.dev[d];
+    if (!dv.base && cs != hipStreamCaptureStatusNone) return nullptr;   // no symbol lookup (a module load) inside a capture
     if (!dv.tried) {
         dv.tried = true;
         void* p = nullptr;
