@@ -31,5 +31,33 @@ for st in ("cover", "add"):
     o.backward(torch.ones_like(o))
 a, b = torch.randn(8192, 1024, device=dev), torch.randn(1024, 4096, device=dev)
 U.gemm_f32(a, b)
+del o, x, target, behaviour, copy_dst, a, b
+# round 2: large-batch LSTM cells (gates recomputed, row-walking backward) and the TD family at B = 262144
+from hpc_rll.torch_utils.network.rnn import LSTM
+S, Bl, Hl = 4, 4096, 1024
+m = LSTM(S, Bl, Hl, Hl, 1).to(dev)
+xl = torch.randn(S, Bl, Hl, device=dev, generator=g, requires_grad=True)
+y, _ = m(xl, None)
+y.backward(torch.ones_like(y))
+del m, xl, y
+from hpc_rll.rl_utils.td import DistNStepTD, IQNNStepTDError, QRDQNNStepTDError
+Bt, Nt, nstep, n_atom, tau = 1 << 18, 64, 5, 51, 32
+act = lambda: torch.randint(0, Nt, (Bt,), device=dev, generator=g)  # noqa: E731
+rew, done, w = torch.randn(nstep, Bt, device=dev, generator=g), (torch.rand(Bt, device=dev, generator=g) < 0.1).float(), torch.rand(Bt, device=dev, generator=g)
+at_, nat = act(), act()
+d = torch.softmax(torch.randn(Bt, Nt, n_atom, device=dev, generator=g), -1).requires_grad_(True)
+nd = torch.softmax(torch.randn(Bt, Nt, n_atom, device=dev, generator=g), -1)
+DistNStepTD(nstep, Bt, Nt, n_atom)(d, nd, at_, nat, rew, done, w, 0.99, -10.0, 10.0)[0].backward()
+del d, nd
+qq = torch.randn(Bt, Nt, tau, device=dev, generator=g, requires_grad=True)
+nqq = torch.randn(Bt, Nt, tau, device=dev, generator=g)
+QRDQNNStepTDError(tau, nstep, Bt, Nt)(qq, nqq, at_, nat, rew, done, 0.99, w)[0].backward()
+del qq, nqq
+Bi = Bt // 4
+qi = torch.randn(tau, Bi, Nt, device=dev, generator=g, requires_grad=True)
+nqi = torch.randn(tau, Bi, Nt, device=dev, generator=g)
+IQNNStepTDError(tau, tau, nstep, Bi, Nt)(qi, nqi, at_[:Bi].contiguous(), nat[:Bi].contiguous(), rew[:, :Bi].contiguous(),
+                                        done[:Bi].contiguous(), torch.rand(tau, Bi, device=dev, generator=g), 0.99, 1.0,
+                                        w[:Bi].contiguous())[0].backward()
 torch.cuda.synchronize()
 print("pmc suite done")
