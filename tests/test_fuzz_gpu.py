@@ -240,3 +240,38 @@ def test_fuzz_lstm():
         (oy.sum() + oh.sum() * 0.5 - oc.sum()).backward()
         assert rel_err(oy.detach().numpy(), y.detach().cpu().numpy()) < 2e-5, (S, B, I, H, L)
         assert rel_err(ox.grad.numpy(), dx.grad.cpu().numpy()) < 2e-4, (S, B, I, H, L)
+
+
+@pytest.mark.parametrize("B,N,K", [(7, 4, 1), (300, 4, 1), (5, 256, 64), (3, 8, 2), (9, 2, 2), (4, 1024, 16), (6, 6, 2)])
+def test_onehot_gradient_row_shapes(B, N, K):
+    """The one-hot-shaped gradients (q-TD K = 1, QR-DQN K = tau, IQN tau planes) at the corners of the 16-byte kernel's
+    index arithmetic: rows of ONE quad (N*K = 4), rows longer than a workgroup's 4096 quads (one row per workgroup, no
+    division), rows that do not allow 16-byte stores (the 4-byte kernel)."""
+    from hpc_rll.rl_utils.td import IQNNStepTDError, QNStepTD, QRDQNNStepTDError
+    rng = np.random.default_rng(B * 131 + N * 7 + K)
+    T = 3
+    a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+    r, done, w = f32(rng, T, B), (rng.random(B) < 0.3).astype(np.float32), rng.random(B).astype(np.float32)
+    if K == 1:
+        q, nq = f32(rng, B, N), f32(rng, B, N)
+        q64 = D(q, True)
+        l64, _ = R.q_nstep_td_error(q64, D(nq), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(w), 0.97, False)
+        l64.backward()
+        dq = G(q, True)
+        QNStepTD(T, B, N)(dq, G(nq), G(a), G(na), G(r), G(done), G(w), 0.97)[0].backward()
+        assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+    tau = max(K, 2)
+    q4, nq4 = f32(rng, B, N, tau), f32(rng, B, N, tau)
+    q64 = D(q4, True)
+    l64, _ = R.qrdqn_nstep_td_error(q64, D(nq4), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), tau, D(w), 0.97)
+    l64.backward()
+    dq = G(q4, True)
+    QRDQNNStepTDError(tau, T, B, N)(dq, G(nq4), G(a), G(na), G(r), G(done), 0.97, G(w))[0].backward()
+    assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+    q3, nq3, rq = f32(rng, tau, B, N), f32(rng, tau, B, N), rng.random((tau, B)).astype(np.float32)
+    q64 = D(q3, True)
+    l64, _ = R.iqn_nstep_td_error(q64, D(nq3), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(rq), D(w), 0.97, 0.8)
+    l64.backward()
+    dq = G(q3, True)
+    IQNNStepTDError(tau, tau, T, B, N)(dq, G(nq3), G(a), G(na), G(r), G(done), G(rq), 0.97, 0.8, G(w))[0].backward()
+    assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
