@@ -51,7 +51,52 @@ namespace hpc_rll {
 // tiling is ONE workgroup walking 8 barriers.
 // Where the last workgroup leaves the NACC sums (x scale[k]); out == nullptr: partials only (the caller finalises).
 // `ticket` is zero before the launch and is left at zero by it.
-struct ScanFold { float* out; unsigned* ticket; float scale[4]; };
+struct ScanFold { float* out; unsigned* ticket; float scale[8]; };
+
+// scan_ops.hip: the fold of a launch on `st` (its ticket, see there), or a partials-only fold when none is available
+ScanFold make_fold(hipStream_t st, int nacc, const float* scale, float* out);
+
+// Workgroup epilogue shared by every kernel that ends in NACC loss sums: thread k < NACC holds the workgroup's sum k in
+// `sum`.  Stores partials[k][blockIdx.x]; with a fold the last workgroup of the grid to arrive adds all partials in a
+// fixed order (fp64) and writes out[k] = total * scale[k].  Called by ALL NT threads (it barriers).
+template <int NACC, int NT>
+__device__ __forceinline__ void publish_sums(float sum, float* __restrict__ partials, const ScanFold& fold) {
+    if (threadIdx.x < NACC) {
+        float* slot = partials + (size_t)threadIdx.x * gridDim.x + blockIdx.x;
+        if (fold.out) {
+            __hip_atomic_store(slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this store has reached the memory side
+        } else {
+            *slot = sum;
+        }
+    }
+    if (!fold.out) return;
+    constexpr int NWAVES = NT / 64;
+    __shared__ int s_last;
+    __shared__ double s_fin[NWAVES];
+    const int lane = threadIdx.x & 63, wr = threadIdx.x >> 6;
+    __syncthreads();   // every partial of this workgroup is out
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(fold.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;   // uniform: the last workgroup to arrive adds all partials
+    for (int k = 0; k < NACC; ++k) {
+        double s = 0.0;
+        for (unsigned i = threadIdx.x; i < gridDim.x; i += NT)
+            s += (double)__hip_atomic_load(partials + (size_t)k * gridDim.x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) s_fin[wr] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int i = 0; i < NWAVES; ++i) tot += s_fin[i];
+            fold.out[k] = (float)(tot * (double)fold.scale[k]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(fold.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <class Op, int V, int LC, int NW, int SUB = 1>
 __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T, int B,
@@ -160,44 +205,10 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
             if (lane == 0) s_red[k * NW + wr] = sum;
         }
         __syncthreads();
-        if (threadIdx.x < NACC) {
-            float sum = 0.f;
+        float sum = 0.f;
+        if (threadIdx.x < NACC)
             for (int i = 0; i < NW; ++i) sum += s_red[threadIdx.x * NW + i];
-            float* slot = partials + (size_t)threadIdx.x * gridDim.x + blockIdx.x;
-            if (fold.out) {
-                __hip_atomic_store(slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this store has reached the memory side
-            } else {
-                *slot = sum;
-            }
-        }
-        if (fold.out) {
-            __shared__ int s_last;
-            __shared__ double s_fin[NW];
-            __syncthreads();   // every partial of this workgroup is out
-            if (threadIdx.x == 0)
-                s_last = __hip_atomic_fetch_add(fold.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-            __syncthreads();
-            if (s_last) {   // uniform: the last workgroup to arrive adds all partials, fixed order, fp64
-                for (int k = 0; k < NACC; ++k) {
-                    double s = 0.0;
-                    for (unsigned i = threadIdx.x; i < gridDim.x; i += NW * 64)
-                        s += (double)__hip_atomic_load(partials + (size_t)k * gridDim.x + i, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-                    if (lane == 0) s_fin[wr] = s;
-                    __syncthreads();
-                    if (threadIdx.x == 0) {
-                        double tot = 0.0;
-                        for (int i = 0; i < NW; ++i) tot += s_fin[i];
-                        fold.out[k] = (float)(tot * (double)fold.scale[k]);
-                    }
-                    __syncthreads();
-                }
-                if (threadIdx.x == 0) __hip_atomic_store(fold.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        publish_sums<NACC, NW * 64>(sum, partials, fold);
     }
 }
 
@@ -227,7 +238,7 @@ inline unsigned scan_grid(const ScanCfg& c, int B) {
 
 template <class Op, bool ALLOW_V2 = true>
 inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* partials, hipStream_t st,
-                           const ScanFold& fold = ScanFold{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f}}) {
+                           const ScanFold& fold = ScanFold{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}}) {
     const unsigned grid = scan_grid(c, B);
     if (c.sub == 2 && c.v == 1 && c.nw == 16) {
         hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 2>), dim3(grid), dim3(1024), 0, st, op, T, B, partials, fold);

@@ -32,7 +32,7 @@ inline int last_error() {
 
 // 4 waves (= 4 samples) per workgroup; workgroup partial = sum of its 4 per-sample weighted losses.
 template <class F>
-__device__ __forceinline__ void wave_per_sample(int B, float* __restrict__ partials, F&& body) {
+__device__ __forceinline__ void wave_per_sample(int B, float* __restrict__ partials, const ScanFold& fold, F&& body) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + w;
@@ -40,7 +40,9 @@ __device__ __forceinline__ void wave_per_sample(int B, float* __restrict__ parti
     if (b < B) contrib = body(b, lane);
     if (lane == 0) red[w] = contrib;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    float s = 0.f;
+    if (threadIdx.x == 0) s = (red[0] + red[1]) + (red[2] + red[3]);
+    publish_sums<1, 256>(s, partials, fold);   // with a fold: the last workgroup also finalises the loss (colscan.hpp)
 }
 
 // ------------------------------------------------------------------------------------------------ C51
@@ -50,8 +52,8 @@ __global__ __launch_bounds__(256) void dist_nstep_fwd_kernel(
     const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
     const float* __restrict__ weight, float* __restrict__ td_err, float* __restrict__ buf,
     float* __restrict__ partials, int nstep, int B, int N, int n_atom, float gamma, float gamma_n, float v_min,
-    float v_max, float dz, float scale) {
-    wave_per_sample(B, partials, [&](int b, int lane) -> float {
+    float v_max, float dz, float scale, const ScanFold fold) {
+    wave_per_sample(B, partials, fold, [&](int b, int lane) -> float {
         float R = 0.f, f = 1.f;
         for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
         const float nd_scale = (1.f - done[b]) * gamma_n;
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(256) void iqn_fwd_kernel(
     const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
     const float* __restrict__ rq, const float* __restrict__ weight, const float* __restrict__ value_gamma,
     float* __restrict__ td_err, float* __restrict__ buf, float* __restrict__ partials, int tau, int tau_p,
-    int nstep, int B, int N, float gamma, float gamma_n, float kappa, float scale) {
-    wave_per_sample(B, partials, [&](int b, int lane) -> float {
+    int nstep, int B, int N, float gamma, float gamma_n, float kappa, float scale, const ScanFold fold) {
+    wave_per_sample(B, partials, fold, [&](int b, int lane) -> float {
         float R = 0.f, f = 1.f;
         for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
         const float vg = (value_gamma ? value_gamma[b] : gamma_n) * (1.f - done[b]);
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(256) void qrdqn_fwd_kernel(
     const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
     const float* __restrict__ weight, const float* __restrict__ value_gamma, float* __restrict__ td_err,
     float* __restrict__ buf, float* __restrict__ partials, int tau, int nstep, int B, int N, float gamma,
-    float gamma_n, float tau_value, float scale) {
-    wave_per_sample(B, partials, [&](int b, int lane) -> float {
+    float gamma_n, float tau_value, float scale, const ScanFold fold) {
+    wave_per_sample(B, partials, fold, [&](int b, int lane) -> float {
         float R = 0.f, f = 1.f;
         for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
         const float vg = (value_gamma ? value_gamma[b] : gamma_n) * (1.f - done[b]);
@@ -197,7 +199,7 @@ template <int G> __device__ __forceinline__ float group_sum(float x) {
 }
 // 4 waves x 64/G samples per workgroup; workgroup partial = the per-sample contributions added in sample order.
 template <int G, class F>
-__device__ __forceinline__ void group_per_sample(int B, float* __restrict__ partials, F&& body) {
+__device__ __forceinline__ void group_per_sample(int B, float* __restrict__ partials, const ScanFold& fold, F&& body) {
     constexpr int SPW = 64 / G;
     __shared__ float red[4 * SPW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gl = lane % G, gs = lane / G;
@@ -205,12 +207,12 @@ __device__ __forceinline__ void group_per_sample(int B, float* __restrict__ part
     const float contrib = body(b, b < (long)B, gl, gs * G);   // every lane runs the body (it shuffles): loads are guarded
     if (gl == 0) red[w * SPW + gs] = b < (long)B ? contrib : 0.f;
     __syncthreads();
+    float s = 0.f;
     if (threadIdx.x == 0) {
-        float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 4 * SPW; ++i) s += red[i];
-        partials[blockIdx.x] = s;
     }
+    publish_sums<1, 256>(s, partials, fold);
 }
 
 __global__ __launch_bounds__(256) void dist_nstep_fwd64_kernel(
@@ -218,8 +220,8 @@ __global__ __launch_bounds__(256) void dist_nstep_fwd64_kernel(
     const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
     const float* __restrict__ weight, float* __restrict__ td_err, float* __restrict__ buf,
     float* __restrict__ partials, int nstep, int B, int N, int n_atom, float gamma, float gamma_n, float v_min,
-    float v_max, float dz, float scale) {
-    wave_per_sample(B, partials, [&](int b, int lane) -> float {
+    float v_max, float dz, float scale, const ScanFold fold) {
+    wave_per_sample(B, partials, fold, [&](int b, int lane) -> float {
         float R = 0.f, f = 1.f;
         for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
         const float nd_scale = (1.f - done[b]) * gamma_n;
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(256) void iqn_fwd_group_kernel(
     const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
     const float* __restrict__ rq, const float* __restrict__ weight, const float* __restrict__ value_gamma,
     float* __restrict__ td_err, float* __restrict__ buf, float* __restrict__ partials, int tau, int tau_p,
-    int nstep, int B, int N, float gamma, float gamma_n, float kappa, float scale) {
-    group_per_sample<G>(B, partials, [&](long b, bool ok, int gl, int base) -> float {
+    int nstep, int B, int N, float gamma, float gamma_n, float kappa, float scale, const ScanFold fold) {
+    group_per_sample<G>(B, partials, fold, [&](long b, bool ok, int gl, int base) -> float {
         float R = 0.f, f = 1.f, vg = 0.f, w = 0.f, qi = 0.f, rho = 0.f, tgt = 0.f;
         if (ok) {
             for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
@@ -339,8 +341,8 @@ __global__ __launch_bounds__(256) void qrdqn_fwd_group_kernel(
     const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
     const float* __restrict__ weight, const float* __restrict__ value_gamma, float* __restrict__ td_err,
     float* __restrict__ buf, float* __restrict__ partials, int tau, int nstep, int B, int N, float gamma,
-    float gamma_n, float tau_value, float scale) {
-    group_per_sample<G>(B, partials, [&](long b, bool ok, int gl, int base) -> float {
+    float gamma_n, float tau_value, float scale, const ScanFold fold) {
+    group_per_sample<G>(B, partials, fold, [&](long b, bool ok, int gl, int base) -> float {
         float R = 0.f, f = 1.f, w = 0.f, qi = 0.f, tgt = 0.f;
         if (ok) {
             for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
@@ -390,16 +392,18 @@ extern "C" int hpc_rll_dist_nstep_td_forward(const float* dist, const float* nex
     const int blocks = (B + 3) / 4;
     // delta_z is a python double in the oracle, rounded to fp32 when it meets the fp32 tensor
     const float dz = (float)(((double)v_max - (double)v_min) / (double)(n_atom - 1));
+    const ScanFold fold = make_fold(st, 1, &scale, loss);
+    const float gamma_n = (float)pow((double)gamma, (double)nstep);
     if (n_atom <= 64)
         hipLaunchKernelGGL(dist_nstep_fwd64_kernel, dim3(blocks), dim3(256), 0, st, dist, next_n_dist, action,
-                           next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma,
-                           (float)pow((double)gamma, (double)nstep), v_min, v_max, dz, scale);
+                           next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma, gamma_n,
+                           v_min, v_max, dz, scale, fold);
     else
-    hipLaunchKernelGGL(dist_nstep_fwd_kernel, dim3(blocks), dim3(256), 0, st, dist, next_n_dist, action,
-                       next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma,
-                       (float)pow((double)gamma, (double)nstep), v_min, v_max, dz, scale);
-    int rc = last_error();
-    if (rc) return rc;
+        hipLaunchKernelGGL(dist_nstep_fwd_kernel, dim3(blocks), dim3(256), 0, st, dist, next_n_dist, action,
+                           next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma, gamma_n,
+                           v_min, v_max, dz, scale, fold);
+    const int rc = last_error();
+    if (rc || fold.out) return rc;
     return finalize_sums(partials, blocks, 1, &scale, loss, st);
 }
 
@@ -426,6 +430,7 @@ extern "C" int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_
     int blocks = (B + 3) / 4;
     const float gamma_n = (float)pow((double)gamma, (double)nstep);
     const int gmax = tau > tau_prime ? tau : tau_prime;
+    const ScanFold fold = make_fold(st, 1, &scale, loss);
     if (gmax <= 64) {
         const int G = group_lanes(gmax);
         blocks = (B + 4 * (64 / G) - 1) / (4 * (64 / G));
@@ -433,15 +438,16 @@ extern "C" int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_
         if (G == G_)                                                                                                    \
             hipLaunchKernelGGL(iqn_fwd_group_kernel<G_>, dim3(blocks), dim3(256), 0, st, q, next_n_q, action,            \
                                next_n_action, reward, done, replay_quantiles, weight, value_gamma, td_err, buf, partials, \
-                               tau, tau_prime, nstep, B, N, gamma, gamma_n, kappa, scale);
+                               tau, tau_prime, nstep, B, N, gamma, gamma_n, kappa, scale, fold);
         HPC_RLL_IQN_G(8) HPC_RLL_IQN_G(16) HPC_RLL_IQN_G(32) HPC_RLL_IQN_G(64)
 #undef HPC_RLL_IQN_G
-    } else
-    hipLaunchKernelGGL(iqn_fwd_kernel, dim3(blocks), dim3(256), 0, st, q, next_n_q, action, next_n_action, reward,
-                       done, replay_quantiles, weight, value_gamma, td_err, buf, partials, tau, tau_prime, nstep, B, N,
-                       gamma, gamma_n, kappa, scale);
-    int rc = last_error();
-    if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(iqn_fwd_kernel, dim3(blocks), dim3(256), 0, st, q, next_n_q, action, next_n_action, reward,
+                           done, replay_quantiles, weight, value_gamma, td_err, buf, partials, tau, tau_prime, nstep, B,
+                           N, gamma, gamma_n, kappa, scale, fold);
+    }
+    const int rc = last_error();
+    if (rc || fold.out) return rc;
     return finalize_sums(partials, blocks, 1, &scale, loss, st);
 }
 
@@ -472,6 +478,7 @@ extern "C" int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_
         return HPC_RLL_EINVAL;
     int blocks = (B + 3) / 4;
     const float gamma_n = (float)pow((double)gamma, (double)nstep);
+    const ScanFold fold = make_fold(st, 1, &scale, loss);
     if (tau <= 64) {
         const int G = group_lanes(tau);
         blocks = (B + 4 * (64 / G) - 1) / (4 * (64 / G));
@@ -479,15 +486,16 @@ extern "C" int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_
         if (G == G_)                                                                                                  \
             hipLaunchKernelGGL(qrdqn_fwd_group_kernel<G_>, dim3(blocks), dim3(256), 0, st, q, next_n_q, action,        \
                                next_n_action, reward, done, weight, value_gamma, td_err, buf, partials, tau, nstep, B, N, \
-                               gamma, gamma_n, tau_value, scale);
+                               gamma, gamma_n, tau_value, scale, fold);
         HPC_RLL_QR_G(8) HPC_RLL_QR_G(16) HPC_RLL_QR_G(32) HPC_RLL_QR_G(64)
 #undef HPC_RLL_QR_G
-    } else
-    hipLaunchKernelGGL(qrdqn_fwd_kernel, dim3(blocks), dim3(256), 0, st, q, next_n_q, action, next_n_action, reward,
-                       done, weight, value_gamma, td_err, buf, partials, tau, nstep, B, N, gamma,
-                       gamma_n, tau_value, scale);
-    int rc = last_error();
-    if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(qrdqn_fwd_kernel, dim3(blocks), dim3(256), 0, st, q, next_n_q, action, next_n_action, reward,
+                           done, weight, value_gamma, td_err, buf, partials, tau, nstep, B, N, gamma, gamma_n, tau_value,
+                           scale, fold);
+    }
+    const int rc = last_error();
+    if (rc || fold.out) return rc;
     return finalize_sums(partials, blocks, 1, &scale, loss, st);
 }
 

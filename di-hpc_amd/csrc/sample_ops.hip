@@ -29,7 +29,8 @@ inline int last_error() {
 
 // Generic "one lane per sample + NACC sums" kernel.  grid = ceil(n/256) workgroups (<= partial capacity).
 template <class Op>
-__global__ __launch_bounds__(256) void sample_kernel(const Op op, long n, float* __restrict__ partials) {
+__global__ __launch_bounds__(256) void sample_kernel(const Op op, long n, float* __restrict__ partials,
+                                                     const ScanFold fold) {
     constexpr int NACC = Op::NACC;
     __shared__ float red[NACC * 4];
     float acc[NACC];
@@ -44,9 +45,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const Op op, long n, float*
         if (lane == 0) red[k * 4 + w] = s;
     }
     __syncthreads();
+    float sum = 0.f;
     if (threadIdx.x < NACC)
-        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
-            (red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1]) + (red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
+        sum = (red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1]) + (red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
+    publish_sums<NACC, 256>(sum, partials, fold);   // with a fold: the last workgroup also finalises the sums (colscan.hpp)
 }
 
 // ---------------------------------------------------------------------------------------------- PPO
@@ -226,11 +228,12 @@ extern "C" int hpc_rll_ppo_forward(const float* logits_new, const float* logits_
     PpoOp op{lpn, ent, lpo, value_new, value_old, adv, ret, weight, coef_logp, coef_ent, gv_unit,
              clip_ratio, dual_clip, scale, use_value_clip};
     const int blocks = (B + 255) / 256;
-    hipLaunchKernelGGL(sample_kernel<PpoOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials);
-    rc = last_error();
-    if (rc) return rc;
     // approx_kl and clipfrac are plain (unweighted) means over the LOCAL batch: scale by 1/B
     const float sc[5] = {scale, 0.5f * scale, scale, 1.f / (float)B, 1.f / (float)B};
+    const ScanFold fold = make_fold(st, 5, sc, out5);
+    hipLaunchKernelGGL(sample_kernel<PpoOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials, fold);
+    rc = last_error();
+    if (rc || fold.out) return rc;
     return finalize_sums(partials, blocks, 5, sc, out5, st);
 }
 
@@ -269,9 +272,10 @@ extern "C" int hpc_rll_q_nstep_td_forward(const float* q, const float* next_n_q,
     QNStepOp op{q, next_n_q, action, next_n_action, reward, done, weight, td_err, grad_buf,
                 nstep, B, N, gamma, (float)pow((double)gamma, (double)nstep), scale, rescale};
     const int blocks = (B + 255) / 256;
-    hipLaunchKernelGGL(sample_kernel<QNStepOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials);
-    int rc = last_error();
-    if (rc) return rc;
+    const ScanFold fold = make_fold(st, 1, &scale, loss);
+    hipLaunchKernelGGL(sample_kernel<QNStepOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials, fold);
+    const int rc = last_error();
+    if (rc || fold.out) return rc;
     return finalize_sums(partials, blocks, 1, &scale, loss, st);
 }
 

@@ -82,11 +82,7 @@ inline unsigned* scan_ticket(hipStream_t st) {
 template <class Op, bool ALLOW_V2>
 inline int scan_and_finalize(const Op& op, const ScanCfg& c, int T, int B, float* partials, int nacc, const float* scale,
                              float* out, hipStream_t st) {
-    ScanFold fold{nullptr, scan_ticket(st), {0.f, 0.f, 0.f, 0.f}};
-    if (fold.ticket && nacc <= 4) {
-        fold.out = out;
-        for (int k = 0; k < nacc; ++k) fold.scale[k] = scale[k];
-    }
+    const ScanFold fold = make_fold(st, nacc, scale, out);
     launch_colscan<Op, ALLOW_V2>(op, c, T, B, partials, st, fold);
     const int rc = last_error();
     if (rc || fold.out) return rc;
@@ -272,6 +268,17 @@ struct UpgoOp {
 };
 
 }  // namespace
+
+ScanFold make_fold(hipStream_t st, int nacc, const float* scale, float* out) {
+    ScanFold fold{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    if (nacc < 1 || nacc > 8) return fold;
+    fold.ticket = scan_ticket(st);
+    if (!fold.ticket) return fold;
+    fold.out = out;
+    for (int k = 0; k < nacc; ++k) fold.scale[k] = scale[k];
+    return fold;
+}
+
 }  // namespace hpc_rll
 
 using namespace hpc_rll;

@@ -114,8 +114,8 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * UPGO) aims for when it picks its waves per workgroup (256..16384, default 4096).  key 20: workgroups of the large-batch
  * LSTM backward cell (768 <= H <= 1024) that walks >= 8 batch rows per workgroup and keeps the bias / gamma / beta column sums (64..1024,
  * default 512 = two per CU; 0 = always one row per workgroup + a separate column-reduction pass).  key 21: 1 (default) =
- * the column scans (TD-lambda, V-trace, UPGO) finalise their loss sums in the last workgroup of the scan launch; 0 = a
- * separate finalize launch (identical results: the same fixed-order fp64 sum of the same partials).
+ * every scalar-loss forward (TD-lambda, V-trace, UPGO, PPO, q / dist / IQN / QR-DQN n-step TD) finalises its loss sums in
+ * the last workgroup of its last launch; 0 = a separate finalize launch (the same partials, summed in fp64 either way).
  */
 int hpc_rll_tune_set(int key, int value);
 

@@ -402,14 +402,14 @@ def test_losses_are_deterministic():
 
 
 def test_folded_finalisation_under_concurrency():
-    """The column scans leave their loss sums to the LAST workgroup of the scan launch (csrc/colscan.hpp: ScanFold, an
-    arrival ticket per stream, relaxed agent-scope atomics, no release fence).  Stress it where it could fail: many
+    """Every scalar-loss forward leaves its loss sums to the LAST workgroup of its last launch (csrc/colscan.hpp:
+    publish_sums / ScanFold, an arrival ticket per stream, relaxed agent-scope atomics, no release fence).  Stress it where it could fail: many
     workgroups (B = 8192 columns -> 128+ partials spread over all XCDs), four streams launching concurrently with
     different data, hundreds of back-to-back launches per stream -- every loss must equal the one the separate
     finalize launch (tune key 21 = 0) computes from the same partials, and the ticket must be back at zero (the next
     launch on the stream works)."""
     import hpc_rl_utils as U
-    from hpc_rll.rl_utils.td import TDLambda
+    from hpc_rll.rl_utils.td import QRDQNNStepTDError, TDLambda
     from hpc_rll.rl_utils.vtrace import VTrace
     T, B, N = 24, 8192, 4
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -417,11 +417,18 @@ def test_folded_finalisation_under_concurrency():
     data = [(torch.randn(T + 1, B, device=DEV, generator=g), torch.randn(T, B, device=DEV, generator=g),
              torch.randn(T, B, N, device=DEV, generator=g), torch.randn(T, B, N, device=DEV, generator=g),
              torch.randint(0, N, (T, B), device=DEV, generator=g)) for _ in range(nstream)]
-    td, vt = TDLambda(T, B), VTrace(T, B, N)
+    td, vt, qr = TDLambda(T, B), VTrace(T, B, N), QRDQNNStepTDError(N, 3, B, T)
+    done = torch.zeros(B, device=DEV)
+
+    def losses(v, r, to, bo, a):
+        # (the QR-DQN call reads `to` (T,B,N) as q (B', N', tau) = (T, B, N): any dense fp32 block will do here)
+        q = to.transpose(0, 1).contiguous()           # (B, T, N): B samples, T actions, N quantiles
+        return torch.stack([td(v, r), *vt(to, bo, a, v, r),
+                            qr(q, q.flip(0), a[0] % T, a[1] % T, r[:3].contiguous(), done, 0.9)[0]])
     try:
         U.tune_set(21, 0)
         with torch.no_grad():
-            want = [torch.stack([td(v, r), *vt(to, bo, a, v, r)]).cpu() for v, r, to, bo, a in data]
+            want = [losses(*d).cpu() for d in data]
         U.tune_set(21, 1)
         streams = [torch.cuda.Stream() for _ in range(nstream)]
         got = [[] for _ in range(nstream)]
@@ -429,9 +436,8 @@ def test_folded_finalisation_under_concurrency():
         with torch.no_grad():
             for _ in range(reps):
                 for i, s in enumerate(streams):
-                    v, r, to, bo, a = data[i]
                     with torch.cuda.stream(s):
-                        got[i].append(torch.stack([td(v, r), *vt(to, bo, a, v, r)]))
+                        got[i].append(losses(*data[i]))
         torch.cuda.synchronize()
     finally:
         U.tune_set(21, 1)
