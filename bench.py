@@ -22,7 +22,9 @@ Rank 0 prints ONE JSON line.  Extra objects:
   roofline     -- dominant kernel's algorithmic bytes per launch / its average launch duration measured
                   live with HIP events on the launch stream, vs the 8 TB/s HBM3E peak.
   cpu_baseline -- oracle/gae_ref.c (a port of the reference algorithm, OpenMP) timed on this host, on a
-                  bounded sample of the same workload.  A reported baseline, not the target.
+                  bounded sample of the same workload.  A reported baseline, not the target.  Its key
+                  `pytorch_restatement` is the same algorithm run the way hpc_rll.origin runs it (oracle/ref_torch.py:
+                  a python loop of fp32 torch CPU ops + autograd backward), on a smaller bounded sample.
 """
 import argparse
 import ctypes
@@ -70,9 +72,38 @@ def cpu_baseline(T, B, gamma, lam, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or reps >= 200:
             break
-    return {"value": T * Bs * reps / dt, "unit": "samples/s", "cores": int(lib.gae_ref_num_threads()),
-            "kind": "port", "sample": f"T={T} B={Bs} (1/{B // Bs} of the batch axis) x {reps} fwd+bwd passes, "
-                                      f"oracle/gae_ref.c OpenMP, {dt:.1f}s"}
+    res = {"value": T * Bs * reps / dt, "unit": "samples/s", "cores": int(lib.gae_ref_num_threads()),
+           "kind": "port", "sample": f"T={T} B={Bs} (1/{B // Bs} of the batch axis) x {reps} fwd+bwd passes, "
+                                     f"oracle/gae_ref.c OpenMP, {dt:.1f}s"}
+    # The same algorithm the way hpc_rll.origin runs it (north_star: "next to hpc_rll.origin timed on the same box's host
+    # CPU"): the pure-PyTorch restatement oracle/ref_torch.gae (origin/gae.py:28-37, a python loop over T of fp32 tensor
+    # ops) forward + autograd backward, on a smaller bounded sample.  Reported beside the (faster) C port, never the target.
+    try:
+        sys.path.insert(0, ROOT)
+        from oracle import ref_torch
+        Bt = min(B, 4096)
+        vt = torch.randn(T + 1, Bt, generator=g, requires_grad=True)
+        rt = torch.randn(T, Bt, generator=g, requires_grad=True)
+        gt = torch.randn(T, Bt, generator=g)
+
+        def one_torch():
+            vt.grad = rt.grad = None
+            ref_torch.gae(vt, rt, gamma, lam).backward(gt)
+
+        one_torch()
+        reps_t, t0 = 0, time.perf_counter()
+        while True:
+            one_torch()
+            reps_t += 1
+            dt_t = time.perf_counter() - t0
+            if dt_t > 6.0 or reps_t >= 50:
+                break
+        res["pytorch_restatement"] = {"value": T * Bt * reps_t / dt_t, "unit": "samples/s", "cores": torch.get_num_threads(),
+                                      "sample": f"T={T} B={Bt} x {reps_t} fwd + autograd bwd passes, oracle/ref_torch.py "
+                                                f"(torch {torch.__version__} CPU, fp32), {dt_t:.1f}s"}
+    except Exception as e:  # the reported baseline above does not depend on this extra reading
+        res["pytorch_restatement"] = {"error": repr(e)}
+    return res
 
 
 def main():
