@@ -225,10 +225,11 @@ inline ScanCfg scan_cfg(int T, int B, bool can_v2) {
     c.nw = 4;
     while (c.nw < 16 && wgs * c.nw < g_scan_wave_target) c.nw <<= 1;
     while (c.nw > 1 && c.nw > chunks) c.nw >>= 1;
-    // narrow batches: sub-wave tiles while the grid is below one workgroup per CU and barriers remain to be saved
+    // narrow batches: sub-wave tiles (2, 4 or 8 groups per wave) while the grid is below one workgroup per CU and barriers
+    // remain to be saved
     c.sub = 1;
     if (c.v == 1 && c.nw == 16)
-        while (c.sub < 4 && (long)wgs * c.sub < 256 && chunks >= 2 * c.nw * c.sub) c.sub <<= 1;
+        while (c.sub < 8 && (long)wgs * c.sub < 256 && chunks >= 2 * c.nw * c.sub) c.sub <<= 1;
     return c;
 }
 inline unsigned scan_grid(const ScanCfg& c, int B) {
@@ -246,6 +247,10 @@ inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* 
     }
     if (c.sub == 4 && c.v == 1 && c.nw == 16) {
         hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 4>), dim3(grid), dim3(1024), 0, st, op, T, B, partials, fold);
+        return;
+    }
+    if (c.sub == 8 && c.v == 1 && c.nw == 16) {   // 8-column tiles: 128 virtual waves = 1024 steps per barrier
+        hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 8>), dim3(grid), dim3(1024), 0, st, op, T, B, partials, fold);
         return;
     }
 #define HPC_RLL_SCAN_CASE(V_, NW_)                                                                          \

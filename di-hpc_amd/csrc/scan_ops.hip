@@ -310,7 +310,7 @@ extern "C" int hpc_rll_td_lambda_backward(const float* grad_loss, const float* g
 // ------------------------------------------------------------------------------------------------ V-trace
 // ws layout (floats): [coef_pg TB | coef_ent TB | gv_unit TB | logp_t TB | ent TB | logp_b TB | partials]
 extern "C" int64_t hpc_rll_vtrace_workspace_floats(int T, int B) {
-    return 6 * (int64_t)T * B + 8 * (((int64_t)B + 31) / 32 + 1);   // partials: 3 sums x up to ceil(B/16) workgroups
+    return 6 * (int64_t)T * B + 8 * (((int64_t)B + 15) / 16 + 1);   // partials: 3 sums x up to ceil(B/8) workgroups
 }
 
 extern "C" int hpc_rll_vtrace_forward(const float* target_output, const float* behaviour_output,

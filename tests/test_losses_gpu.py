@@ -56,7 +56,8 @@ def test_td_lambda_golden(golden):
 
 # (1024,64), (2000,17), (513,300), (300,1000): sub-wave tiles of colscan.hpp (4 / 4 / 2 / 2 time chunks per wave)
 @pytest.mark.parametrize("T,B,wmode", [(1024, 64, 2), (256, 16384, 2), (37, 4100, 1), (5, 70000, 0), (1, 1, 2), (100, 3, 1),
-                                       (2000, 17, 1), (513, 300, 0), (300, 1000, 2)])
+                                       (2000, 17, 1), (513, 300, 0), (300, 1000, 2),
+                                       (1100, 96, 2), (2048, 8, 1), (1024, 100, 0)])   # 8 time chunks per wave (8-column tiles)
 def test_td_lambda_oracle(T, B, wmode):
     from hpc_rll.rl_utils.td import TDLambda
     rng = np.random.default_rng(T + B)
@@ -91,7 +92,8 @@ def test_vtrace_golden(golden):
 @pytest.mark.parametrize("T,B,N", [(128, 128, 128), (64, 300, 6), (16, 70, 1000), (9, 33, 2500), (256, 1024, 18), (3, 5, 1),
                                    (5, 7, 9), (40, 100, 4), (3, 11, 5001), (2, 3, 20000), (31, 50, 30), (7, 9, 2),
                                    (3, 7, 8192), (2, 5, 16384), (2, 9, 4100), (3, 4, 12000), (5, 3, 2052),
-                                   (1024, 48, 5), (700, 200, 7), (300, 1030, 4)])          # sub-wave scan tiles
+                                   (1024, 48, 5), (700, 200, 7), (300, 1030, 4),           # sub-wave scan tiles
+                                   (1024, 96, 5), (1500, 8, 3)])                           # ... 8-column tiles
 def test_vtrace_oracle(T, B, N):
     from hpc_rll.rl_utils.vtrace import VTrace
     rng = np.random.default_rng(T * 7 + N)
@@ -173,7 +175,8 @@ def test_upgo_golden(golden):
 
 
 @pytest.mark.parametrize("T,B,N", [(256, 256, 256), (100, 70, 5), (2, 5000, 12), (1, 3, 4),
-                                   (1024, 48, 5), (700, 200, 7), (300, 1030, 4)])          # sub-wave scan tiles
+                                   (1024, 48, 5), (700, 200, 7), (300, 1030, 4),           # sub-wave scan tiles
+                                   (1024, 96, 5), (1500, 8, 3)])                           # ... 8-column tiles
 def test_upgo_oracle(T, B, N):
     from hpc_rll.rl_utils.upgo import UPGO
     rng = np.random.default_rng(T * 3 + N)
