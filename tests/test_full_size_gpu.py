@@ -216,3 +216,50 @@ def test_c5_pad_round_trip_one_million_elements():
     new_x, mask, shapes = P.Padding1D(xs)
     assert new_x.shape == (n, int(lens.max())) and int(mask.sum()) == int(lens.sum())
     assert torch.equal(torch.cat(P.UnPadding1D(new_x, shapes)), flat)
+
+
+def test_td_family_large_batch_equals_its_slices():
+    """Size-independent property of the per-sample ops at a batch where the large-batch kernels run (B = 2^17: group-per-
+    sample IQN / QR-DQN, one-pass C51, 16-byte one-hot gradients with 64-bit offsets): the per-sample TD error of sample b
+    does not depend on what else is in the batch, and the mean-reduced loss scales its gradient by 1/B -- so a slice of
+    1024 samples computed ALONE must reproduce td_err bit for bit and the gradient rows times 2^7 (an exact scaling)."""
+    from hpc_rll.rl_utils.td import DistNStepTD, IQNNStepTDError, QNStepTD, QRDQNNStepTDError
+    B, N, nstep, n_atom, tau, SL = 1 << 17, 64, 5, 51, 32, 1024
+    g = torch.Generator(device=DEV).manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    a, na = (torch.randint(0, N, (B,), device=DEV, generator=g) for _ in range(2))
+    rew, done, w = rnd(nstep, B), (torch.rand(B, device=DEV, generator=g) < 0.1).float(), torch.rand(B, device=DEV, generator=g)
+    starts = [0, 37 * 1024, B - SL]
+
+    def check(make_inputs, run, batch_dim):
+        full_in = make_inputs()
+        leaf = full_in[0].requires_grad_(True)
+        loss, per = run(B, leaf, *full_in[1:], a, na, rew, done, w)
+        loss.backward()
+        for s0 in starts:
+            sl = slice(s0, s0 + SL)
+            cut = lambda t: t.detach().narrow(batch_dim, s0, SL).contiguous()  # noqa: E731
+            sub = cut(leaf).requires_grad_(True)
+            l2, p2 = run(SL, sub, *[cut(t) for t in full_in[1:]], a[sl].contiguous(), na[sl].contiguous(),
+                         rew[:, sl].contiguous(), done[sl].contiguous(), w[sl].contiguous())
+            l2.backward()
+            assert torch.equal(per[sl], p2), (run.__name__, s0)
+            assert torch.equal(leaf.grad.narrow(batch_dim, s0, SL) * float(B // SL), sub.grad), (run.__name__, s0)
+            assert float(sub.grad.abs().max()) > 0
+        del leaf
+
+    def q_td(Bk, q, nq, a_, na_, r_, d_, w_):
+        return QNStepTD(nstep, Bk, N)(q, nq, a_, na_, r_, d_, w_, 0.99)
+    check(lambda: [rnd(B, N), rnd(B, N)], q_td, 0)
+
+    def c51(Bk, d, nd, a_, na_, r_, d_, w_):
+        return DistNStepTD(nstep, Bk, N, n_atom)(d, nd, a_, na_, r_, d_, w_, 0.99, -10.0, 10.0)
+    check(lambda: [torch.softmax(rnd(B, N, n_atom), -1), torch.softmax(rnd(B, N, n_atom), -1)], c51, 0)
+
+    def qr(Bk, q, nq, a_, na_, r_, d_, w_):
+        return QRDQNNStepTDError(tau, nstep, Bk, N)(q, nq, a_, na_, r_, d_, 0.99, w_)
+    check(lambda: [rnd(B, N, tau), rnd(B, N, tau)], qr, 0)
+
+    def iqn(Bk, q, nq, rq, a_, na_, r_, d_, w_):
+        return IQNNStepTDError(tau, tau, nstep, Bk, N)(q, nq, a_, na_, r_, d_, rq, 0.99, 1.0, w_)
+    check(lambda: [rnd(tau, B, N), rnd(tau, B, N), torch.rand(tau, B, device=DEV, generator=g)], iqn, 1)
