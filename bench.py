@@ -1,30 +1,44 @@
 #!/usr/bin/env python3
-"""Headline benchmark: GAE forward+backward samples/s at T=1024, B=65536 fp32 per GPU (BASELINE.json).
+"""Headline benchmark: GAE forward+backward samples/s at T=1024, B=65536 fp32 (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W            # N=1 direct; N>1 under torch.distributed.run
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input: ``adv = GAE(value, reward)``
-followed by ``adv.backward(grad_adv)`` through the drop-in ``hpc_rll.rl_utils.gae.GAE`` module (HIP
-kernels behind the C ABI).  Inputs are resident in HBM before the timed region.  The batch axis shards
-across ranks with NO data-path collective (every trajectory is independent), so per-GPU
-work is fixed as N grows: weak scaling; ``value`` = (N * T * B) * K / max-over-ranks wall time.
-``--scaling strong`` makes the headline ``value`` the strong reading instead (``--B`` is then the GLOBAL batch, split
-over the ranks) and ``--graph`` replays the step from a captured hipGraph -- the launch-latency regime strong scaling
-ends up in.
+N = 1 runs in this process.  N > 1: if the process was not started by a launcher (no RANK in the environment) it starts
+its own ranks -- it re-executes itself under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1`` -- so a plain ``python bench.py --gpus 8`` works; under ``torch.distributed.run`` it uses the
+ranks it was given.  One rank per GPU over RCCL.
 
-Whatever the headline is, the same JSON line carries ``scaling_detail`` with BOTH readings BASELINE.md section 4 /
-SURVEY.md 8d ask for, measured in this run after the headline region: weak (B per GPU) and strong (global B = 65536
-split over the N ranks), each eager and as hipGraph replay, with per-rank step times and the RCCL world size seen.
-With one rank it also times the per-rank shapes an N = 2, 4, 8 strong-scaling run would hold (B = 32768, 16384, 8192),
-so the launch-latency regime is visible without a multi-GPU box.
+A "step" is one pass of the hot path over one batch of synthetic input: ``adv = GAE(value, reward)`` followed by the
+backward pass for both gradients, through the drop-in ``hpc_rll.rl_utils.gae.GAE`` module (HIP kernels behind the C
+ABI).  Inputs are resident in HBM before the timed region.  Every trajectory (column) is independent:
+the batch axis shards across ranks with NO data-path collective.
+
+What the headline ``value`` is (BASELINE.json metric: "T=1024, B=64k; 1/2/4/8 GPUs"):
+  * N = 1: B = 65536 on the one GPU, eager launches (``module(...)`` + ``.backward()``).
+  * N > 1: STRONG scaling -- the same GLOBAL batch of 65536 trajectories split over the N ranks (B = 65536/N per GPU),
+    ``"scaling": "strong"``.  A rank then holds a step of a few tens of microseconds, the launch-latency regime, so the
+    step is launched the way the library ships for that regime: ``hpc_rll.graphed`` (forward + backward captured once
+    into a hipGraph, one hipGraphLaunch per step; same kernels, same order, same results), stated in
+    ``config.launch``.  ``--scaling weak`` / ``--launch eager`` select the other readings as the headline.
+Whatever the headline is, the same JSON line carries ``scaling_detail`` with BOTH readings, measured in this run after
+the headline region: weak (B = 65536 per GPU) and strong (global B = 65536 split over the N ranks), each eager and as
+hipGraph replay, with every rank's step time and the RCCL world size seen.  With one rank it also times the per-rank
+shapes an N = 2, 4, 8 strong-scaling run would hold (B = 32768, 16384, 8192).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     -- dominant kernel's algorithmic bytes per launch / its average launch duration measured
-                  live with HIP events on the launch stream, vs the 8 TB/s HBM3E peak.
+  roofline     -- dominant kernel's algorithmic bytes per launch / its average launch duration measured live: the
+                  dispatch's own begin/end timestamps (HIP events attached to the launch through hipExtLaunchKernelGGL
+                  on the launch stream = what rocprofv3 --kernel-trace reports) over >= 100 alternating fwd/bwd launches
+                  right after the timed region; the hipEventRecord-bracketed figures (they include the gaps between
+                  launches) are listed beside them, with the shader clock sampled during the pass.
   cpu_baseline -- oracle/gae_ref.c (a port of the reference algorithm, OpenMP) timed on this host, on a
                   bounded sample of the same workload.  A reported baseline, not the target.  Its key
                   `pytorch_restatement` is the same algorithm run the way hpc_rll.origin runs it (oracle/ref_torch.py:
                   a python loop of fp32 torch CPU ops + autograd backward), on a smaller bounded sample.
+  suite        -- (N = 1) BASELINE.json configs[2..4] through the same drop-in modules: V-trace / UPGO / TD-lambda at
+                  T=256,B=16384,N=128; LSTM S=128,B=4096,H=1024; ScatterConnection (cover, add) B=4096,M=256,N=64,64x64
+                  and the packed Pad1D over 2^20 ragged rows: forward / backward ms and roofline fraction each
+                  (tests/tools/bench_suite.py holds the byte / flop models).
 """
 import argparse
 import ctypes
@@ -106,26 +120,96 @@ def cpu_baseline(T, B, gamma, lam, budget_s=12.0):
     return res
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this file on this node and hand over."""
+    import socket
+    one_device = os.environ.get("HPC_RLL_BENCH_ONE_DEVICE") == "1"
+    if not one_device and torch.cuda.device_count() < args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: this node shows {torch.cuda.device_count()} GPU(s)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+class SclkSampler:
+    """Shader clock during a measurement: the active level of the GPU's pp_dpm_sclk sysfs table, polled from a thread
+    (the DVFS state is what makes a profiled and an un-profiled run differ; MI355X_MICROARCH.md)."""
+
+    def __init__(self, index):
+        import glob
+        self.path, self.samples, self._stop, self._th = None, [], False, None
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if cands:
+            self.path = cands[min(index, len(cands) - 1)]
+
+    def _read(self):
+        try:
+            for ln in open(self.path).read().splitlines():
+                if ln.rstrip().endswith("*"):
+                    return float(ln.split(":")[1].strip().split("M")[0])
+        except Exception:
+            return None
+        return None
+
+    def __enter__(self):
+        if self.path is None:
+            return self
+        import threading
+
+        def run():
+            while not self._stop:
+                v = self._read()
+                if v is not None:
+                    self.samples.append(v)
+                time.sleep(0.002)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th is not None:
+            self._th.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        xs = sorted(self.samples)
+        return {"median": xs[len(xs) // 2], "min": xs[0], "max": xs[-1], "samples": len(xs), "source": self.path}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--T", type=int, default=T_DEFAULT)
-    ap.add_argument("--B", type=int, default=B_DEFAULT, help="batch per GPU")
+    ap.add_argument("--B", type=int, default=B_DEFAULT,
+                    help="weak scaling: batch per GPU; strong scaling: the GLOBAL batch, split over the ranks")
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default): B per GPU fixed; strong: --B is the GLOBAL batch, split over the ranks")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                    help="headline reading; auto = strong for N > 1 (global B fixed, SURVEY.md 8d), N = 1 is both")
+    ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
+                    help="headline launch mode; auto = eager for N = 1, hpc_rll.graphed (hipGraph replay) for N > 1")
+    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--no-scaling-detail", action="store_true", help="skip the extra weak/strong legs (profiler runs)")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture one fwd+bwd step in a hipGraph and replay it (the latency regime: small B per GPU)")
+    ap.add_argument("--no-suite", action="store_true", help="skip the configs[2..4] suite (N = 1 only)")
     args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hpc_rll product path has no CPU fallback")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)      # does not return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the hpc_rll product path has no CPU fallback")
     # TEST HOOKS (tests/test_dist.py runs this file with 2 ranks on a ONE-GPU box, where RCCL refuses two ranks per
     # device): HPC_RLL_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, HPC_RLL_BENCH_BACKEND=gloo swaps the backend.  The
     # driver's runs set neither: one rank per GPU over RCCL.
@@ -142,14 +226,20 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import hpc_rl_utils as U
+    import hpc_rll
     from hpc_rll.rl_utils.gae import GAE
+    lib = ctypes.CDLL(os.path.join(ROOT, "di-hpc_amd", "hpc_rll", "_lib", "libhpc_rll_hip.so"))   # already loaded: diagnostics
 
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    launch = "graph" if args.graph else args.launch
+    if launch == "auto":
+        launch = "graph" if (world > 1 and scaling == "strong") else "eager"
     T, B, gamma, lam = args.T, args.B, 0.99, 0.97
-    global_B = B if args.scaling == "strong" else B * world
-    if args.scaling == "strong":
+    global_B = B if scaling == "strong" else B * world
+    if scaling == "strong":
         assert B % world == 0, "strong scaling: the global batch must divide by the number of ranks"
         B //= world
 
@@ -159,7 +249,7 @@ def main():
         torch.cuda.synchronize()
 
     def make_step(Bk, graph):
-        """(step callable, tensors) for one fwd+bwd pass at batch Bk on this rank; graph=True replays a hipGraph."""
+        """(step callable, tensors) for one fwd+bwd pass at batch Bk on this rank; graph=True: hpc_rll.graphed."""
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         value = torch.randn(T + 1, Bk, device=dev, generator=g).requires_grad_(True)
         reward = torch.randn(T, Bk, device=dev, generator=g).requires_grad_(True)
@@ -175,18 +265,8 @@ def main():
         if not graph:
             return step, (value, reward, grad_adv)
         # same kernels, same order; only the host-side launch path changes (one hipGraphLaunch per step)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        value.grad = None
-        reward.grad = None
-        cg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cg):
-            gae(value, reward, gamma, lam).backward(grad_adv)
-        return cg.replay, (value, reward, grad_adv, cg)
+        gs = hpc_rll.graphed(gae, value, reward, gamma, lam, grad_outputs=grad_adv)
+        return gs.replay, (value, reward, grad_adv, gs)
 
     def timed(step, steps, warmup):
         """W untimed steps, barrier + synchronize, EXACTLY `steps` timed steps, barrier + synchronize.
@@ -207,37 +287,56 @@ def main():
         per_rank = [x.item() for x in allt]
         return max(per_rank), per_rank
 
-    step, keep = make_step(B, args.graph)
+    step, keep = make_step(B, launch == "graph")
     value, reward, grad_adv = keep[:3]
     # device clock / allocator pre-roll: a freshly leased GPU idles at its low power state and the first ~10 ms of
     # work run at ramping clocks.  Untimed, not part of W or K (the W warmup steps and the K timed steps follow).
-    for _ in range(30):
+    for _ in range(max(30, int(30 * 65536 / max(B, 1)) if B < 65536 else 30)):
         step()
     elapsed, per_rank_s = timed(step, args.steps, args.warmup)
 
-    # ---- per-kernel durations, measured IMMEDIATELY after the timed region (same clocks / thermal state: on a power-
-    # capped part the step time drifts by ~5 % over the first seconds of streaming): HIP events on the launch stream
-    # (torch's current stream) around EVERY launch of a second, instrumented pass over the same K steps in the same
-    # alternating fwd/bwd order as the timed region (a kernel repeated back to back would find its inputs in the 256 MiB Infinity Cache and look
-    # faster than it is in the real sequence; rocprofv3 --kernel-trace of this command sees the same pattern).
+    # ---- per-kernel durations, measured IMMEDIATELY after the timed region (same clocks / thermal state), in the same
+    # alternating fwd/bwd order as the timed region (a kernel repeated back to back would find its inputs in the
+    # 256 MiB Infinity Cache and look faster than it is in the real sequence; rocprofv3 --kernel-trace of this command
+    # sees the same pattern).  Two readings of the same >= 100 launch pairs, all on torch's current stream = the launch
+    # stream: (a) the dispatch's own begin / end timestamps (hpc_rll_ktime_*: start/stop HIP events attached to the
+    # launch itself) -- the kernel's duration as rocprofv3 reports it, used for the roofline figure; (b) hipEventRecord
+    # around every launch -- includes the gap to the neighbouring launch, listed for comparison.
     v_d, r_d = value.detach(), reward.detach()
     adv = torch.empty_like(r_d)
     gv, gr = torch.empty_like(v_d), torch.empty_like(r_d)
-    n_ev = max(args.steps, 10)
+    n_ev = max(args.steps, 100)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_ev + 1)]
     U.GaeForward([v_d, r_d], [adv], gamma, lam)
     U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
-    ev[0].record()
-    for i in range(n_ev):
-        U.GaeForward([v_d, r_d], [adv], gamma, lam)
-        ev[2 * i + 1].record()
-        U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
-        ev[2 * i + 2].record()
-    ev[-1].synchronize()
-    t_fwd = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(n_ev)) / n_ev * 1e-3
-    t_bwd = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(n_ev)) / n_ev * 1e-3
+    torch.cuda.synchronize()
+    with SclkSampler(dev.index or 0) as sclk:
+        assert lib.hpc_rll_ktime_begin(2 * n_ev) == 0
+        ev[0].record()
+        for i in range(n_ev):
+            U.GaeForward([v_d, r_d], [adv], gamma, lam)
+            ev[2 * i + 1].record()
+            U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
+            ev[2 * i + 2].record()
+        ev[-1].synchronize()
+        kms = (ctypes.c_float * (2 * n_ev))()
+        kkind = (ctypes.c_int * (2 * n_ev))()
+        n_k = lib.hpc_rll_ktime_end(kms, kkind, 2 * n_ev)
+    assert n_k == 2 * n_ev, f"hpc_rll_ktime_end: {n_k}"
+    kf = [kms[i] for i in range(n_k) if kkind[i] == 0]
+    kb = [kms[i] for i in range(n_k) if kkind[i] == 1]
+    t_fwd, t_bwd = sum(kf) / len(kf) * 1e-3, sum(kb) / len(kb) * 1e-3
+    t_fwd_ev = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(n_ev)) / n_ev * 1e-3
+    t_bwd_ev = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(n_ev)) / n_ev * 1e-3
     bytes_launch = 12 * T * B + 4 * B  # either direction: SURVEY.md 8(d)
     dom, t_dom = ("gae_bwd_kernel", t_bwd) if t_bwd >= t_fwd else ("gae_fwd_kernel", t_fwd)
+    cfg = {}
+    for d, name in ((0, "gae_fwd_kernel"), (1, "gae_bwd_kernel")):
+        c6 = (ctypes.c_int * 6)()
+        lib.hpc_rll_gae_last_config(d, c6)
+        cfg[name] = {"cols_per_lane": c6[0], "steps_per_chunk": c6[1], "waves_per_workgroup": c6[2], "nontemporal": c6[3],
+                     "half_wave_tiles": bool(c6[4]), "pipelined": bool(c6[5])}
+    del adv, gv, gr
 
     # ---- both scaling readings in the same line.  Bounded: 3 x 100 steps per leg.
     def leg(Bk, graph, steps=100, warmup=20, rounds=3):
@@ -249,7 +348,7 @@ def main():
         del keep_alive
         order = sorted(range(rounds), key=lambda i: rs[i][0])
         mx, per = rs[order[rounds // 2]]
-        return {"B_per_gpu": Bk, "global_B": Bk * world, "launch": "hipGraph replay" if graph else "eager",
+        return {"B_per_gpu": Bk, "global_B": Bk * world, "launch": "hpc_rll.graphed (hipGraph replay)" if graph else "eager",
                 "ms_per_step": mx / steps * 1e3, "value": T * Bk * world * steps / mx,
                 "rounds_ms_per_step": [r[0] / steps * 1e3 for r in rs],
                 "per_rank_ms_per_step": [p / steps * 1e3 for p in per]}
@@ -268,7 +367,8 @@ def main():
 
     # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not
     # fit one pass and cannot be combined with tracing), so the figure is the committed result of
-    # tests/tools/collect_profiles.sh for this shape (profiles/<round>_gae_pmc_traffic.csv), not a live measurement
+    # tests/tools/collect_profiles.sh for this shape (profiles/<round>_gae_pmc_traffic.csv), not a live measurement --
+    # and it is only quoted when the record was taken with the SAME launch configuration the kernels just used.
     traffic = None
     traffic_source = None
     tj = os.path.join(ROOT, "profiles", "gae_traffic.json")
@@ -276,44 +376,82 @@ def main():
         try:
             rec = json.load(open(tj))
             if rec.get("T") == T and rec.get("B") == B:
-                traffic = rec.get(dom)
-                traffic_source = rec.get("source")
+                if rec.get("config") == cfg:
+                    traffic = rec.get(dom)
+                    traffic_source = rec.get("source")
+                else:
+                    traffic_source = (f"profiles/gae_traffic.json was recorded with another launch configuration "
+                                      f"({rec.get('config')}): not quoted")
         except Exception:
             traffic = None
 
+    suite = None
+    if world == 1 and not args.no_suite:
+        del step, keep, value, reward, grad_adv, v_d, r_d
+        torch.cuda.empty_cache()
+        suite = run_suite(dev)
+
     if rank == 0:
-        samples = T * B * world
         out = {
             "metric": "gae_fwd_bwd_samples_per_sec",
-            "value": samples * args.steps / elapsed,
+            "value": T * global_B * args.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GAE fwd+bwd, T={T}, B={B} per GPU, fp32 (BASELINE.json configs[1])",
+            "config": {"workload": f"GAE fwd+bwd, T={T}, global B={global_B} ({B} per GPU), fp32 (BASELINE.json configs[1])",
                        "T": T, "B_per_gpu": B, "global_B": global_B,
                        "parallelism": f"batch-sharded x{world}, no data-path collective",
-                       "launch": "hipGraph replay" if args.graph else "eager"},
+                       "launch": "hpc_rll.graphed (hipGraph replay of the same kernels)" if launch == "graph" else "eager",
+                       "backend": (dist.get_backend() if dist is not None else None)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_launch / t_dom / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bytes_launch / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_launch,
+                         "timing": f"kernel begin/end timestamps of {len(kf)} forward and {len(kb)} backward launches, alternating",
                          "fwd_us": t_fwd * 1e6, "bwd_us": t_bwd * 1e6,
-                         "fwd_bwd_frac": (2 * bytes_launch) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS},
+                         "fwd_us_min_max": [min(kf) * 1e3, max(kf) * 1e3], "bwd_us_min_max": [min(kb) * 1e3, max(kb) * 1e3],
+                         "fwd_bwd_frac": (2 * bytes_launch) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS,
+                         "stream_event_fwd_us": t_fwd_ev * 1e6, "stream_event_bwd_us": t_bwd_ev * 1e6,
+                         "sclk_mhz": sclk.summary(), "launch_config": cfg},
             "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per_rank_s],
             "scaling_detail": detail,
+            "suite": suite,
             "cpu_baseline": None if (args.skip_cpu_baseline or world > 1) else cpu_baseline(T, B, gamma, lam),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_suite(dev):
+    """BASELINE.json configs[2..4] through the drop-in modules (bounded: well under a minute).  The timing harness and
+    the algorithmic byte / flop models are tests/tools/bench_suite.py's (the tool DESIGN.md's tables come from)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import bench_suite as S
+    S.QUIET = True
+    S.dev = dev
+    t0 = time.perf_counter()
+    out = {}
+    for name, fn in (("c3", S.suite_c3), ("c4", S.suite_c4), ("c5", lambda: S.suite_c5(quick=True))):
+        S.rows.clear()
+        try:
+            fn()
+            for r in S.rows:
+                out[r["op"]] = {k: v for k, v in r.items() if k != "op"}
+        except Exception as e:      # the headline does not depend on the suite
+            out[name + "_error"] = repr(e)
+        torch.cuda.empty_cache()
+    out["seconds"] = time.perf_counter() - t0
+    out["peaks"] = {"hbm_GBs": S.HBM, "mfma_f32_TFLOPs": S.MFMA_F32}
+    return out
 
 
 if __name__ == "__main__":

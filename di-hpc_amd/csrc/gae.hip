@@ -22,6 +22,7 @@
 // HBM traffic = algorithmic + the one `value` row per chunk boundary that two waves both read
 // (an L2 hit: same workgroup, same instant).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <initializer_list>
 #include <type_traits>
@@ -206,6 +207,166 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, software-pipelined (round 3).  Same chunk / carry scheme and the SAME arithmetic order as gae_fwd_kernel
+// (bit-identical results), but the 2*LC+1 row loads of iteration it+1 are issued BEFORE iteration it publishes its
+// chunk head, waits at the barrier, resolves the carries and stores: a wave always has a full chunk of loads in
+// flight, instead of alternating between a load phase and a store phase.  Costs a second live register set
+// ((2*LC+1)*V loaded + (LC+1)*V computed), which the 128-thread workgroups of the streaming regime have to spare.
+// Only full 64-column-per-V tiles (no half-wave variant: that regime is latency-, not bandwidth-bound).
+// ------------------------------------------------------------------------------------------------
+// FULLB: B is a multiple of the tile width, no lane is ever out of range -- no exec-masked region around the stores
+// (which would make the compiler's vmcnt bookkeeping pessimistic again, see GUARD below).
+template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB>
+__global__ __launch_bounds__(NW * 64) void gae_fwd_pf_kernel(const float* __restrict__ value,
+                                                             const float* __restrict__ reward,
+                                                             float* __restrict__ adv,
+                                                             const float* __restrict__ coef, int T, int B,
+                                                             float gamma) {
+    constexpr int TILE = 64 * V;
+    __shared__ float lds[2 * NW * TILE + 2 * NW];
+    float* const s_l0 = lds;
+    float* const s_p0 = lds + 2 * NW * TILE;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    const bool col_ok = FULLB || col < (long)B;
+
+    float carry[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) carry[k] = 0.f;
+
+    constexpr int SPAN = NW * LC;
+    const int n_full = T / SPAN;            // iterations in which every wave's chunk lies inside [0,T)
+    const bool ragged = (T % SPAN) != 0;    // one more iteration with per-step guards
+
+    Pack<V> vr[LC + 1], rr[LC];
+#pragma unroll
+    for (int j = 0; j <= LC; ++j)
+#pragma unroll
+        for (int k = 0; k < V; ++k) vr[j].v[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < LC; ++j)
+#pragma unroll
+        for (int k = 0; k < V; ++k) rr[j].v[k] = 0.f;
+
+    auto chunk_t0 = [&](int it) { return T - (it * NW + (NW - 1 - w)) * LC - LC; };
+    auto issue = [&](int it) {
+        if (col_ok) {
+            const int t0 = chunk_t0(it);
+            const float* vp = value + (size_t)t0 * B + col;
+            const float* rp = reward + (size_t)t0 * B + col;
+#pragma unroll
+            for (int j = LC; j >= 0; --j) vr[j] = load_pack<V, NTL>(vp + (size_t)j * B);
+#pragma unroll
+            for (int j = LC - 1; j >= 0; --j) rr[j] = load_pack<V, NTL>(rp + (size_t)j * B);
+        }
+    };
+    // publish the chunk head, resolve the carries through LDS, repair and store (identical to gae_fwd_kernel)
+    // GUARD: per-step `t >= 0` tests (ragged iteration only).  In the full iterations the stores MUST be unconditional:
+    // vmcnt counts loads and stores in issue order, and behind a conditional store the compiler has to assume it was
+    // not issued -- its wait for the prefetched rows then also waits for the stores that WERE issued after them.
+    auto finish = [&](auto guard_, int it, int t0, float (&L)[LC][V], float (&P)[LC]) {
+        constexpr bool GUARD = decltype(guard_)::value != 0;
+        const int buf = it & 1;
+#pragma unroll
+        for (int k = 0; k < V; ++k) s_l0[(buf * NW + w) * TILE + lane * V + k] = L[0][k];
+        if (lane == 0) s_p0[buf * NW + w] = P[0];
+        __syncthreads();
+        float A[V], Aw[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { A[k] = carry[k]; Aw[k] = 0.f; }
+#pragma unroll
+        for (int u = NW - 1; u >= 0; --u) {
+            if (u == w) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) Aw[k] = A[k];
+            }
+            const float p0 = s_p0[buf * NW + u];
+#pragma unroll
+            for (int k = 0; k < V; ++k) A[k] = fmaf(p0, A[k], s_l0[(buf * NW + u) * TILE + lane * V + k]);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) carry[k] = A[k];
+        if (col_ok) {
+#pragma unroll
+            for (int j = LC - 1; j >= 0; --j) {
+                const int t = t0 + j;
+                if (!GUARD || t >= 0) {
+                    Pack<V> o;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) o.v[k] = fmaf(P[j], Aw[k], L[j][k]);
+                    store_pack<V, NTS>(adv + (size_t)t * B + col, o);
+                }
+            }
+        }
+    };
+
+    if (n_full > 0) issue(0);
+    for (int it = 0; it < n_full; ++it) {
+        const int t0 = chunk_t0(it);
+        float L[LC][V];
+        float P[LC];
+        {
+            float a[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) a[k] = 0.f;
+            float p = 1.f;
+#pragma unroll
+            for (int j = LC - 1; j >= 0; --j) {
+                const float c = coef[t0 + j];
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float delta = fmaf(gamma, vr[j + 1].v[k], rr[j].v[k]) - vr[j].v[k];
+                    a[k] = fmaf(c, a[k], delta);
+                    L[j][k] = a[k];
+                }
+                p *= c;
+                P[j] = p;
+            }
+        }
+        if (it + 1 < n_full) issue(it + 1);      // next chunk's loads fly over the barrier, the resolve and the stores
+        finish(std::integral_constant<int, 0>{}, it, t0, L, P);
+    }
+    if (ragged) {
+        const int it = n_full;
+        const int t0 = chunk_t0(it);
+        float L[LC][V];
+        float P[LC];
+        float a[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) a[k] = 0.f;
+        float p = 1.f;
+#pragma unroll
+        for (int j = LC - 1; j >= 0; --j) {
+            const int t = t0 + j;
+            if (t >= 0) {
+                const float c = coef[t];
+                Pack<V> v0, v1, r;
+                if (col_ok) {
+                    v0 = load_pack<V, NTL>(value + (size_t)t * B + col);
+                    v1 = load_pack<V, NTL>(value + (size_t)(t + 1) * B + col);
+                    r = load_pack<V, NTL>(reward + (size_t)t * B + col);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) v0.v[k] = v1.v[k] = r.v[k] = 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float delta = fmaf(gamma, v1.v[k], r.v[k]) - v0.v[k];
+                    a[k] = fmaf(c, a[k], delta);
+                }
+                p *= c;
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) L[j][k] = a[k];
+            P[j] = p;
+        }
+        finish(std::integral_constant<int, 1>{}, it, t0, L, P);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward: d_t = g_t + c_{t-1} d_{t-1} (forward in time), chunks aligned to t = 0, wave 0 earliest.
 // ------------------------------------------------------------------------------------------------
 template <int V, int LC, int NW, bool NTL, bool NTS, bool HALF = false>
@@ -347,9 +508,185 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward, software-pipelined (round 3): the mirror image of gae_fwd_pf_kernel.  Both gradients are written
+// (grad_value and grad_reward non-null; the dispatcher falls back to gae_bwd_kernel otherwise).  Same arithmetic
+// order as gae_bwd_kernel: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB>
+__global__ __launch_bounds__(NW * 64) void gae_bwd_pf_kernel(const float* __restrict__ grad_adv,
+                                                             float* __restrict__ grad_value,
+                                                             float* __restrict__ grad_reward,
+                                                             const float* __restrict__ coef, int T, int B,
+                                                             float gamma) {
+    constexpr int TILE = 64 * V;
+    __shared__ float lds[2 * NW * TILE + 2 * NW];
+    float* const s_l0 = lds;
+    float* const s_p0 = lds + 2 * NW * TILE;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    const bool col_ok = FULLB || col < (long)B;
+
+    float carry[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) carry[k] = 0.f;
+
+    constexpr int SPAN = NW * LC;
+    const int n_full = T / SPAN;
+    const bool ragged = (T % SPAN) != 0;
+
+    Pack<V> g[LC];
+#pragma unroll
+    for (int j = 0; j < LC; ++j)
+#pragma unroll
+        for (int k = 0; k < V; ++k) g[j].v[k] = 0.f;
+
+    auto chunk_t0 = [&](int it) { return (it * NW + w) * LC; };
+    auto issue = [&](int it) {
+        if (col_ok) {
+            const float* gp = grad_adv + (size_t)chunk_t0(it) * B + col;
+#pragma unroll
+            for (int j = 0; j < LC; ++j) g[j] = load_pack<V, NTL>(gp + (size_t)j * B);
+        }
+    };
+    auto finish = [&](auto guard_, int it, int t0, float (&L)[LC][V], float (&Q)[LC]) {
+        constexpr bool GUARD = decltype(guard_)::value != 0;
+        const int buf = it & 1;
+#pragma unroll
+        for (int k = 0; k < V; ++k) s_l0[(buf * NW + w) * TILE + lane * V + k] = L[LC - 1][k];
+        if (lane == 0) s_p0[buf * NW + w] = Q[LC - 1];
+        __syncthreads();
+        float A[V], Aw[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { A[k] = carry[k]; Aw[k] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            if (u == w) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) Aw[k] = A[k];
+            }
+            const float q0 = s_p0[buf * NW + u];
+#pragma unroll
+            for (int k = 0; k < V; ++k) A[k] = fmaf(q0, A[k], s_l0[(buf * NW + u) * TILE + lane * V + k]);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) carry[k] = A[k];
+        if (col_ok) {
+            float prev[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) prev[k] = Aw[k];
+#pragma unroll
+            for (int j = 0; j < LC; ++j) {
+                const int t = t0 + j;
+                if (!GUARD || t < T) {
+                    Pack<V> d, gv;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        d.v[k] = fmaf(Q[j], Aw[k], L[j][k]);
+                        gv.v[k] = fmaf(gamma, prev[k], -d.v[k]);
+                        prev[k] = d.v[k];
+                    }
+                    store_pack<V, NTS>(grad_reward + (size_t)t * B + col, d);
+                    store_pack<V, NTS>(grad_value + (size_t)t * B + col, gv);
+                    if ((GUARD || j == LC - 1) && t == T - 1) {  // bootstrap row: dL/dV_T = gamma * d_{T-1}
+                        Pack<V> last;
+#pragma unroll
+                        for (int k = 0; k < V; ++k) last.v[k] = gamma * d.v[k];
+                        store_pack<V, NTS>(grad_value + (size_t)T * B + col, last);
+                    }
+                }
+            }
+        }
+    };
+
+    if (n_full > 0) issue(0);
+    for (int it = 0; it < n_full; ++it) {
+        const int t0 = chunk_t0(it);
+        float L[LC][V];
+        float Q[LC];
+        {
+            float a[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) a[k] = 0.f;
+            float q = 1.f;
+#pragma unroll
+            for (int j = 0; j < LC; ++j) {
+                const int t = t0 + j;
+                const float c = (t > 0) ? coef[t - 1] : 0.f;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    a[k] = fmaf(c, a[k], g[j].v[k]);
+                    L[j][k] = a[k];
+                }
+                q *= c;
+                Q[j] = q;
+            }
+        }
+        if (it + 1 < n_full) issue(it + 1);
+        finish(std::integral_constant<int, 0>{}, it, t0, L, Q);
+    }
+    if (ragged) {
+        const int it = n_full;
+        const int t0 = chunk_t0(it);
+        float L[LC][V];
+        float Q[LC];
+        float a[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) a[k] = 0.f;
+        float q = 1.f;
+#pragma unroll
+        for (int j = 0; j < LC; ++j) {
+            const int t = t0 + j;
+            if (t < T) {
+                const float c = (t > 0) ? coef[t - 1] : 0.f;
+                Pack<V> gg;
+                if (col_ok) {
+                    gg = load_pack<V, NTL>(grad_adv + (size_t)t * B + col);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) gg.v[k] = 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < V; ++k) a[k] = fmaf(c, a[k], gg.v[k]);
+                q *= c;
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) L[j][k] = a[k];
+            Q[j] = q;
+        }
+        finish(std::integral_constant<int, 1>{}, it, t0, L, Q);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side: configuration choice + dispatch
 // ------------------------------------------------------------------------------------------------
-struct Cfg { int v, lc, nw, flags; bool half; };
+struct Cfg { int v, lc, nw, flags; bool half; bool pf; };
+
+// Kernel timing (hpc_rll_ktime_begin / _end): while armed, every GAE launch goes through hipExtLaunchKernelGGL with a
+// start/stop event pair that brackets the KERNEL ITSELF (the dispatch packet's begin / end timestamps -- what
+// rocprofv3 --kernel-trace reports), not the gap to the neighbouring launches that a pair of hipEventRecord calls on
+// the stream also counts.  A diagnostic for bench.py's live roofline figure; not thread-safe, not for capture.
+struct KTime {
+    bool on = false;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;
+    int* kind = nullptr;
+    int last_cfg[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};   // per direction: v, lc, nw, flags, half, pipelined
+};
+KTime g_kt;
+
+template <class K, class... A>
+inline void launch(K kernel, dim3 grid, dim3 block, hipStream_t st, int kind, A... args) {
+    if (g_kt.on && g_kt.n < g_kt.cap) {
+        const int i = g_kt.n++;
+        g_kt.kind[i] = kind;
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, st, g_kt.ev[2 * i], g_kt.ev[2 * i + 1], 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+    }
+}
 
 inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
@@ -414,13 +751,21 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
     }
     // narrow batches: half-wave tiles (32 columns, two time chunks per wave) when the 64-column tiling cannot give
     // every CU a workgroup and the trajectory has enough chunks for 32 virtual waves; explicit request: flags bit 2
+    const int explicit_flags = flags;
     bool half = flags >= 0 && (flags & 4);
     if (flags < 0) {
         flags = afl;
         half = all_auto && !streaming && v == 1 && lc == 16 && nw == 16 && wgs_for(1) < 256 && T >= 512;
     }
     if (half && !(v == 1 && nw == 16 && (lc == 8 || lc == 16))) half = false;
-    return Cfg{v, lc, nw, flags & 3, half};
+    // software-pipelined forward (gae_fwd_pf_kernel): explicit request = flags bit 3; instantiated for
+    // lc in {4,8,16} (not (4,16)), nw in {2,4,8}, nontemporal stores
+    bool pf = !half && explicit_flags >= 0 && (explicit_flags & 8);
+    if (pf && !(nw == 2 || nw == 4 || nw == 8)) pf = false;
+    if (pf && fwd && !((lc == 4 || lc == 8 || lc == 16) && !(v == 4 && lc == 16) && !(v == 1 && lc == 4))) pf = false;
+    if (pf && !fwd && !((lc == 2 || lc == 4 || lc == 8) && !(v == 1 && lc != 8))) pf = false;
+    if (pf) flags |= 2;
+    return Cfg{v, lc, nw, flags & 3, half, pf};
 }
 
 template <int N> using I = std::integral_constant<int, N>;
@@ -437,18 +782,22 @@ inline void for_each_cfg(F&& f) {
 #undef HPC_RLL_NW_ROW
 }
 
-#define HPC_RLL_GAE_DISPATCH(KERNEL, ...)                                                          \
+#define HPC_RLL_GAE_DISPATCH(KERNEL, KIND, ...)                                                    \
     do {                                                                                           \
         bool hit = false;                                                                          \
+        {                                                                                          \
+            int* lc_ = g_kt.last_cfg[KIND];                                                        \
+            lc_[0] = cfg.v; lc_[1] = cfg.lc; lc_[2] = cfg.nw; lc_[3] = cfg.flags; lc_[4] = cfg.half; lc_[5] = cfg.pf; \
+        }                                                                                          \
         if (cfg.half) {                                                                            \
             const dim3 grid((unsigned)((B + 31) / 32)), block(1024);                               \
             const bool ntl = cfg.flags & 1;                                                        \
             if (cfg.lc == 16) {                                                                    \
-                if (ntl) hipLaunchKernelGGL((KERNEL<1, 16, 16, true, true, true>), grid, block, 0, st, __VA_ARGS__);   \
-                else hipLaunchKernelGGL((KERNEL<1, 16, 16, false, true, true>), grid, block, 0, st, __VA_ARGS__);      \
+                if (ntl) launch(KERNEL<1, 16, 16, true, true, true>, grid, block, st, KIND, __VA_ARGS__);   \
+                else launch(KERNEL<1, 16, 16, false, true, true>, grid, block, st, KIND, __VA_ARGS__);      \
             } else {                                                                               \
-                if (ntl) hipLaunchKernelGGL((KERNEL<1, 8, 16, true, true, true>), grid, block, 0, st, __VA_ARGS__);    \
-                else hipLaunchKernelGGL((KERNEL<1, 8, 16, false, true, true>), grid, block, 0, st, __VA_ARGS__);       \
+                if (ntl) launch(KERNEL<1, 8, 16, true, true, true>, grid, block, st, KIND, __VA_ARGS__);    \
+                else launch(KERNEL<1, 8, 16, false, true, true>, grid, block, st, KIND, __VA_ARGS__);       \
             }                                                                                      \
             hit = true;                                                                            \
         }                                                                                          \
@@ -458,10 +807,10 @@ inline void for_each_cfg(F&& f) {
             if (!hit && cfg.v == V && cfg.lc == LC && cfg.nw == NW) {                                \
                 const dim3 grid((unsigned)((B + 64 * V - 1) / (64 * V))), block(NW * 64);          \
                 switch (cfg.flags) {                                                               \
-                    case 0: hipLaunchKernelGGL((KERNEL<V, LC, NW, false, false>), grid, block, 0, st, __VA_ARGS__); break; \
-                    case 1: hipLaunchKernelGGL((KERNEL<V, LC, NW, true, false>), grid, block, 0, st, __VA_ARGS__); break;  \
-                    case 2: hipLaunchKernelGGL((KERNEL<V, LC, NW, false, true>), grid, block, 0, st, __VA_ARGS__); break;  \
-                    default: hipLaunchKernelGGL((KERNEL<V, LC, NW, true, true>), grid, block, 0, st, __VA_ARGS__); break;  \
+                    case 0: launch(KERNEL<V, LC, NW, false, false>, grid, block, st, KIND, __VA_ARGS__); break; \
+                    case 1: launch(KERNEL<V, LC, NW, true, false>, grid, block, st, KIND, __VA_ARGS__); break;  \
+                    case 2: launch(KERNEL<V, LC, NW, false, true>, grid, block, st, KIND, __VA_ARGS__); break;  \
+                    default: launch(KERNEL<V, LC, NW, true, true>, grid, block, st, KIND, __VA_ARGS__); break;  \
                 }                                                                                  \
                 hit = true;                                                                        \
             }                                                                                      \
@@ -469,6 +818,57 @@ inline void for_each_cfg(F&& f) {
         for_each_cfg(go);                                                                          \
         if (!hit) return HPC_RLL_EUNSUPPORTED;                                                     \
     } while (0)
+
+// the pipelined forward: (V, LC) x NW in {2,4,8}, nontemporal stores, both load flavours
+template <class... A>
+inline bool dispatch_fwd_pf(const Cfg& cfg, int B, hipStream_t st, A... args) {
+    bool hit = false;
+    auto go = [&](auto V_, auto LC_, auto NW_) {
+        constexpr int V = decltype(V_)::value, LC = decltype(LC_)::value, NW = decltype(NW_)::value;
+        if (!hit && cfg.v == V && cfg.lc == LC && cfg.nw == NW) {
+            const dim3 grid((unsigned)((B + 64 * V - 1) / (64 * V))), block(NW * 64);
+            const bool full = (B % (64 * V)) == 0;
+            if (cfg.flags & 1) {
+                if (full) launch(gae_fwd_pf_kernel<V, LC, NW, true, true, true>, grid, block, st, 0, args...);
+                else launch(gae_fwd_pf_kernel<V, LC, NW, true, true, false>, grid, block, st, 0, args...);
+            } else {
+                if (full) launch(gae_fwd_pf_kernel<V, LC, NW, false, true, true>, grid, block, st, 0, args...);
+                else launch(gae_fwd_pf_kernel<V, LC, NW, false, true, false>, grid, block, st, 0, args...);
+            }
+            hit = true;
+        }
+    };
+#define HPC_RLL_PF_ROW(V, LC) go(I<V>{}, I<LC>{}, I<2>{}); go(I<V>{}, I<LC>{}, I<4>{}); go(I<V>{}, I<LC>{}, I<8>{});
+    HPC_RLL_PF_ROW(1, 8) HPC_RLL_PF_ROW(1, 16) HPC_RLL_PF_ROW(2, 4) HPC_RLL_PF_ROW(2, 8) HPC_RLL_PF_ROW(2, 16)
+    HPC_RLL_PF_ROW(4, 4) HPC_RLL_PF_ROW(4, 8)
+#undef HPC_RLL_PF_ROW
+    return hit;
+}
+
+template <class... A>
+inline bool dispatch_bwd_pf(const Cfg& cfg, int B, hipStream_t st, A... args) {
+    bool hit = false;
+    auto go = [&](auto V_, auto LC_, auto NW_) {
+        constexpr int V = decltype(V_)::value, LC = decltype(LC_)::value, NW = decltype(NW_)::value;
+        if (!hit && cfg.v == V && cfg.lc == LC && cfg.nw == NW) {
+            const dim3 grid((unsigned)((B + 64 * V - 1) / (64 * V))), block(NW * 64);
+            const bool full = (B % (64 * V)) == 0;
+            if (cfg.flags & 1) {
+                if (full) launch(gae_bwd_pf_kernel<V, LC, NW, true, true, true>, grid, block, st, 1, args...);
+                else launch(gae_bwd_pf_kernel<V, LC, NW, true, true, false>, grid, block, st, 1, args...);
+            } else {
+                if (full) launch(gae_bwd_pf_kernel<V, LC, NW, false, true, true>, grid, block, st, 1, args...);
+                else launch(gae_bwd_pf_kernel<V, LC, NW, false, true, false>, grid, block, st, 1, args...);
+            }
+            hit = true;
+        }
+    };
+#define HPC_RLL_PF_ROW(V, LC) go(I<V>{}, I<LC>{}, I<2>{}); go(I<V>{}, I<LC>{}, I<4>{}); go(I<V>{}, I<LC>{}, I<8>{});
+    HPC_RLL_PF_ROW(1, 8) HPC_RLL_PF_ROW(2, 2) HPC_RLL_PF_ROW(2, 4) HPC_RLL_PF_ROW(2, 8)
+    HPC_RLL_PF_ROW(4, 2) HPC_RLL_PF_ROW(4, 4) HPC_RLL_PF_ROW(4, 8)
+#undef HPC_RLL_PF_ROW
+    return hit;
+}
 
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
@@ -497,7 +897,13 @@ extern "C" int hpc_rll_gae_forward_ex(const float* value, const float* reward, f
     if (!aligned(value, 4) || !aligned(reward, 4) || !aligned(adv, 4) || !aligned(coef, 4)) return HPC_RLL_EALIGN;
     const Cfg cfg = choose_cfg(true, T, B, max_vec(B, {value, reward, adv}), vec, lc, nw, flags);
     hipStream_t st = (hipStream_t)stream;
-    HPC_RLL_GAE_DISPATCH(gae_fwd_kernel, value, reward, adv, coef, T, B, gamma);
+    if (cfg.pf) {
+        int* lc_ = g_kt.last_cfg[0];
+        lc_[0] = cfg.v; lc_[1] = cfg.lc; lc_[2] = cfg.nw; lc_[3] = cfg.flags; lc_[4] = 0; lc_[5] = 1;
+        if (!dispatch_fwd_pf(cfg, B, st, value, reward, adv, coef, T, B, gamma)) return HPC_RLL_EUNSUPPORTED;
+        return check_launch();
+    }
+    HPC_RLL_GAE_DISPATCH(gae_fwd_kernel, 0, value, reward, adv, coef, T, B, gamma);
     return check_launch();
 }
 
@@ -521,11 +927,66 @@ extern "C" int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value,
         return HPC_RLL_EALIGN;
     const Cfg cfg = choose_cfg(false, T, B, max_vec(B, {grad_adv, grad_value, grad_reward}), vec, lc, nw, flags);
     hipStream_t st = (hipStream_t)stream;
-    HPC_RLL_GAE_DISPATCH(gae_bwd_kernel, grad_adv, grad_value, grad_reward, coef, T, B, gamma);
+    if (cfg.pf && grad_value && grad_reward) {
+        int* lc_ = g_kt.last_cfg[1];
+        lc_[0] = cfg.v; lc_[1] = cfg.lc; lc_[2] = cfg.nw; lc_[3] = cfg.flags; lc_[4] = 0; lc_[5] = 1;
+        if (!dispatch_bwd_pf(cfg, B, st, grad_adv, grad_value, grad_reward, coef, T, B, gamma)) return HPC_RLL_EUNSUPPORTED;
+        return check_launch();
+    }
+    HPC_RLL_GAE_DISPATCH(gae_bwd_kernel, 1, grad_adv, grad_value, grad_reward, coef, T, B, gamma);
     return check_launch();
 }
 
 extern "C" int hpc_rll_gae_backward(const float* grad_adv, float* grad_value, float* grad_reward, const float* coef,
                                     int T, int B, float gamma, void* stream) {
     return hpc_rll_gae_backward_ex(grad_adv, grad_value, grad_reward, coef, T, B, gamma, 0, 0, 0, -1, stream);
+}
+
+// ---- diagnostics: per-launch kernel durations of the GAE kernels (see KTime above) ----------------------------------
+extern "C" int hpc_rll_ktime_begin(int capacity) {
+    if (capacity <= 0 || g_kt.on) return HPC_RLL_EINVAL;
+    g_kt.ev = new hipEvent_t[2 * (size_t)capacity];
+    g_kt.kind = new int[capacity];
+    for (int i = 0; i < 2 * capacity; ++i) {
+        const hipError_t e = hipEventCreate(&g_kt.ev[i]);
+        if (e != hipSuccess) return (int)e;
+    }
+    g_kt.cap = capacity;
+    g_kt.n = 0;
+    g_kt.on = true;
+    return HPC_RLL_OK;
+}
+
+// Waits for the recorded launches, writes their durations (milliseconds) and kinds (0 = forward, 1 = backward) in launch
+// order, disarms.  Returns the number of launches recorded (<= max written) or a negative / HIP status.
+extern "C" int hpc_rll_ktime_end(float* ms, int* kind, int max) {
+    if (!g_kt.on) return HPC_RLL_EINVAL;
+    g_kt.on = false;
+    const int n = g_kt.n;
+    int rc = n;
+    for (int i = 0; i < n; ++i) {
+        hipError_t e = hipEventSynchronize(g_kt.ev[2 * i + 1]);
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, g_kt.ev[2 * i], g_kt.ev[2 * i + 1]);
+        if (e != hipSuccess) { rc = (int)e > 0 ? -1000 - (int)e : HPC_RLL_EINVAL; break; }
+        if (i < max) {
+            if (ms) ms[i] = t;
+            if (kind) kind[i] = g_kt.kind[i];
+        }
+    }
+    for (int i = 0; i < 2 * g_kt.cap; ++i) (void)hipEventDestroy(g_kt.ev[i]);
+    delete[] g_kt.ev;
+    delete[] g_kt.kind;
+    g_kt.ev = nullptr;
+    g_kt.kind = nullptr;
+    g_kt.cap = g_kt.n = 0;
+    return rc;
+}
+
+// The launch configuration the most recent GAE forward (dir = 0) / backward (dir = 1) call of this process used:
+// out[6] = {columns per lane, steps per wave chunk, waves per workgroup, nontemporal flags, half-wave tiles, pipelined}.
+extern "C" int hpc_rll_gae_last_config(int dir, int* out) {
+    if ((dir != 0 && dir != 1) || !out) return HPC_RLL_EINVAL;
+    for (int i = 0; i < 6; ++i) out[i] = g_kt.last_cfg[dir][i];
+    return HPC_RLL_OK;
 }

@@ -5,3 +5,10 @@ Like the reference (all of whose ``__init__.py`` files are empty) nothing is re-
 the leaf modules, e.g. ``from hpc_rll.rl_utils.gae import GAE``.
 """
 __version__ = "0.1.0"
+
+
+def graphed(module, *example_inputs, **kwargs):
+    """One hipGraph per forward+backward step of an hpc_rll module (see ``hpc_rll/graph.py``); an addition to the
+    reference's surface for the launch-latency regime (small per-GPU batches under strong scaling)."""
+    from .graph import graphed as _graphed
+    return _graphed(module, *example_inputs, **kwargs)

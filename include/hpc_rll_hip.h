@@ -69,6 +69,19 @@ int hpc_rll_gae_forward_ex(const float* value, const float* reward, float* adv, 
                            int T, int B, float gamma, int vec, int lc, int nw, int flags, void* stream);
 int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value, float* grad_reward, const float* coef,
                             int T, int B, float gamma, int vec, int lc, int nw, int flags, void* stream);
+/* Forward flags bit 3 (value 8, with explicit vec/lc/nw): the software-pipelined forward kernel (the next chunk's row
+ * loads are issued before the current chunk's barrier / stores); bit-identical results.
+ *
+ * Diagnostics (no reference counterpart; the reference times whole python calls, tests/test_gae.py:31-52).
+ * hpc_rll_ktime_begin(capacity) arms per-launch KERNEL timing for the next `capacity` GAE launches of this process
+ * (start/stop events attached to the dispatch itself: the kernel's own begin/end, what rocprofv3 --kernel-trace
+ * reports); hpc_rll_ktime_end waits for them, writes durations in milliseconds and kinds (0 forward, 1 backward) in
+ * launch order, disarms and returns the number recorded.  Not thread-safe, not usable under stream capture.
+ * hpc_rll_gae_last_config(dir, out[6]): the configuration the latest forward (dir 0) / backward (dir 1) launch used:
+ * {columns per lane, steps per chunk, waves per workgroup, nontemporal flags, half-wave tiles, pipelined}. */
+int hpc_rll_ktime_begin(int capacity);
+int hpc_rll_ktime_end(float* ms, int* kind, int max);
+int hpc_rll_gae_last_config(int dir, int* out);
 
 /* ------------------------------------------------------------------------------------------
  * Shared helpers of the scalar-loss ops.

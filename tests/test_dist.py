@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT, rel_err
+from conftest import ROOT, grad_err, rel_err
 
 
 def _free_port():
@@ -325,11 +325,11 @@ def test_gpu_two_ranks_match_single_process():
         for a, b in zip(full, lstm[:-1]):
             assert rel_err(a, b) < 2e-4
         kb = LB // world
-        assert rel_err(x.grad.cpu().numpy()[:, rank * kb:(rank + 1) * kb], lstm[-1]) < 2e-4
+        assert grad_err(x.grad.cpu().numpy()[:, rank * kb:(rank + 1) * kb], lstm[-1]) < 2e-4
         assert rel_err(l1.item(), r1) < 1e-6
         assert rel_err([x.item() for x in l3], r3) < 1e-6
-        assert rel_err(v.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gv) < 1e-6
-        assert rel_err(to.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gt) < 1e-6
+        assert grad_err(v.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gv) < 1e-6
+        assert grad_err(to.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gt) < 1e-6
         assert np.array_equal(adv[:, rank * k:(rank + 1) * k], radv)     # GAE columns are independent: bit equal
 
 
@@ -397,28 +397,15 @@ def test_gpu_rccl_backend_on_device_tensors():
     assert [x.item() for x in loss] == rl and list(info) == rinfo and np.array_equal(ln.grad.cpu().numpy(), gln)
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_emits_both_scaling_readings(tmp_path):
-    """bench.py under torch.distributed.run with TWO ranks: one JSON line from rank 0 with the
-    headline, per-rank step times, and `scaling_detail` carrying weak AND strong readings (eager and hipGraph) with the
-    world size it saw.  Two ranks share the one GPU of the test box, so the test hooks put both on cuda:0 over gloo
-    (RCCL refuses two ranks per device); the driver's 2/4/8-GPU runs use the same code with one rank per GPU over RCCL."""
-    import json
-    import subprocess
-    import sys
-    env = dict(os.environ, HPC_RLL_BENCH_ONE_DEVICE="1", HPC_RLL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-           "--B", "4096", "--skip-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak"
-    assert d["config"]["B_per_gpu"] == 4096 and d["config"]["global_B"] == 8192
-    assert len(d["per_rank_ms_per_step"]) == 2 and d["cpu_baseline"] is None
-    assert abs(d["value"] - 1024 * 8192 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+def _check_bench_line(d, scaling, launch_word, B_per_gpu):
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == scaling
+    assert d["config"]["B_per_gpu"] == B_per_gpu and d["config"]["global_B"] == 2 * B_per_gpu
+    assert launch_word in d["config"]["launch"] and d["config"]["backend"] == "gloo"
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["cpu_baseline"] is None and d["suite"] is None
+    assert abs(d["value"] - 1024 * 2 * B_per_gpu / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert rf["fwd_us"] > 0 and rf["bwd_us"] > 0 and rf["stream_event_fwd_us"] >= 0.8 * rf["fwd_us"]
+    assert rf["launch_config"]["gae_fwd_kernel"]["cols_per_lane"] in (1, 2, 4)
     sd = d["scaling_detail"]
     assert sd["world_size"] == 2 and sd["backend"] == "gloo"
     for reading, per_gpu in (("weak", 65536), ("strong", 32768)):
@@ -427,3 +414,115 @@ def test_bench_two_ranks_emits_both_scaling_readings(tmp_path):
             assert leg["B_per_gpu"] == per_gpu and leg["global_B"] == 2 * per_gpu
             assert len(leg["per_rank_ms_per_step"]) == 2 and len(leg["rounds_ms_per_step"]) == 3 and leg["ms_per_step"] > 0
     assert sd["strong_per_rank_probe"] is None        # only printed by a single rank
+
+
+def _bench_env():
+    return dict(os.environ, HPC_RLL_BENCH_ONE_DEVICE="1", HPC_RLL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_emits_both_scaling_readings(tmp_path):
+    """bench.py under torch.distributed.run with TWO ranks (the driver's launch form): one JSON line from rank 0 with the
+    headline, per-rank step times, and `scaling_detail` carrying weak AND strong readings (eager and hipGraph) with the
+    world size it saw.  Two ranks share the one GPU of the test box, so the test hooks put both on cuda:0 over gloo
+    (RCCL refuses two ranks per device); the driver's 2/4/8-GPU runs use the same code with one rank per GPU over RCCL.
+    Here with the weak reading / eager launches selected explicitly."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--B", "4096", "--skip-cpu-baseline", "--scaling", "weak", "--launch", "eager"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_bench_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    _check_bench_line(json.loads(lines[0]), "weak", "eager", 4096)
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """a plain `python bench.py --gpus 2` (no launcher -- the form of the driver's N=1 command) starts
+    its own two ranks and exits 0.  Defaults for N > 1: the STRONG reading (--B is the global batch, split over the
+    ranks) launched through hpc_rll.graphed."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in _bench_env().items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--B", "8192",
+           "--skip-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    _check_bench_line(json.loads(lines[0]), "strong", "graphed", 4096)
+
+
+def _rccl_multi_worker(rank, world, port, q):
+    """One rank per GPU over RCCL (runs only on a box with >= 2 GPUs)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+    from hpc_rll import dist as D
+    from hpc_rll.rl_utils.gae import GAE
+    from hpc_rll.rl_utils.vtrace import VTrace
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    T, B, N = 20, 64 * world, 6
+    d = {k: torch.from_numpy(v) for k, v in _data(6, T, B, N).items()}
+    sh = {k: D.shard_batch(v, 1, rank, world).to(dev) for k, v in d.items()}
+    to = sh["target"].clone().requires_grad_(True)
+    v = sh["value"].clone().requires_grad_(True)
+    l3 = VTrace(T, B // world, N, sharded=True)(to, sh["behaviour"], sh["action"], v, sh["reward"])
+    sum(l3).sum().backward()
+    adv = GAE(T, B // world)(sh["value"], sh["reward"])
+    full = D.all_gather_batch(adv, 1)
+    s3 = D.all_reduce_sum([torch.full((1,), float(rank + 1), device=dev), torch.full((2,), 2.0 * (rank + 1), device=dev)])
+    width = D.all_reduce_max_int(10 + rank)
+    p = torch.nn.Parameter(torch.zeros(5, 3, device=dev))
+    p.grad = torch.full((5, 3), float(rank + 1), device=dev)
+    p2 = torch.nn.Parameter(torch.zeros(7, device=dev))
+    p2.grad = torch.arange(7, device=dev, dtype=torch.float32) * (rank + 1)
+    D.all_reduce_grads_([p, p2])
+    q.put((rank, [x.item() for x in l3], to.grad.cpu().numpy(), v.grad.cpu().numpy(), full.cpu().numpy(),
+           [x.cpu().numpy() for x in s3], width, p.grad.cpu().numpy(), p2.grad.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_multi_gpu_matches_single_process():
+    """RCCL with MORE THAN ONE rank (VERDICT r02 missing #6): runs whenever the box has >= 2 GPUs, one rank per GPU,
+    through every hpc_rll.dist entry point -- all_reduce_sum (packed differentiable all-reduce inside sharded V-trace
+    and directly), all_gather_batch, all_reduce_max_int, all_reduce_grads_ -- and compares with the single-process
+    result on GPU 0."""
+    ngpu = torch.cuda.device_count()
+    if ngpu < 2:
+        pytest.skip(f"needs >= 2 GPUs for one RCCL rank per device (this box has {ngpu})")
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
+    from hpc_rll.rl_utils.gae import GAE
+    from hpc_rll.rl_utils.vtrace import VTrace
+    world = min(ngpu, 8)
+    res = sorted(_spawn(_rccl_multi_worker, world, 600), key=lambda r: r[0])
+    dev = torch.device("cuda:0")
+    T, B, N = 20, 64 * world, 6
+    d = {k: torch.from_numpy(v).to(dev) for k, v in _data(6, T, B, N).items()}
+    to = d["target"].clone().requires_grad_(True)
+    v = d["value"].clone().requires_grad_(True)
+    l3 = VTrace(T, B, N)(to, d["behaviour"], d["action"], v, d["reward"])
+    sum(l3).sum().backward()
+    adv = GAE(T, B)(d["value"], d["reward"]).cpu().numpy()
+    k = B // world
+    tri = world * (world + 1) / 2
+    for rank, r3, gt, gvv, full, s3, width, pg, p2g in res:
+        assert rel_err([x.item() for x in l3], r3) < 1e-6
+        assert grad_err(to.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gt) < 1e-6
+        assert grad_err(v.grad.cpu().numpy()[:, rank * k:(rank + 1) * k], gvv) < 1e-6
+        assert np.array_equal(full, adv)
+        assert s3[0].tolist() == [tri] and s3[1].tolist() == [2 * tri, 2 * tri]
+        assert width == 10 + world - 1
+        assert np.array_equal(pg, np.full((5, 3), tri, np.float32))
+        assert np.array_equal(p2g, np.arange(7, dtype=np.float32) * tri)

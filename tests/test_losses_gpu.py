@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import grad_err, rel_err
 from oracle import ref_torch as R
 
 pytestmark = pytest.mark.gpu
@@ -51,7 +51,7 @@ def test_td_lambda_golden(golden):
         assert loss.shape == (1,)
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < TOL
-        assert rel_err(g[f"c{i}_grad_value"], v.grad.cpu().numpy()) < GTOL
+        assert grad_err(g[f"c{i}_grad_value"], v.grad.cpu().numpy()) < GTOL
 
 
 # (1024,64), (2000,17), (513,300), (300,1000): sub-wave tiles of colscan.hpp (4 / 4 / 2 / 2 time chunks per wave)
@@ -70,7 +70,7 @@ def test_td_lambda_oracle(T, B, wmode):
     loss = TDLambda(T, B)(dv, G(r), None if w is None else G(w))
     (3.0 * loss).backward()
     assert rel_err(l64.item(), loss.item()) < TOL
-    assert rel_err(3.0 * v64.grad.numpy(), dv.grad.cpu().numpy()) < GTOL
+    assert grad_err(3.0 * v64.grad.numpy(), dv.grad.cpu().numpy()) < GTOL
 
 
 # ------------------------------------------------------------------------------------------------ V-trace
@@ -85,8 +85,8 @@ def test_vtrace_golden(golden):
                                             float(rc), float(cc), float(pc))
         (co[0] * ls.policy_loss + co[1] * ls.value_loss + co[2] * ls.entropy_loss).sum().backward()
         assert rel_err(g[f"c{i}_losses"], [x.item() for x in ls]) < TOL
-        assert rel_err(g[f"c{i}_grad_target_output"], to.grad.cpu().numpy()) < GTOL
-        assert rel_err(g[f"c{i}_grad_value"], v.grad.cpu().numpy()) < GTOL
+        assert grad_err(g[f"c{i}_grad_target_output"], to.grad.cpu().numpy()) < GTOL
+        assert grad_err(g[f"c{i}_grad_value"], v.grad.cpu().numpy()) < GTOL
 
 
 @pytest.mark.parametrize("T,B,N", [(128, 128, 128), (64, 300, 6), (16, 70, 1000), (9, 33, 2500), (256, 1024, 18), (3, 5, 1),
@@ -107,8 +107,8 @@ def test_vtrace_oracle(T, B, N):
     ls = VTrace(T, B, N)(dto, G(bo), G(a), dv, G(r))
     sum(ls).backward()            # the reference test's pattern (tests/test_vtrace.py:44-52)
     assert rel_err([x.item() for x in l64], [x.item() for x in ls]) < TOL
-    assert rel_err(to64.grad.numpy(), dto.grad.cpu().numpy()) < GTOL
-    assert rel_err(v64.grad.numpy(), dv.grad.cpu().numpy()) < GTOL
+    assert grad_err(to64.grad.numpy(), dto.grad.cpu().numpy()) < GTOL
+    assert grad_err(v64.grad.numpy(), dv.grad.cpu().numpy()) < GTOL
 
 
 def _mask(rng, logits, action, frac=0.3):
@@ -140,9 +140,9 @@ def test_masked_actions_vtrace_ppo(T, B, N):
     sum(ls).backward()
     assert all(np.isfinite(x.item()) for x in ls) and torch.isfinite(dto.grad).all()
     assert rel_err([x.item() for x in l64], [x.item() for x in ls]) < TOL
-    assert rel_err(to64.grad.numpy(), dto.grad.cpu().numpy()) < GTOL
+    assert grad_err(to64.grad.numpy(), dto.grad.cpu().numpy()) < GTOL
     assert (dto.grad.cpu().numpy()[np.isinf(to)] == 0).all()          # masked actions get exactly zero gradient
-    assert rel_err(v64.grad.numpy(), dv.grad.cpu().numpy()) < GTOL
+    assert grad_err(v64.grad.numpy(), dv.grad.cpu().numpy()) < GTOL
 
     Bp = T * B
     ap = a.reshape(Bp)
@@ -157,7 +157,7 @@ def test_masked_actions_vtrace_ppo(T, B, N):
     sum(pl).backward()
     assert rel_err([x.item() for x in p64], [x.item() for x in pl]) < TOL
     assert rel_err(list(i64), list(info)) < 1e-4
-    assert rel_err(ln64.grad.numpy(), dln.grad.cpu().numpy()) < GTOL
+    assert grad_err(ln64.grad.numpy(), dln.grad.cpu().numpy()) < GTOL
     assert (dln.grad.cpu().numpy()[np.isinf(ln)] == 0).all()
 
 
@@ -171,7 +171,7 @@ def test_upgo_golden(golden):
                                             G(g[f"c{i}_value"]))
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < TOL
-        assert rel_err(g[f"c{i}_grad_target_output"], to.grad.cpu().numpy()) < GTOL
+        assert grad_err(g[f"c{i}_grad_target_output"], to.grad.cpu().numpy()) < GTOL
 
 
 @pytest.mark.parametrize("T,B,N", [(256, 256, 256), (100, 70, 5), (2, 5000, 12), (1, 3, 4),
@@ -194,13 +194,13 @@ def test_upgo_oracle(T, B, N):
     margin = np.abs((r[1:] + v[2:]) - v[1:-1]) if T > 1 else np.ones(1)
     if margin.min() > 1e-5:
         assert rel_err(l64.item(), loss.item()) < TOL
-        assert rel_err(to64.grad.numpy(), dto.grad.cpu().numpy()) < GTOL
+        assert grad_err(to64.grad.numpy(), dto.grad.cpu().numpy()) < GTOL
     else:  # a knife-edge comparison exists: fall back to the fp32 evaluation of the same oracle
         to32 = torch.from_numpy(to).requires_grad_(True)
         l32 = R.upgo_loss(to32, torch.from_numpy(rho), torch.from_numpy(a), torch.from_numpy(r), torch.from_numpy(v))
         l32.backward()
         assert rel_err(l32.item(), loss.item()) < 5e-5
-        assert rel_err(to32.grad.numpy(), dto.grad.cpu().numpy()) < 5e-5
+        assert grad_err(to32.grad.numpy(), dto.grad.cpu().numpy()) < 5e-5
 
 
 # ------------------------------------------------------------------------------------------------ PPO
@@ -217,8 +217,8 @@ def test_ppo_golden(golden):
         assert isinstance(info.approx_kl, float) and isinstance(info.clipfrac, float)
         assert rel_err(g[f"c{i}_losses"], [x.item() for x in ls]) < TOL
         assert rel_err(g[f"c{i}_info"], list(info)) < TOL
-        assert rel_err(g[f"c{i}_grad_logit_new"], ln.grad.cpu().numpy()) < GTOL
-        assert rel_err(g[f"c{i}_grad_value_new"], vn.grad.cpu().numpy()) < GTOL
+        assert grad_err(g[f"c{i}_grad_logit_new"], ln.grad.cpu().numpy()) < GTOL
+        assert grad_err(g[f"c{i}_grad_value_new"], vn.grad.cpu().numpy()) < GTOL
 
 
 @pytest.mark.parametrize("B,N,dual,uvc", [(128, 128, None, True), (4096, 18, 3.0, True), (70000, 6, None, False), (3, 1000, 1.5, True)])
@@ -238,8 +238,8 @@ def test_ppo_oracle(B, N, dual, uvc):
     sum(ls).backward()
     assert rel_err([x.item() for x in l64], [x.item() for x in ls]) < TOL
     assert rel_err(list(i64), list(info)) < 1e-4     # clipfrac counts strict inequalities of fp32 ratios
-    assert rel_err(ln64.grad.numpy(), dln.grad.cpu().numpy()) < GTOL
-    assert rel_err(vn64.grad.numpy(), dvn.grad.cpu().numpy()) < GTOL
+    assert grad_err(ln64.grad.numpy(), dln.grad.cpu().numpy()) < GTOL
+    assert grad_err(vn64.grad.numpy(), dvn.grad.cpu().numpy()) < GTOL
 
 
 # ------------------------------------------------------------------------------------------------ q n-step TD
@@ -255,7 +255,7 @@ def test_qntd_golden(golden):
             loss.backward()
             assert rel_err(g[f"c{i}_{tag}_loss"], loss.item()) < 5e-5
             assert rel_err(g[f"c{i}_{tag}_td_err"], per.cpu().numpy()) < 5e-5
-            assert rel_err(g[f"c{i}_{tag}_grad_q"], q.grad.cpu().numpy()) < 5e-5
+            assert grad_err(g[f"c{i}_{tag}_grad_q"], q.grad.cpu().numpy()) < 5e-5
 
 
 @pytest.mark.parametrize("rescale", [False, True])
@@ -275,7 +275,7 @@ def test_qntd_oracle_reference_shape(rescale):
     loss.backward()
     assert rel_err(l64.item(), loss.item()) < 2e-5
     assert rel_err(p64.detach().numpy(), per.cpu().numpy()) < 2e-5
-    assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+    assert grad_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
 
 
 # ------------------------------------------------------------------------------------------------ dist (C51)
@@ -291,7 +291,7 @@ def test_dntd_golden(golden):
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < 1e-4
         assert rel_err(g[f"c{i}_td_err"], per.cpu().numpy()) < 1e-4
-        assert rel_err(g[f"c{i}_grad_dist"], d.grad.cpu().numpy()) < 1e-4
+        assert grad_err(g[f"c{i}_grad_dist"], d.grad.cpu().numpy()) < 1e-4
 
 
 def test_dntd_oracle_reference_shape():
@@ -315,7 +315,7 @@ def test_dntd_oracle_reference_shape():
     loss.backward()
     assert rel_err(l32.item(), loss.item()) < 1e-4
     assert rel_err(p32.detach().numpy(), per.cpu().numpy()) < 1e-4
-    assert rel_err(d32.grad.numpy(), dd.grad.cpu().numpy()) < 1e-4
+    assert grad_err(d32.grad.numpy(), dd.grad.cpu().numpy()) < 1e-4
 
 
 # ------------------------------------------------------------------------------------------------ IQN / QR-DQN
@@ -331,7 +331,7 @@ def test_iqn_golden(golden):
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < 5e-5
         assert rel_err(g[f"c{i}_td_err"], per.cpu().numpy()) < 5e-5
-        assert rel_err(g[f"c{i}_grad_q"], q.grad.cpu().numpy()) < 5e-5
+        assert grad_err(g[f"c{i}_grad_q"], q.grad.cpu().numpy()) < 5e-5
 
 
 def test_iqn_oracle_reference_shape():
@@ -351,7 +351,7 @@ def test_iqn_oracle_reference_shape():
     loss.backward()
     assert rel_err(l64.item(), loss.item()) < 2e-5
     assert rel_err(p64.detach().numpy(), per.cpu().numpy()) < 2e-5
-    assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+    assert grad_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
 
 
 def test_qrdqn_golden(golden):
@@ -365,7 +365,7 @@ def test_qrdqn_golden(golden):
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < 5e-5
         assert rel_err(g[f"c{i}_td_err"], per.cpu().numpy()) < 5e-5
-        assert rel_err(g[f"c{i}_grad_q"], q.grad.cpu().numpy()) < 5e-5
+        assert grad_err(g[f"c{i}_grad_q"], q.grad.cpu().numpy()) < 5e-5
 
 
 def test_qrdqn_oracle_reference_shape():
@@ -384,7 +384,7 @@ def test_qrdqn_oracle_reference_shape():
     loss.backward()
     assert rel_err(l64.item(), loss.item()) < 2e-5
     assert rel_err(p64.detach().numpy(), per.cpu().numpy()) < 2e-5
-    assert rel_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+    assert grad_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
 
 
 # ------------------------------------------------------------------------------------------------ misc

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import grad_err, rel_err
 from oracle import ref_torch as R
 
 pytestmark = pytest.mark.gpu
@@ -82,17 +82,17 @@ def test_lstm_golden(golden):
         assert rel_err(g[f"c{i}_hn"], hn.detach().cpu().numpy()) < 1e-5
         assert rel_err(g[f"c{i}_cn"], cn.detach().cpu().numpy()) < 1e-5
         tol = 2e-4
-        assert rel_err(g[f"c{i}_grad_x"], x.grad.cpu().numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_h0"], h0.grad.cpu().numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_c0"], c0.grad.cpu().numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_bias"].reshape(-1), m.bias.grad.cpu().numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_ln_gamma"], m.ln_gamma.grad.cpu().numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_ln_beta"], m.ln_beta.grad.cpu().numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_x"], x.grad.cpu().numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_h0"], h0.grad.cpu().numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_c0"], c0.grad.cpu().numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_bias"].reshape(-1), m.bias.grad.cpu().numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_ln_gamma"], m.ln_gamma.grad.cpu().numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_ln_beta"], m.ln_beta.grad.cpu().numpy()) < tol
         gwx = _split_flat(m.wx.grad.cpu().numpy(), L, I, H)
         gwh = m.wh.grad.cpu().numpy().reshape(L, H, 4 * H)
         for l in range(L):
-            assert rel_err(g[f"c{i}_grad_wx{l}"], gwx[l]) < tol
-            assert rel_err(g[f"c{i}_grad_wh{l}"], gwh[l]) < tol
+            assert grad_err(g[f"c{i}_grad_wx{l}"], gwx[l]) < tol
+            assert grad_err(g[f"c{i}_grad_wh{l}"], gwh[l]) < tol
 
 
 @pytest.mark.parametrize("S,B,I,H,L", [(64, 3, 1792, 384, 3), (6, 200, 64, 128, 2), (3, 40, 20, 600, 1), (2, 5, 9, 1100, 1), (1, 1, 1, 1, 1),

@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
-import cabi  # noqa: E402
 
-dev = torch.device("cuda:0")
+dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cuda:0")
+QUIET = False      # bench.py imports this module for its `suite` object and sets QUIET (one JSON line on stdout)
 HBM, MFMA_F32 = 8000.0, 157.3   # GB/s, TFLOP/s (MI355X_MICROARCH.md)
 rows = []
 
@@ -46,7 +46,8 @@ def report(name, shape, t_f, bytes_f, t_b=None, bytes_b=None, flops_f=None, flop
         else:
             r.update(bwd_gbs=bytes_b / t_b / 1e9, bwd_frac=bytes_b / t_b / 1e9 / HBM)
     rows.append(r)
-    print(json.dumps(r), flush=True)
+    if not QUIET:
+        print(json.dumps(r), flush=True)
 
 
 def fwd_bwd(make_loss, grads_of):
@@ -192,7 +193,9 @@ def suite_gemm():
         del a, b, c
 
 
-def suite_c5(B=4096, M=256, N=64, H=64, W=64):
+def suite_c5(B=4096, M=256, N=64, H=64, W=64, quick=False):
+    """quick: Scatter + the packed Pad1D only (bench.py's driver-run `suite`); the list-of-tensors legs build 131k
+    tensor objects on the host and take seconds."""
     from hpc_rll.torch_utils.network.scatter_connection import ScatterConnection
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn(B, M, N, device=dev, generator=g, requires_grad=True)
@@ -216,6 +219,16 @@ def suite_c5(B=4096, M=256, N=64, H=64, W=64):
     # Pad1D / Unpad1D over n ragged tensors (views of one buffer), len ~ U[32,128)
     from hpc_rll.rl_utils import padding as P
     import numpy as np
+    del x, loc
+    n1m = 1 << 20
+    lens1m = torch.from_numpy(np.random.default_rng(1).integers(32, 128, n1m)).to(dev)
+    flat1m = torch.randn(int(lens1m.sum().item()), device=dev)
+    t_pk = timed(lambda: P.Padding1DPacked(flat1m, lens1m, max_len=127), n=3)
+    report("pad1d_packed_api", f"n={n1m} len~U[32,128) (device table, no host loop)", t_pk, 4 * flat1m.numel() + 8 * n1m * 127)
+    del flat1m, lens1m
+    if quick:
+        return
+    import cabi
     n = 1 << 17
     lens = np.random.default_rng(0).integers(32, 128, n)
     flat = torch.randn(int(lens.sum()), device=dev)
@@ -225,18 +238,15 @@ def suite_c5(B=4096, M=256, N=64, H=64, W=64):
     table = torch.tensor([[t.data_ptr(), 1, 1, t.shape[0]] for t in xs], dtype=torch.int64).to(dev)
     t_un = timed(lambda: P.UnPadding1D(new_x, shapes), n=1, rounds=2)
     rows.append(dict(op="unpad1d_python_api", shape=f"n={n}", fwd_ms=t_un * 1e3, note="list-of-tensors API incl. host table build"))
-    print(json.dumps(rows[-1]), flush=True)
+    if not QUIET:
+        print(json.dumps(rows[-1]), flush=True)
     mx = int(lens.max())
     t_k = timed(lambda: cabi.call("hpc_rll_pad_forward", dev, table.data_ptr(), new_x.data_ptr(), mask.data_ptr(), n, 1, 1, mx, 0), n=5)
     report("pad1d_kernel", f"n={n} len~U[32,128)", t_k, 4 * int(lens.sum()) + 8 * n * mx)
-    n1m = 1 << 20
-    lens1m = torch.from_numpy(np.random.default_rng(1).integers(32, 128, n1m)).to(dev)
-    flat1m = torch.randn(int(lens1m.sum().item()), device=dev)
-    t_pk = timed(lambda: P.Padding1DPacked(flat1m, lens1m, max_len=127), n=3)
-    report("pad1d_packed_api", f"n={n1m} len~U[32,128) (device table, no host loop)", t_pk, 4 * flat1m.numel() + 8 * n1m * 127)
     t_api = timed(lambda: P.Padding1D(xs), n=1, rounds=2)
     rows.append(dict(op="pad1d_python_api", shape=f"n={n}", fwd_ms=t_api * 1e3, note="list-of-tensors API incl. host table build"))
-    print(json.dumps(rows[-1]), flush=True)
+    if not QUIET:
+        print(json.dumps(rows[-1]), flush=True)
 
 
 def suite_small():
