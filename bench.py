@@ -145,8 +145,14 @@ class SclkSampler:
         import glob
         self.path, self.samples, self._stop, self._th = None, [], False, None
         cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if cands:
-            self.path = cands[min(index, len(cands) - 1)]
+        try:        # the card whose PCI address is this HIP device's (a node exposes all its cards in sysfs)
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for c in cands:
+                if os.path.basename(os.path.realpath(os.path.dirname(c))).startswith(want):
+                    self.path = c
+        except Exception:
+            self.path = None
 
     def _read(self):
         try:

@@ -718,6 +718,7 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
     const bool all_auto = v == 0 && lc == 0 && nw == 0;
     const bool streaming = (12.0 * (double)T * (double)B) >= 300e6;
     int av, alc, anw, afl;
+    bool apf = false;   // the software-pipelined kernels (round 3)
     if (streaming && fwd) {
         av = (B >= 65536 && vmax >= 2) ? 2 : 1;
         const int wgs = wgs_for(av);
@@ -725,11 +726,17 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
         else if (wgs >= 512) { alc = 8; anw = av == 2 ? 2 : 4; }   // ~35 KiB of loads in flight per CU either way
         else { alc = 16; anw = 8; }
         afl = 3;
+        // round 3 (tests/tools/r03_gae_pf_sweep.py, profiles/r03_gae_pf_sweep_1024x65536.txt, alternating with the
+        // backward, kernel timestamps): pipelined (2,4,2) 128.7-128.9 us against 131.8-132.1 for the (2,8,2) above in
+        // the same process; (4,4,8) pipelined ties, plain loads are 0.3 us faster but cost the next backward 25 us
+        if (B == 65536 && vmax >= 2 && wgs == 512) { alc = 4; anw = 2; apf = true; }
     } else if (streaming) {
         if (B >= 262144 && vmax >= 2) { av = 2; alc = 16; anw = 16; }
         // in-process A/B at B = 65536 (tests/tools/gae_bwd_ab.py): (2,2,4) 115.5 us, (4,2,4) 116.8, (4,4,4) 120.1;
         // at B = 131072 (alt_shapes.py) (4,2,4) is best
         else if (B >= 131072 && vmax >= 4) { av = 4; alc = 2; anw = 4; }
+        // round 3, same sweep: pipelined (4,2,4) 112.3-112.6 us against 116.1 for the plain (2,2,4)
+        else if (B >= 65536 && vmax >= 4) { av = 4; alc = 2; anw = 4; apf = true; }
         else if (B >= 65536 && vmax >= 2) { av = 2; alc = 2; anw = 4; }
         else { av = 1; alc = 8; anw = 8; }
         afl = 2;
@@ -760,7 +767,7 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
     if (half && !(v == 1 && nw == 16 && (lc == 8 || lc == 16))) half = false;
     // software-pipelined forward (gae_fwd_pf_kernel): explicit request = flags bit 3; instantiated for
     // lc in {4,8,16} (not (4,16)), nw in {2,4,8}, nontemporal stores
-    bool pf = !half && explicit_flags >= 0 && (explicit_flags & 8);
+    bool pf = !half && (explicit_flags >= 0 ? (explicit_flags & 8) != 0 : (all_auto && apf));
     if (pf && !(nw == 2 || nw == 4 || nw == 8)) pf = false;
     if (pf && fwd && !((lc == 4 || lc == 8 || lc == 16) && !(v == 4 && lc == 16) && !(v == 1 && lc == 4))) pf = false;
     if (pf && !fwd && !((lc == 2 || lc == 4 || lc == 8) && !(v == 1 && lc != 8))) pf = false;

@@ -12,8 +12,9 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python "$REPO/bench.py" --steps 20 --warmup 5 --skip-cpu-baseline \
-    --no-scaling-detail > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python "$REPO/bench.py" --steps 200 --warmup 20 --skip-cpu-baseline \
+    --no-scaling-detail --no-suite > "$OUT/trace.log" 2>&1
+export PROBE_CONFIG_OUT="$OUT/gae_config.json"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- python "$REPO/tests/tools/pmc_probe.py" > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o write -- python "$REPO/tests/tools/pmc_probe.py" > "$OUT/write.log" 2>&1
 cd "$REPO"

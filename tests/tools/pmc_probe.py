@@ -25,4 +25,16 @@ for _ in range(3):
 for _ in range(3):
     U.GaeBackward([ga], [gv, gr], 0.99, 0.97)
 torch.cuda.synchronize()
+# the launch configuration these counters belong to (bench.py quotes the traffic only for the SAME configuration)
+import ctypes  # noqa: E402
+import json  # noqa: E402
+lib = ctypes.CDLL(os.path.join(ROOT, "di-hpc_amd", "hpc_rll", "_lib", "libhpc_rll_hip.so"))
+cfg = {}
+for d, name in ((0, "gae_fwd_kernel"), (1, "gae_bwd_kernel")):
+    c6 = (ctypes.c_int * 6)()
+    lib.hpc_rll_gae_last_config(d, c6)
+    cfg[name] = {"cols_per_lane": c6[0], "steps_per_chunk": c6[1], "waves_per_workgroup": c6[2], "nontemporal": c6[3],
+                 "half_wave_tiles": bool(c6[4]), "pipelined": bool(c6[5])}
+if os.environ.get("PROBE_CONFIG_OUT"):
+    json.dump(cfg, open(os.environ["PROBE_CONFIG_OUT"], "w"))
 print("probe done: copy bytes R=W=%d ; gae algorithmic bytes per launch=%d" % (T * B * 4, 12 * T * B + 4 * B))

@@ -53,7 +53,7 @@ agg = collections.defaultdict(list)
 full = {}
 for name in ("fetch", "write"):
     for k, cname, val in counter_rows(name):
-        short = ("gae_fwd_kernel" if "gae_fwd_kernel" in k else "gae_bwd_kernel" if "gae_bwd_kernel" in k
+        short = ("gae_fwd_kernel" if "gae_fwd_" in k else "gae_bwd_kernel" if "gae_bwd_" in k
                  else "copyBuffer(calibration)" if "copyBuffer" in k else None)
         if short:
             agg[(short, cname)].append(val)
@@ -74,7 +74,9 @@ for k in ("gae_fwd_kernel", "gae_bwd_kernel"):
     traffic[k] = tb
     lines.append(f"# {k}: HBM traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 = {tb:.0f} B per launch; algorithmic {alg} B; ratio {tb/alg:.4f}")
 open(os.path.join(out, f"{tag}_gae_pmc_traffic.csv"), "w").write("\n".join(lines) + "\n")
-json.dump({"T": T, "B": B, **traffic, "source": f"profiles/{tag}_gae_pmc_traffic.csv (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md)"},
+cfg_path = os.path.join(src, "gae_config.json")
+config = json.load(open(cfg_path)) if os.path.exists(cfg_path) else None
+json.dump({"T": T, "B": B, **traffic, "config": config, "source": f"profiles/{tag}_gae_pmc_traffic.csv (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md)"},
           open(os.path.join(out, "gae_traffic.json"), "w"), indent=1)
 prof_log = os.path.join(src, "trace.log")
 if os.path.exists(prof_log):   # the bench line printed by the PROFILED command itself (its live kernel timings agree with
