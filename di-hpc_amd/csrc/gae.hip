@@ -702,8 +702,8 @@ inline int max_vec(int B, std::initializer_list<const void*> ptrs) {
 
 // Launch-configuration heuristic, tuned on MI355X with forward and backward launches ALTERNATING (the real
 // access pattern; a kernel repeated back to back finds part of its input in the 256 MiB Infinity Cache and
-// looks faster than it is).  Sweeps: profiles/r01_gae_tuning_*.txt (every instantiation at T=1024,B=65536) and
-// profiles/r01_gae_heuristic_shapes.txt (candidate sets at 7 more shapes); summary in DESIGN.md.
+// looks faster than it is).  Sweeps: profiles/r01/r01_gae_tuning_*.txt (every instantiation at T=1024,B=65536) and
+// profiles/r01/r01_gae_heuristic_shapes.txt (candidate sets at 7 more shapes); summary in DESIGN.md.
 //   * ~32 KiB of loads in flight per CU saturates HBM; beyond ~2048 waves more occupancy does not help.
 //   * Stores are always NONTEMPORAL: a regular store leaves dirty lines in L2/MALL whose write-back lands in the
 //     NEXT kernel (+35-45 us on the following launch).  For working sets beyond the Infinity Cache the forward also
@@ -719,6 +719,13 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
     const bool streaming = (12.0 * (double)T * (double)B) >= 300e6;
     int av, alc, anw, afl;
     bool apf = false;   // the software-pipelined kernels (round 3)
+    // Round 3 sweeps (tests/tools/r03_gae_pf_sweep.py -> profiles/r03_gae_pf_sweep_*.txt; forward and backward
+    // alternating, kernel begin/end timestamps, shipped round-2 configuration -> pipelined one in the same process):
+    //   T=1024 B=32768  fwd (1,8,4) 65.7 -> (2,16,8)p 63.8      bwd (1,8,8) 59.5 -> (4,4,4)p 56.3
+    //   T=1024 B=65536  fwd (2,8,2) 132.1 -> (2,4,2)p 128.8     bwd (2,2,4) 116.1 -> (4,2,4)p 112.4
+    //   T=1024 B=131072 fwd (2,16,8) 272.7, no pipelined gain   bwd (4,2,4) 305.1 -> (4,2,4)p 288.9
+    //   T=256  B=262144 fwd (2,16,8) 131.6 -> (2,16,4)p 129.2   bwd (2,16,16) 135.4 -> (1,8,8)p 115.4
+    // (plain loads in the forward are 0.3 us faster but cost the next backward 25 us: forward loads stay nontemporal)
     if (streaming && fwd) {
         av = (B >= 65536 && vmax >= 2) ? 2 : 1;
         const int wgs = wgs_for(av);
@@ -726,18 +733,18 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
         else if (wgs >= 512) { alc = 8; anw = av == 2 ? 2 : 4; }   // ~35 KiB of loads in flight per CU either way
         else { alc = 16; anw = 8; }
         afl = 3;
-        // round 3 (tests/tools/r03_gae_pf_sweep.py, profiles/r03_gae_pf_sweep_1024x65536.txt, alternating with the
-        // backward, kernel timestamps): pipelined (2,4,2) 128.7-128.9 us against 131.8-132.1 for the (2,8,2) above in
-        // the same process; (4,4,8) pipelined ties, plain loads are 0.3 us faster but cost the next backward 25 us
-        if (B == 65536 && vmax >= 2 && wgs == 512) { alc = 4; anw = 2; apf = true; }
+        if (vmax >= 2) {
+            if (B < 65536) { if (B >= 32768) { av = 2; alc = 16; anw = 8; apf = true; } }   // narrower: keep the round-2 choice
+            else if (B < 131072) { av = 2; alc = 4; anw = 2; apf = true; }
+            else if (B >= 262144) { av = 2; alc = 16; anw = 4; apf = true; }
+        }
     } else if (streaming) {
-        if (B >= 262144 && vmax >= 2) { av = 2; alc = 16; anw = 16; }
-        // in-process A/B at B = 65536 (tests/tools/gae_bwd_ab.py): (2,2,4) 115.5 us, (4,2,4) 116.8, (4,4,4) 120.1;
-        // at B = 131072 (alt_shapes.py) (4,2,4) is best
-        else if (B >= 131072 && vmax >= 4) { av = 4; alc = 2; anw = 4; }
-        // round 3, same sweep: pipelined (4,2,4) 112.3-112.6 us against 116.1 for the plain (2,2,4)
+        if (B >= 262144) { av = 1; alc = 8; anw = 8; apf = true; }
         else if (B >= 65536 && vmax >= 4) { av = 4; alc = 2; anw = 4; apf = true; }
+        else if (B >= 131072 && vmax >= 2) { av = 2; alc = 2; anw = 4; }
+        // round 2 in-process A/B at B = 65536 (tests/tools/gae_bwd_ab.py): (2,2,4) 115.5 us, (4,2,4) 116.8, (4,4,4) 120.1
         else if (B >= 65536 && vmax >= 2) { av = 2; alc = 2; anw = 4; }
+        else if (B >= 32768 && vmax >= 4) { av = 4; alc = 4; anw = 4; apf = true; }
         else { av = 1; alc = 8; anw = 8; }
         afl = 2;
     } else {

@@ -32,6 +32,7 @@
 
 #include "hpc_rll_hip.h"
 #include "wave.hpp"
+#include "pad_group.hpp"
 
 namespace hpc_rll {
 namespace {
@@ -537,8 +538,9 @@ namespace {
 //   rank 2/3 (long lists only): key = numel  -> the cost model of hpc_rll/origin/padding.py:16-17 (arr[end] * count);
 //     the per-dimension maxima of padding.cu are not monotone in a numel-sorted list, their exact DP stays quadratic
 //     and is kept for n <= 512.  The group SHAPES are always the true per-dimension maxima.
-void dc_layer(const int64_t* key, const int64_t* prev, int64_t* cur, int32_t* arg, int lo, int hi, int klo, int khi,
-              int64_t INF) {
+// E: element count of the first k items (E[k] = k for the element-level DP, the run boundaries for the run-level one)
+void dc_layer(const int64_t* key, const int64_t* E, const int64_t* prev, int64_t* cur, int32_t* arg, int lo, int hi, int klo,
+              int khi, int64_t INF) {
     if (lo > hi) return;
     const int mid = (lo + hi) >> 1;
     int64_t best = INF;
@@ -546,47 +548,84 @@ void dc_layer(const int64_t* key, const int64_t* prev, int64_t* cur, int32_t* ar
     const int kend = khi < mid - 1 ? khi : mid - 1;
     for (int k = klo; k <= kend; ++k) {
         if (prev[k] >= INF) continue;
-        const int64_t c = prev[k] + key[mid - 1] * (int64_t)(mid - k);
+        const int64_t c = prev[k] + key[mid - 1] * (E[mid] - E[k]);
         if (c < best) { best = c; bk = k; }
     }
     cur[mid] = best;
     arg[mid] = bk;
-    dc_layer(key, prev, cur, arg, lo, mid - 1, klo, best >= INF ? khi : bk, INF);
-    dc_layer(key, prev, cur, arg, mid + 1, hi, best >= INF ? klo : bk, khi, INF);
+    dc_layer(key, E, prev, cur, arg, lo, mid - 1, klo, best >= INF ? khi : bk, INF);
+    dc_layer(key, E, prev, cur, arg, mid + 1, hi, best >= INF ? klo : bk, khi, INF);
+}
+
+// monotone DP over m items (elements, or runs of equal keys) into M groups; ps[0..M] = item boundaries
+void dc_split(const int64_t* key, const int64_t* E, int m, int M, std::vector<int32_t>& ps) {
+    const int64_t INF = kSplitInf;
+    std::vector<int32_t> pos((size_t)(m + 1) * (M + 1), 0);
+    std::vector<int64_t> prev(m + 1, INF), cur(m + 1, INF);
+    std::vector<int32_t> arg(m + 1, 0);
+    prev[0] = 0;
+    for (int j = 1; j <= M; ++j) {
+        std::fill(cur.begin(), cur.end(), INF);
+        dc_layer(key, E, prev.data(), cur.data(), arg.data(), 1, m, 0, m - 1, INF);
+        for (int i = 1; i <= m; ++i) pos[(size_t)i * (M + 1) + j] = arg[i];
+        prev.swap(cur);
+    }
+    ps.assign(M + 1, 0);
+    int lp = m;
+    ps[M] = m;
+    for (int j = M; j >= 1; --j) { lp = pos[(size_t)lp * (M + 1) + j]; ps[j - 1] = lp; }
 }
 }  // namespace
+
+namespace hpc_rll { int g_split_algo = 0; }   // hpc_rll_tune_set key 22: 0 = runs of equal keys (default), 1 = the
+                                              // round-2 paths (quadratic element DP / divide-and-conquer over elements)
 
 extern "C" int hpc_rll_oracle_split_group(const int32_t* sizes, int n, int dim, int group, int32_t* group_shapes,
                                           int32_t* positions) {
     if (!sizes || n <= 0 || dim <= 0 || dim > 3 || group <= 0 || !group_shapes || !positions) return HPC_RLL_EINVAL;
     const int M = group < n ? group : n;  // more groups than tensors is meaningless (the reference would walk off)
-    const int64_t INF = INT64_MAX / 4;
-    std::vector<int32_t> pos((size_t)(n + 1) * (M + 1), 0);
-    auto P = [&](int i, int j) -> int32_t& { return pos[(size_t)i * (M + 1) + j]; };
-    // long lists: monotone DP on the element count (see dc_layer); needs the documented precondition "sorted by numel"
-    std::vector<int64_t> key;
-    bool sorted = n > 512;
-    if (sorted) {
-        key.resize(n);
-        for (int i = 0; i < n; ++i) {
-            int64_t e = 1;
-            for (int d = 0; d < dim; ++d) e *= sizes[(size_t)i * dim + d];
-            key[i] = e;
-            if (i && key[i] < key[i - 1]) { sorted = false; break; }
-        }
+    const int64_t INF = kSplitInf;
+    // lists sorted by element count (the documented precondition; hpc_rll/rl_utils/padding.py sorts): DP on the key
+    std::vector<int64_t> key(n);
+    bool sorted = true;
+    for (int i = 0; i < n; ++i) {
+        int64_t e = 1;
+        for (int d = 0; d < dim; ++d) e *= sizes[(size_t)i * dim + d];
+        key[i] = e;
+        if (i && key[i] < key[i - 1]) { sorted = false; break; }
     }
-    if (!sorted && n > 20000) return HPC_RLL_EUNSUPPORTED;   // the quadratic DP would take hours: sort the list first
-    if (sorted) {
-        std::vector<int64_t> prev(n + 1, INF), cur(n + 1, INF);
-        std::vector<int32_t> arg(n + 1, 0);
-        prev[0] = 0;
-        for (int j = 1; j <= M; ++j) {
-            std::fill(cur.begin(), cur.end(), INF);
-            dc_layer(key.data(), prev.data(), cur.data(), arg.data(), 1, n, 0, n - 1, INF);
-            for (int i = 1; i <= n; ++i) P(i, j) = arg[i];
-            prev.swap(cur);
+    // rank 1: key = the length, the DP cost is the exact padded-element count of padding.cu:44-108 for any n.
+    // rank 2/3: key = numel is the cost model of hpc_rll/origin/padding.py:16-17 (arr[end] * count); padding.cu's
+    // per-dimension maxima are not monotone in a numel-sorted list, their exact DP stays quadratic and is kept for
+    // n <= 512.  The group SHAPES are always the true per-dimension maxima.
+    const bool by_key = sorted && (dim == 1 || n > 512);
+    if (!by_key && n > 20000) return HPC_RLL_EUNSUPPORTED;   // the quadratic DP would take hours: sort the list first
+    std::vector<int32_t> ps;
+    if (by_key && g_split_algo == 0) {
+        // runs of equal keys (pad_group.hpp): O(n) + O(M D log D) for D distinct keys
+        std::vector<int64_t> val, E(1, 0);
+        for (int i = 0; i < n; ++i) {
+            if (val.empty() || key[i] != val.back()) { val.push_back(key[i]); E.push_back(E.back()); }
+            ++E.back();
         }
+        const int D = (int)val.size();
+        std::vector<int64_t> pe(M + 1, 0);
+        if (D < M) {
+            std::vector<int32_t> gm(M);
+            split_runs_few(val.data(), E.data(), D, (int64_t)n, M, pe.data(), gm.data());
+        } else {
+            std::vector<int32_t> pr;
+            dc_split(val.data(), E.data(), D, M, pr);
+            for (int g = 0; g <= M; ++g) pe[g] = E[pr[g]];
+        }
+        ps.assign(pe.begin(), pe.end());
+    } else if (by_key && (dim > 1 || n > 512)) {
+        std::vector<int64_t> E(n + 1);
+        for (int i = 0; i <= n; ++i) E[i] = i;
+        dc_split(key.data(), E.data(), n, M, ps);
     } else {
+        std::vector<int32_t> pos((size_t)(n + 1) * (M + 1), 0);
+        auto P = [&](int i, int j) -> int32_t& { return pos[(size_t)i * (M + 1) + j]; };
         std::vector<int64_t> cost((size_t)(n + 1) * (M + 1), INF);
         auto C = [&](int i, int j) -> int64_t& { return cost[(size_t)i * (M + 1) + j]; };
         C(0, 0) = 0;
@@ -613,12 +652,11 @@ extern "C" int hpc_rll_oracle_split_group(const int32_t* sizes, int n, int dim, 
                 P(i, j) = arg;
             }
         }
+        int lp = n, lc = M;
+        ps.push_back(n);
+        while (lp > 0) { lp = P(lp, lc); --lc; ps.push_back(lp); }
+        std::reverse(ps.begin(), ps.end());
     }
-    std::vector<int32_t> ps;
-    int lp = n, lc = M;
-    ps.push_back(n);
-    while (lp > 0) { lp = P(lp, lc); --lc; ps.push_back(lp); }
-    std::reverse(ps.begin(), ps.end());
     const int ng = (int)ps.size() - 1;
     for (int g = 0; g < ng; ++g) {
         for (int d = 0; d < dim; ++d) {

@@ -129,6 +129,8 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * default 512 = two per CU; 0 = always one row per workgroup + a separate column-reduction pass).  key 21: 1 (default) =
  * every scalar-loss forward (TD-lambda, V-trace, UPGO, PPO, q / dist / IQN / QR-DQN n-step TD) finalises its loss sums in
  * the last workgroup of its last launch; 0 = a separate finalize launch (the same partials, summed in fp64 either way).
+ * key 22: group-split algorithm of hpc_rll_oracle_split_group for key-sorted lists: 0 (default) = DP over the runs of
+ * equal keys, 1 = the round-2 element-level paths (cross-check; identical results).
  */
 int hpc_rll_tune_set(int key, int value);
 
