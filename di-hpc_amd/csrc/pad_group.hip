@@ -12,7 +12,7 @@
 //   3. stable LSD radix sort (8-bit digits, 1 pass for max_len < 256, 2 below 65536) of (length, row index) -> `order`,
 //      python's sorted() order: ascending length, original order among equal lengths; deterministic (no atomics decide
 //      an output position);
-//   4. one launch writes all groups: the dense index space of the concatenated outputs, rows fetched through `order`.
+//   4. one launch writes all groups: one wave per sorted row, rows fetched through `order`, outputs back to back.
 // Integer / byte work, HBM-bound, bit exact.  The only host synchronisation is the one the return convention forces:
 // the caller must know the bucket shapes to allocate them (3 * group + 4 integers come back).
 #include <hip/hip_runtime.h>
@@ -290,7 +290,9 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------ 4. all groups, one launch
-// The dense index space of the concatenated outputs.  table: rows {pointer, 1, 1, length} of hpc_rll_packed_table.
+// One wave per sorted row p: the row's group, source row and length are wave-uniform (scalar loads), the lanes copy /
+// fill the row's `width` columns; consecutive rows of a group are consecutive in the output, so the workgroups write
+// contiguous spans.  table: rows {pointer, 1, 1, length} of hpc_rll_packed_table.  No division per element.
 template <int G_MAX>
 __global__ __launch_bounds__(256) void pad_groups_kernel(const int64_t* __restrict__ table, const int64_t* __restrict__ order,
                                                          const int64_t* __restrict__ plan, int G, float* __restrict__ out,
@@ -298,27 +300,31 @@ __global__ __launch_bounds__(256) void pad_groups_kernel(const int64_t* __restri
     __shared__ int64_t s_pos[G_MAX + 1], s_off[G_MAX + 1];
     __shared__ int32_t s_w[G_MAX];
     const int ng = (int)plan[0];
-    if (threadIdx.x <= ng) {
+    if ((int)threadIdx.x <= ng) {
         s_pos[threadIdx.x] = plan[2 + threadIdx.x];
         s_off[threadIdx.x] = plan[3 + 2 * G + threadIdx.x];
-        if (threadIdx.x < ng) s_w[threadIdx.x] = (int32_t)plan[3 + G + threadIdx.x];
+        if ((int)threadIdx.x < ng) s_w[threadIdx.x] = (int32_t)plan[3 + G + threadIdx.x];
     }
     __syncthreads();
-    const int64_t total = s_off[ng];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int g = 0;
-        while (g + 1 < ng && i >= s_off[g + 1]) ++g;
-        const uint32_t wdt = (uint32_t)s_w[g];
-        const uint64_t rel = (uint64_t)(i - s_off[g]);
-        const uint64_t row = rel / wdt;                      // wdt > 0 whenever the group holds an output element
-        const uint32_t col = (uint32_t)(rel - row * wdt);
-        const int64_t src = order[s_pos[g] + (int64_t)row];
+    const int64_t n = s_pos[ng];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    int g = 0;
+    for (int64_t p = wave; p < n; p += nwaves) {
+        while (g + 1 < ng && p >= s_pos[g + 1]) ++g;       // rows only move forward: amortised O(1)
+        const int wdt = s_w[g];
+        const int64_t base = s_off[g] + (p - s_pos[g]) * (int64_t)wdt;
+        const int64_t src = order[p];
         const int64_t* tr = table + src * 4;
-        const uint32_t len = (uint32_t)tr[3];
-        const bool in = col < len;
-        const float x = in ? reinterpret_cast<const float*>(tr[0])[col] : value;
-        __builtin_nontemporal_store(x, out + i);
-        __builtin_nontemporal_store(in ? 1 : 0, mask + i);
+        const float* sp = reinterpret_cast<const float*>(tr[0]);
+        const int len = (int)tr[3];
+        for (int c = lane; c < wdt; c += 64) {
+            const bool in = c < len;
+            const float x = in ? sp[c] : value;
+            __builtin_nontemporal_store(x, out + base + c);
+            __builtin_nontemporal_store(in ? 1 : 0, mask + base + c);
+        }
     }
 }
 
@@ -387,8 +393,7 @@ extern "C" int hpc_rll_pad1d_group_forward(const int64_t* table, const int64_t* 
     if (group > 63) return HPC_RLL_EUNSUPPORTED;
     if (total_out == 0) return HPC_RLL_OK;
     if (!table || !order || !plan || !out || !mask) return HPC_RLL_EINVAL;
-    int64_t blocks = (total_out + 255) / 256;
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    const int64_t blocks = 256 * 16;        // 16 workgroups of 4 waves per CU, rows dealt round robin
     hipLaunchKernelGGL(pad_groups_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, order, plan,
                        group, out, mask, (float)value);
     return last_err();

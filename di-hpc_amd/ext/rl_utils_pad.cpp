@@ -248,6 +248,57 @@ Tensor unpad1d_packed(const Tensor& x, const Tensor& lengths, std::optional<int6
     return flat;
 }
 
+// Grouped variant (the reference's group > 1 convention, on packed rows, entirely on the device): returns
+// [list of new_x_g (cnt_g, width_g), list of mask_g, list of lengths_g (cnt_g,), order (n,)].  Rows are taken in sorted
+// order (ascending length, original order among equal lengths): row r of group g is original row order[cuts[g] + r].
+// ONE host synchronisation: the 3*group+4 plan integers (the bucket shapes must be known to allocate the buckets).
+std::vector<TensorList> pad1d_packed_grouped(const Tensor& flat, const Tensor& lengths, std::optional<int64_t> max_len,
+                                             int64_t value, int64_t group, bool oracle, uint64_t seed) {
+    req(flat, "flat");
+    const at::Device dev = flat.device();
+    req(lengths, "lengths", dev, at::kLong);
+    TORCH_CHECK(flat.dim() == 1 && lengths.dim() == 1, "Padding1DPacked: flat and lengths must be 1-D");
+    TORCH_CHECK(group >= 1 && group <= 63, "Padding1DPacked: group must be in 1..63, got ", group);
+    const int64_t n = lengths.numel();
+    c10::DeviceGuard g(dev);
+    int64_t ml = 0;
+    if (max_len.has_value()) ml = *max_len;
+    else if (n) ml = lengths.max().item<int64_t>();
+    TORCH_CHECK(ml >= 0 && ml <= 16384, "Padding1DPacked(group>1): max_len must be <= 16384 (the device split works on a "
+                "histogram of the lengths), got ", ml);
+    const int G = (int)group;
+    auto lopt = at::TensorOptions().dtype(at::kLong).device(dev);
+    Tensor order = at::empty({n}, lopt);
+    Tensor plan = at::empty({3 * G + 4}, lopt);
+    Tensor ws = at::empty({hpc_rll_pad1d_group_workspace_int64(n, (int)ml, G)}, lopt);
+    check(hpc_rll_pad1d_group_plan(lengths.const_data_ptr<int64_t>(), n, (int)ml, G, oracle ? 0 : 1, seed, ws.data_ptr<int64_t>(),
+                                   plan.data_ptr<int64_t>(), order.data_ptr<int64_t>(), stream_of(dev)),
+          "hpc_rll_pad1d_group_plan");
+    Tensor table;
+    if (n) table = packed_table(lengths, (int64_t)(uintptr_t)flat.data_ptr(), 4, dev);   // overlaps the copy below
+    const Tensor hplan = plan.cpu();   // the one synchronisation
+    const int64_t* hp = hplan.const_data_ptr<int64_t>();
+    TORCH_CHECK(hp[1] == 0, "Padding1DPacked: a length lies outside [0, max_len=", ml, "]");
+    const int ng = (int)hp[0];
+    const int64_t total = hp[3 + 2 * G + ng];
+    Tensor out = new_f32({total}, dev);
+    Tensor mask = at::empty({total}, at::TensorOptions().dtype(at::kInt).device(dev));
+    if (total)
+        check(hpc_rll_pad1d_group_forward(table.const_data_ptr<int64_t>(), order.const_data_ptr<int64_t>(),
+                                          plan.const_data_ptr<int64_t>(), G, out.data_ptr<float>(), mask.data_ptr<int32_t>(),
+                                          total, (int)value, stream_of(dev)),
+              "hpc_rll_pad1d_group_forward");
+    Tensor sorted_len = n ? lengths.index_select(0, order) : lengths;
+    TensorList xs, ms, ls;
+    for (int gi = 0; gi < ng; ++gi) {
+        const int64_t lo = hp[2 + gi], hi = hp[2 + gi + 1], w = hp[3 + G + gi], off = hp[3 + 2 * G + gi];
+        xs.push_back(out.narrow(0, off, (hi - lo) * w).view({hi - lo, w}));
+        ms.push_back(mask.narrow(0, off, (hi - lo) * w).view({hi - lo, w}));
+        ls.push_back(sorted_len.narrow(0, lo, hi - lo));
+    }
+    return {xs, ms, ls, {order}};
+}
+
 }  // namespace
 
 void bind_padding(pybind11::module_& m) {
@@ -290,6 +341,14 @@ void bind_padding(pybind11::module_& m) {
     }, py::arg("inputs"), py::arg("group"), py::arg("seed") = py::none());
     m.def("pad1d_packed", &pad1d_packed, py::arg("flat"), py::arg("lengths"), py::arg("max_len") = py::none(),
           py::arg("value") = 0);
+    m.def("pad1d_packed_grouped", [](const Tensor& flat, const Tensor& lengths, std::optional<int64_t> max_len, int64_t value,
+                                     int64_t group, const std::string& group_mode, std::optional<uint64_t> seed) {
+        TORCH_CHECK(group_mode == "oracle" || group_mode == "sample", "group_mode must be 'oracle' or 'sample'");
+        const uint64_t s = seed.has_value() ? *seed
+                           : group_mode == "sample" ? py::module_::import("random").attr("getrandbits")(63).cast<uint64_t>() : 0;
+        return pad1d_packed_grouped(flat, lengths, max_len, value, group, group_mode == "oracle", s);
+    }, py::arg("flat"), py::arg("lengths"), py::arg("max_len") = py::none(), py::arg("value") = 0, py::arg("group") = 2,
+       py::arg("group_mode") = "oracle", py::arg("seed") = py::none());
     m.def("unpad1d_packed", &unpad1d_packed, py::arg("x"), py::arg("lengths"), py::arg("total") = py::none());
 
     // host-logic hooks for the CPU test tier (no GPU needed): the tables the pad / unpad kernels consume

@@ -88,10 +88,22 @@ def UnPadding3D(x: Union[torch.Tensor, List[torch.Tensor]], shapes: Union[List, 
 # device layout is ONE flat buffer plus a device vector of lengths.  Same kernels, table built on the device, no host
 # loop and (when ``max_len`` is given) no host synchronisation.
 # ---------------------------------------------------------------------------------------------------------------------
-def Padding1DPacked(flat: torch.Tensor, lengths: torch.Tensor, max_len: int = None, value: int = 0):
+def Padding1DPacked(flat: torch.Tensor, lengths: torch.Tensor, max_len: int = None, value: int = 0, group: int = 1,
+                    group_mode: str = 'oracle', seed: int = None):
     """flat (sum(lengths),) fp32, lengths (n,) int64 on the same GPU -> (new_x (n,max_len) fp32, mask (n,max_len) int32).
     Row i of new_x holds flat[offset_i : offset_i + lengths[i]] followed by ``value``.  The offsets are an exclusive scan
-    done on the device inside the extension; ``max_len=None`` costs the only host sync (lengths.max())."""
+    done on the device inside the extension; ``max_len=None`` costs the only host sync (lengths.max()).
+
+    ``group > 1`` (the reference's bucketing, hpc_rll/rl_utils/padding.py:20-45, entirely on the device): the rows are
+    taken in sorted order (ascending length, original order among equal lengths -- python's ``sorted``), split into at
+    most ``group`` buckets by ``group_mode`` ('oracle': the padded-element-minimising DP of
+    hpc_rll/origin/padding.py:11-50 with its tie rule; 'sample': random cuts) and every bucket is padded to its own
+    width by ONE launch.  Returns ``[tuple(new_x_g), tuple(mask_g), tuple(lengths_g), order]``: bucket g holds the
+    original rows ``order[cut_g : cut_{g+1}]``, ``lengths_g`` their lengths.  ``max_len`` <= 16384; one host sync (the
+    bucket shapes)."""
+    if group > 1:
+        xs, ms, ls, (order,) = hpc_rl_utils.pad1d_packed_grouped(flat, lengths, max_len, value, group, group_mode, seed)
+        return [tuple(xs), tuple(ms), tuple(ls), order]
     new_x, mask = hpc_rl_utils.pad1d_packed(flat, lengths, max_len, value)
     return new_x, mask
 

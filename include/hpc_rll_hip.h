@@ -250,6 +250,24 @@ int hpc_rll_oracle_split_group(const int32_t* sizes, int n, int dim, int group, 
                                int32_t* positions);
 int hpc_rll_sample_split_group(const int32_t* sizes, int n, int dim, int group, uint64_t seed,
                                int32_t* group_shapes, int32_t* positions);
+/* Grouped padding of PACKED 1-D rows entirely on the device (what hpc_rll/rl_utils/padding.py:20-45 does on the host
+ * with a python sorted() + the split policies above + one pad per group; SURVEY.md 8f-3: ~1M rows at configs[4]).
+ * lengths (n,) int64 on the device, every length in [0, max_len], max_len <= 16384, group <= 63.
+ *   plan  : histogram of the lengths -> runs of equal lengths -> the split policy on the runs (mode 0 = oracle: the same
+ *           cuts as hpc_rll_oracle_split_group incl. its tie rule; mode 1 = sample with `seed`) -> `plan`, 3*group+4
+ *           int64 on the device: [0] number of groups ng, [1] status (1 = a length was outside [0,max_len] and clamped),
+ *           [2 .. 2+group] cut positions in sorted order, [3+group .. 3+2*group) group widths,
+ *           [3+2*group .. 4+3*group) offsets of the groups in the concatenated output (ng+1 used);
+ *           and a STABLE radix sort of (length, row) -> order (n,) int64: order[p] = original row of sorted position p
+ *           (ascending length, original order among equal lengths = python's sorted()).
+ *           ws: hpc_rll_pad1d_group_workspace_int64(n, max_len, group) int64.  No host synchronisation.
+ *   forward: all groups in ONE launch.  table = hpc_rll_packed_table rows of the ORIGINAL order; out / mask hold the
+ *           groups back to back (group g: (cuts[g+1]-cuts[g]) rows of width[g] at offset[g]); total_out = offset[ng]. */
+int64_t hpc_rll_pad1d_group_workspace_int64(int64_t n, int max_len, int group);
+int hpc_rll_pad1d_group_plan(const int64_t* lengths, int64_t n, int max_len, int group, int mode, uint64_t seed,
+                             int64_t* ws, int64_t* plan, int64_t* order, void* stream);
+int hpc_rll_pad1d_group_forward(const int64_t* table, const int64_t* order, const int64_t* plan, int group, float* out,
+                                int32_t* mask, int64_t total_out, int value, void* stream);
 
 /* ScatterConnection -- replaces ScatterConnectionForward/Backward (torch_utils/network/entry.h:21-29,
  * src/torch_utils/network/scatter_connection.cu:8-73).  x (B,M,N) fp32, location (B,M,2) int64 (y,x),

@@ -218,6 +218,22 @@ def test_c5_pad_round_trip_one_million_elements():
     assert torch.equal(torch.cat(P.UnPadding1D(new_x, shapes)), flat)
 
 
+def test_c5_list_api_round_trip_at_two_to_the_twenty_tensors():
+    """configs[4] at its STATED size through the reference's own entry points: Padding1D /
+    UnPadding1D over a python list of 2^20 tensors (views of one buffer), len ~ U[32,128): bit-exact round trip.  The
+    host cost of a million tensor objects dominates (seconds); the kernels take ~0.1 ms."""
+    from hpc_rll.rl_utils import padding as P
+    n = 1 << 20
+    lens = np.random.default_rng(1).integers(32, 128, n)
+    flat = torch.randn(int(lens.sum()), device=DEV)
+    xs = list(torch.split(flat, lens.tolist()))
+    new_x, mask, shapes = P.Padding1D(xs)
+    assert new_x.shape == (n, int(lens.max())) and len(shapes) == n and int(mask.sum()) == int(lens.sum())
+    back = P.UnPadding1D(new_x, shapes)
+    assert len(back) == n and torch.equal(torch.cat(back), flat)
+    del back, xs
+
+
 def test_td_family_large_batch_equals_its_slices():
     """Size-independent property of the per-sample ops at a batch where the large-batch kernels run (B = 2^17: group-per-
     sample IQN / QR-DQN, one-pass C51, 16-byte one-hot gradients with 64-bit offsets): the per-sample TD error of sample b

@@ -129,3 +129,50 @@ def test_unsorted_long_list_is_refused_not_quadratic():
     xs = [torch.empty(3, (i * 7919) % 50 + 1) for i in range(20001)]      # not sorted by numel
     with pytest.raises(RuntimeError):
         U.oracle_split_group(xs, 4)
+
+
+def _split_pos_np(nl, group, algo):
+    """positions from the C ABI directly (no tensor list): algo 0 = runs of equal keys, 1 = the element-level paths"""
+    import cabi as N
+    n = len(nl)
+    sizes = (ctypes.c_int32 * n)(*nl)
+    shapes = (ctypes.c_int32 * max(group, 1))()
+    pos = (ctypes.c_int32 * (group + 1))()
+    assert N.lib.hpc_rll_tune_set(22, algo) == 0
+    try:
+        ng = N.lib.hpc_rll_oracle_split_group(sizes, n, 1, group, shapes, pos)
+    finally:
+        N.lib.hpc_rll_tune_set(22, 0)
+    assert ng >= 1, ng
+    return list(pos[:ng + 1]), list(shapes[:ng])
+
+
+def test_run_level_split_equals_reference_dp_including_forced_cuts():
+    """Round 3 (f-3): the split works on RUNS of equal keys (csrc/pad_group.hpp).  Small lists against the python
+    restatement of hpc_rll.origin.padding.oracle_split_group (the quadratic element DP, smallest split point on ties):
+    many ties, fewer distinct lengths than groups (cuts forced inside runs), single-run lists, group > n."""
+    rng = np.random.default_rng(7)
+    cases = [([5] * 9, 4), ([5] * 3, 8), ([1, 1, 1, 2, 2, 9], 5), ([3, 3, 3, 3, 7, 7, 7, 7, 7, 7], 4), ([2], 3), ([4, 4], 2),
+             ([1, 2, 3, 4, 5, 6, 7, 8], 8), ([1, 2, 3, 4, 5, 6, 7, 8], 3), ([0, 0, 1, 1, 1, 5], 4)]
+    for _ in range(300):
+        n = int(rng.integers(1, 60))
+        hi = int(rng.integers(1, 12))
+        cases.append((sorted(int(v) for v in rng.integers(0 if hi > 3 else 1, hi + 1, n)), int(rng.integers(1, 12))))
+    for nl, group in cases:
+        want = R.oracle_split_group(nl, min(group, len(nl)))
+        pos, shapes = _split_pos_np(nl, group, 0)
+        assert pos == want, (nl, group, pos, want)
+        assert shapes == [max(nl[a:b]) for a, b in zip(pos, pos[1:])]
+        if len(nl) > 0:
+            assert _split_pos_np(nl, group, 1)[0] == want, (nl, group)
+
+
+@pytest.mark.parametrize("n,hi,group", [(5000, 6, 8), (20000, 40, 8), (200000, 128, 8), (200000, 3, 16), (50000, 5000, 12),
+                                        (30000, 1, 5)])
+def test_run_level_split_equals_element_level_dp_on_long_lists(n, hi, group):
+    """... and long lists (up to 2 x 10^5) against the round-2 divide-and-conquer DP over ELEMENTS (tune key 22 = 1)."""
+    rng = np.random.default_rng(n + hi)
+    nl = sorted(int(v) for v in rng.integers(1, hi + 1, n))
+    a = _split_pos_np(nl, group, 0)
+    b = _split_pos_np(nl, group, 1)
+    assert a == b

@@ -118,6 +118,128 @@ def test_packed_padding_matches_list_api_at_one_million_entities():
     assert torch.equal(new_x[:k, :w], lx) and torch.equal(mask[:k, :w], lm)
 
 
+def _packed_group_reference(flat, lens, group, value):
+    """What hpc_rll/rl_utils/padding.py:20-45 does, restated for packed rows with torch ops: stable sort by length, the
+    split policy on the sorted lengths (the C ABI's host entry point, itself pinned to the reference DP by
+    tests/test_host_logic.py), one dense pad per group."""
+    import ctypes
+    import cabi as N
+    lens_c = lens.cpu().numpy()
+    order = np.argsort(lens_c, kind="stable")
+    sl = lens_c[order]
+    n = len(sl)
+    sizes = (ctypes.c_int32 * n)(*[int(v) for v in sl])
+    shapes = (ctypes.c_int32 * group)()
+    pos = (ctypes.c_int32 * (group + 1))()
+    ng = N.lib.hpc_rll_oracle_split_group(sizes, n, 1, group, shapes, pos)
+    assert ng >= 1
+    offs = np.concatenate([[0], np.cumsum(lens_c)])
+    fc = flat.cpu()
+    xs, ms = [], []
+    for g in range(ng):
+        rows = order[pos[g]:pos[g + 1]]
+        w = int(shapes[g])
+        x = torch.full((len(rows), w), float(value))
+        m = torch.zeros((len(rows), w), dtype=torch.int32)
+        for r, i in enumerate(rows):
+            L = int(lens_c[i])
+            x[r, :L] = fc[offs[i]:offs[i] + L]
+            m[r, :L] = 1
+        xs.append(x)
+        ms.append(m)
+    return xs, ms, [sl[pos[g]:pos[g + 1]] for g in range(ng)], order, list(pos[:ng + 1])
+
+
+@pytest.mark.parametrize("n,lo,hi,group", [(1, 3, 4, 4), (2, 1, 2, 2), (7, 5, 6, 3), (300, 0, 9, 4), (1000, 32, 128, 8), (5000, 1, 4, 6),
+                                           (4097, 200, 1000, 5), (2500, 0, 300, 16), (3000, 7, 8, 2), (1025, 1, 3, 63)])
+def test_packed_group_padding_on_device_matches_the_reference_policy(n, lo, hi, group):
+    """f-3 on the device: histogram -> split on runs -> stable radix sort -> one pad launch.  Bit
+    exact against the reference policy incl. its tie rule: few distinct lengths (cuts forced inside runs), a single
+    length, group > n, zero-length rows, max_len >= 256 (two radix passes), ragged last sort chunk."""
+    from hpc_rll.rl_utils import padding as P
+    rng = np.random.default_rng(n * 31 + group)
+    lens = torch.from_numpy(rng.integers(lo, hi, n)).to(DEV)
+    flat = torch.randn(int(lens.sum().item()) + 1, device=DEV)[: int(lens.sum().item())]
+    for value, max_len in ((0, None), (-4, hi + 5)):
+        xs, ms, ls, order = P.Padding1DPacked(flat, lens, max_len=max_len, value=value, group=group, group_mode="oracle")
+        rx, rm, rl, rorder, _ = _packed_group_reference(flat, lens, group, value)
+        assert np.array_equal(order.cpu().numpy(), rorder)
+        assert len(xs) == len(rx) == len(ms) == len(ls)
+        for a, b, c, d, e, f in zip(xs, rx, ms, rm, ls, rl):
+            assert a.shape == b.shape and torch.equal(a.cpu(), b) and torch.equal(c.cpu(), d)
+            assert np.array_equal(e.cpu().numpy(), f)
+
+
+def test_packed_group_padding_equals_host_dp_at_200k_and_runs_at_one_million():
+    """n = 2 x 10^5: cuts, order and widths identical to the host DP.  n = 2^20, group = 8 (configs[4] scale): the same
+    checks against the host policy evaluated on the sorted lengths, every row spot-checked through its mask, and the
+    whole call (plan + sort + one host sync + pad of ~0.8 GB of output) inside 5 ms."""
+    import time
+    from hpc_rll.rl_utils import padding as P
+    for n, timed in ((200000, False), (1 << 20, True)):
+        rng = np.random.default_rng(n)
+        lens = torch.from_numpy(rng.integers(32, 128, n)).to(DEV)
+        total = int(lens.sum().item())
+        flat = torch.randn(total, device=DEV)
+        xs, ms, ls, order = P.Padding1DPacked(flat, lens, max_len=127, group=8)
+        lens_c = lens.cpu().numpy()
+        rorder = np.argsort(lens_c, kind="stable")
+        assert np.array_equal(order.cpu().numpy(), rorder)
+        import ctypes
+        import cabi as N
+        sl = lens_c[rorder]
+        sizes = (ctypes.c_int32 * n)(*sl.tolist())
+        shapes, pos = (ctypes.c_int32 * 8)(), (ctypes.c_int32 * 9)()
+        assert N.lib.hpc_rll_oracle_split_group(sizes, n, 1, 8, shapes, pos) == 8
+        assert [x.shape[0] for x in xs] == [pos[g + 1] - pos[g] for g in range(8)]
+        assert [x.shape[1] for x in xs] == list(shapes)
+        offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), lens.cumsum(0)])
+        for g in range(8):
+            rows = order[pos[g]:pos[g + 1]]
+            assert torch.equal(ms[g].sum(1).long(), lens[rows]) and torch.equal(ls[g], lens[rows])
+            assert bool((ms[g][:, 1:] <= ms[g][:, :-1]).all())                      # a mask row is 1...10...0
+            # the values: row r of the group, column c < len  ==  flat[offs[row] + c]
+            w = xs[g].shape[1]
+            col = torch.arange(w, device=DEV)[None, :]
+            src = (offs[rows][:, None] + col).clamp(max=total - 1)
+            want = torch.where(ms[g].bool(), flat[src], torch.zeros((), device=DEV))
+            assert torch.equal(xs[g], want)
+        if timed:
+            best = 1e9
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = P.Padding1DPacked(flat, lens, max_len=127, group=8)
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            del out
+            assert best < 5e-3, f"grouped packed pad of 2^20 rows took {best * 1e3:.2f} ms"
+
+
+def test_packed_group_padding_sample_policy_and_errors():
+    from hpc_rll.rl_utils import padding as P
+    rng = np.random.default_rng(3)
+    n = 5000
+    lens = torch.from_numpy(rng.integers(10, 90, n)).to(DEV)
+    flat = torch.randn(int(lens.sum().item()), device=DEV)
+    a = P.Padding1DPacked(flat, lens, group=5, group_mode="sample", seed=11)
+    b = P.Padding1DPacked(flat, lens, group=5, group_mode="sample", seed=11)
+    assert len(a[0]) <= 5 and all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
+    order = a[3]
+    sl = lens[order]
+    assert bool((sl[1:] >= sl[:-1]).all()) and sum(x.shape[0] for x in a[0]) == n
+    k = 0
+    for x, m, l in zip(*a[:3]):
+        assert x.shape[1] == int(l.max()) and torch.equal(l, sl[k:k + x.shape[0]]) and torch.equal(m.sum(1).long(), l)
+        k += x.shape[0]
+    widths = [x.shape[1] for x in a[0]]
+    assert all(p < q for p, q in zip(widths, widths[1:]))              # equal-width neighbours are merged
+    with pytest.raises(RuntimeError):
+        P.Padding1DPacked(flat, lens, max_len=50, group=4)               # a length beyond max_len
+    with pytest.raises(RuntimeError):
+        P.Padding1DPacked(flat, lens, max_len=20000, group=4)            # beyond the histogram width of the device split
+
+
 def test_padding_errors():
     from hpc_rll.rl_utils import padding as P
     with pytest.raises(RuntimeError):
