@@ -122,11 +122,15 @@ __global__ __launch_bounds__(256) void unpad_kernel(const float* __restrict__ pa
             if (table[mid * 4] <= o) lo = mid; else hi = mid - 1;
         }
         const int64_t* __restrict__ e = table + lo * 4;
-        const unsigned d1 = (unsigned)e[2], d2 = (unsigned)e[3];
+        const unsigned d0 = (unsigned)e[1], d1 = (unsigned)e[2], d2 = (unsigned)e[3];
         unsigned rem = (unsigned)(o - e[0]);
+        // a caller-supplied `total` beyond the sum of the shapes, or a shape larger than the padded tensor (the packed
+        // API takes both from the caller unchecked): nothing to read for this element -- never index outside `padded`
+        if ((unsigned long)rem >= (unsigned long)d0 * d1 * d2) continue;
         const unsigned c = rem % d2; rem /= d2;
         const unsigned b = rem % d1;
         const unsigned a = rem / d1;
+        if (a >= m0 || b >= m1 || c >= m2) continue;
         flat[o] = padded[(((size_t)lo * m0 + a) * m1 + b) * m2 + c];
     }
 }

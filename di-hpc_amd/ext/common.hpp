@@ -119,10 +119,27 @@ inline float loss_scale(std::optional<double> scale, int64_t local_count) {
 class SavedByBuffer {
   public:
     static constexpr size_t kCap = 256;
-    struct Entry { std::vector<Tensor> tensors; double scalar = 0.0; uint64_t seed = 0; uint64_t stamp = 0; };
+    struct Entry {
+        std::vector<Tensor> tensors;
+        double scalar = 0.0;
+        uint64_t seed = 0;
+        uint64_t stamp = 0;
+        // identity of the key buffer and the state of the parked tensors at forward time: an address that
+        // was freed and handed to another tensor must not resolve to the old module's state, and an input modified in
+        // place between forward and backward is an error here exactly as on the native (save_for_backward) path
+        c10::weak_intrusive_ptr<c10::StorageImpl> key_storage{c10::intrusive_ptr<c10::StorageImpl>()};
+        std::vector<uint32_t> versions;
+    };
     void put(const Tensor& key, Entry e) {
         std::lock_guard<std::mutex> lk(mu_);
         e.stamp = ++clock_;
+        e.key_storage = c10::weak_intrusive_ptr<c10::StorageImpl>(key.storage().getWeakStorageImpl());
+        e.versions.clear();
+        for (const Tensor& t : e.tensors) e.versions.push_back(t.defined() ? t._version() : 0);
+        // entries whose module buffer is gone can never be asked for again: release what they pin
+        for (auto it = map_.begin(); it != map_.end();) {
+            if (it->second.key_storage.expired()) it = map_.erase(it); else ++it;
+        }
         map_[key.data_ptr()] = std::move(e);
         if (map_.size() > kCap) {   // drop the oldest half (rare: amortised O(1))
             std::vector<std::pair<uint64_t, void*>> order;
@@ -137,6 +154,14 @@ class SavedByBuffer {
         auto it = map_.find(key.data_ptr());
         TORCH_CHECK(it != map_.end(), what, ": no forward state for this scratch buffer (call the Forward with the "
                     "same module buffers first)");
+        const auto live = it->second.key_storage.lock();
+        TORCH_CHECK(live && live.get() == key.storage().unsafeGetStorageImpl(), what, ": the scratch buffer at this address is "
+                    "not the one the Forward was called with (freed and re-allocated?)");
+        for (size_t i = 0; i < it->second.tensors.size(); ++i) {
+            const Tensor& t = it->second.tensors[i];
+            TORCH_CHECK(!t.defined() || t._version() == it->second.versions[i], what, ": a tensor the backward pass re-reads "
+                        "was modified in place after the Forward");
+        }
         return it->second;
     }
   private:
@@ -155,6 +180,16 @@ inline void check_abi() {
 }
 
 // Common bindings every module carries (tests and tuning scripts use them).
+// `n` consecutive floats of `buf` starting at `offset` as an INDEPENDENT tensor over the same storage (not a view in
+// autograd's sense): several outputs of one autograd node may alias one buffer, and the caller may still modify each of
+// them in place (`loss += ...`) -- narrow() views would raise "Output 0 of ...Backward is a view and is being modified
+// inplace ... returns multiple views" (the reference returns separate module buffers).
+inline at::Tensor alias_of(const at::Tensor& buf, int64_t offset, int64_t n) {
+    at::Tensor t = at::empty({0}, buf.options());
+    t.set_(buf.storage(), buf.storage_offset() + offset, {n}, {1});
+    return t;
+}
+
 inline void bind_common(pybind11::module_& m) {
     check_abi();
     m.def("abi_version", []() { return hpc_rll_abi_version(); });

@@ -45,20 +45,51 @@ void lstm_check_params(const LstmDims& d, const Tensor& c0, const Tensor& bias, 
                 "bias / ln_gamma / ln_beta: wrong number of elements");
 }
 
+// The persistent small-batch kernels (B <= 4) report a co-residency timeout ASYNCHRONOUSLY (a pinned status word,
+// include/hpc_rll_hip.h): the launch that timed out has already returned OK.  What the extension does about it
+// (ADVICE r02): the first LSTM entry point that sees the status clears it -- which retires the persistent path for the
+// rest of the process -- warns that the LSTM results produced since the last synchronisation are invalid, bumps an
+// epoch and RE-RUNS itself on the step kernels; a backward whose forward ran on the persistent path in an older epoch
+// refuses to run (its saved activations may be those of a launch that gave up).  hpc_rll.torch_utils.network.rnn.LSTM
+// (check_persistent=True) closes the remaining window by synchronising after every persistent-path forward.
+std::atomic<int64_t> g_persist_epoch{0};
+constexpr int64_t kPersistMaxB = 4;
+
+bool lstm_recover_from_timeout(const char* what) {
+    if (hpc_rll_async_error() != HPC_RLL_ETIMEOUT) return false;
+    check(hpc_rll_clear_async_error(), "hpc_rll_clear_async_error");
+    g_persist_epoch.fetch_add(1);
+    TORCH_WARN("hpc_rll LSTM: a persistent small-batch kernel gave up waiting for its co-resident workgroups (another process "
+               "is holding the GPU's compute units).  LSTM results produced by this process since its last synchronisation "
+               "are INVALID; ", what, " is re-run on the step kernels, which are used from now on "
+               "(HPC_RLL_LSTM_PERSIST=0 selects them from the start on GPUs shared between processes).");
+    return true;
+}
+
 void lstm_forward_launch(const LstmDims& d, const Tensor& x, const Tensor& h0, const Tensor& c0, const Tensor& wx,
                          const Tensor& wh, const Tensor& bias, const Tensor& gamma, const Tensor& beta, const Tensor& y,
                          const Tensor& hn, const Tensor& cn, const Tensor& ws, double dropout, uint64_t seed) {
-    check(hpc_rll_lstm_forward(fptr(x), fptr(h0), fptr(c0), fptr(wx), fptr(wh), fptr(bias), fptr(gamma), fptr(beta),
-                               fmut(y), fmut(hn), fmut(cn), fmut(ws), (int)d.S, (int)d.B, (int)d.I, (int)d.H, (int)d.L,
-                               (float)dropout, seed, stream_of(d.dev)),
-          "hpc_rll_lstm_forward");
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int rc = hpc_rll_lstm_forward(fptr(x), fptr(h0), fptr(c0), fptr(wx), fptr(wh), fptr(bias), fptr(gamma),
+                                            fptr(beta), fmut(y), fmut(hn), fmut(cn), fmut(ws), (int)d.S, (int)d.B, (int)d.I,
+                                            (int)d.H, (int)d.L, (float)dropout, seed, stream_of(d.dev));
+        if (rc == HPC_RLL_ETIMEOUT && attempt == 0 && lstm_recover_from_timeout("this forward")) continue;
+        check(rc, "hpc_rll_lstm_forward");
+        return;
+    }
 }
 
 struct LstmGrads { Tensor dx, dh0, dc0, dwx, dwh, dbias, dgamma, dbeta; };
 
 void lstm_backward_launch(const LstmDims& d, const Tensor& dy, const Tensor& dhn, const Tensor& dcn, const Tensor& x,
                           const Tensor& h0, const Tensor& c0, const Tensor& wx, const Tensor& wh, const Tensor& gamma,
-                          const Tensor& ws, const LstmGrads& g, double dropout, uint64_t seed) {
+                          const Tensor& ws, const LstmGrads& g, double dropout, uint64_t seed, int64_t fwd_epoch = -1) {
+    // a timeout seen now may be this graph's own forward: its saved activations cannot be trusted
+    const bool recovered = lstm_recover_from_timeout("nothing");
+    TORCH_CHECK(!(d.B <= kPersistMaxB && (recovered || (fwd_epoch >= 0 && fwd_epoch != g_persist_epoch.load()))),
+                "hpc_rll LSTM backward: the forward pass of this graph ran on a persistent small-batch kernel around the time "
+                "one of them timed out; its saved activations may be invalid.  Run the forward pass again (it now uses the "
+                "step kernels).");
     check(hpc_rll_lstm_backward(fptr(dy), fptr(dhn), fptr(dcn), fptr(x), fptr(h0), fptr(c0), fptr(wx), fptr(wh),
                                 fptr(gamma), fmut(ws), fmut(g.dx), fmut(g.dh0), fmut(g.dc0), fmut(g.dwx), fmut(g.dwh),
                                 fmut(g.dbias), fmut(g.dgamma), fmut(g.dbeta), (int)d.S, (int)d.B, (int)d.I, (int)d.H,
@@ -183,6 +214,7 @@ struct LstmFn : public ag::Function<LstmFn> {
         ctx->saved_data["seed"] = seed;
         ctx->saved_data["bias_shape"] = bias.sizes().vec();
         ctx->saved_data["beta_shape"] = beta.sizes().vec();
+        ctx->saved_data["persist_epoch"] = g_persist_epoch.load();
         return {y, hn, cn};
     }
     static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {
@@ -201,7 +233,8 @@ struct LstmFn : public ag::Function<LstmFn> {
         gr.dgamma = at::empty_like(gamma);
         gr.dbeta = new_f32(ctx->saved_data["beta_shape"].toIntVector(), d.dev);
         lstm_backward_launch(d, cont(grads[0]), cont(grads[1]), cont(grads[2]), x, h0, c0, wx, wh, gamma, ws, gr,
-                             ctx->saved_data["dropout"].toDouble(), (uint64_t)ctx->saved_data["seed"].toInt());
+                             ctx->saved_data["dropout"].toDouble(), (uint64_t)ctx->saved_data["seed"].toInt(),
+                             ctx->saved_data["persist_epoch"].toInt());
         return {gr.dx, gr.dwx, gr.dwh, gr.dbias, gr.dgamma, gr.dbeta, gr.dh0, gr.dc0, undef(), undef()};
     }
 };

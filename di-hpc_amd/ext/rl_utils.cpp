@@ -254,7 +254,7 @@ struct VtraceFn : public ag::Function<VtraceFn> {
         vtrace_forward_launch(d, target, behaviour, action, value, reward, weight, losses, ws, gamma, lambda, rho_clip,
                               c_clip, rho_pg_clip, scale);
         ctx->save_for_backward({target, action, ws});
-        return {losses.narrow(0, 0, 1), losses.narrow(0, 1, 1), losses.narrow(0, 2, 1)};
+        return {alias_of(losses, 0, 1), alias_of(losses, 1, 1), alias_of(losses, 2, 1)};
     }
     static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {
         ag::tensor_list out(12);
@@ -384,9 +384,9 @@ struct PpoFn : public ag::Function<PpoFn> {
         ppo_forward_launch(d, ln, lo, action, vn, vo, adv, ret, weight, out5, ws, use_value_clip, clip_ratio, dual_clip,
                            scale);
         ctx->save_for_backward({ln, action, ws});
-        Tensor info = out5.narrow(0, 3, 2);
+        Tensor info = alias_of(out5, 3, 2);
         ctx->mark_non_differentiable({info});
-        return {out5.narrow(0, 0, 1), out5.narrow(0, 1, 1), out5.narrow(0, 2, 1), info};
+        return {alias_of(out5, 0, 1), alias_of(out5, 1, 1), alias_of(out5, 2, 1), info};
     }
     static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {
         ag::tensor_list out(12);

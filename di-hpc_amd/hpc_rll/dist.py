@@ -52,7 +52,8 @@ class _AllReduceSum(torch.autograd.Function):
         ctx.sizes = [t.numel() for t in losses]
         packed = torch.cat([t.reshape(-1) for t in losses])
         all_reduce_losses_(packed, group, True, mean_slots)
-        return tuple(p.view_as(t) for p, t in zip(torch.split(packed, ctx.sizes), losses))
+        # independent tensors (not views of `packed`): the caller may modify a returned loss in place
+        return tuple(p.clone().view_as(t) for p, t in zip(torch.split(packed, ctx.sizes), losses))
 
     @staticmethod
     def backward(ctx, *grads):

@@ -88,8 +88,18 @@ def UnPadding3D(x: Union[torch.Tensor, List[torch.Tensor]], shapes: Union[List, 
 # device layout is ONE flat buffer plus a device vector of lengths.  Same kernels, table built on the device, no host
 # loop and (when ``max_len`` is given) no host synchronisation.
 # ---------------------------------------------------------------------------------------------------------------------
+def _validate_packed(numel: int, lengths: torch.Tensor, max_len, what: str):
+    """The packed entry points trust ``lengths`` / ``max_len`` / ``total`` (no host synchronisation); ``validate=True``
+    checks them with one: every length in [0, max_len] and sum(lengths) == the flat element count."""
+    if lengths.numel() == 0:
+        return
+    lo, hi, tot = int(lengths.min()), int(lengths.max()), int(lengths.sum())
+    if lo < 0 or (max_len is not None and hi > max_len) or (numel is not None and tot != numel):
+        raise ValueError(f"{what}: lengths in [{lo}, {hi}] (max_len {max_len}), sum {tot} (flat elements {numel})")
+
+
 def Padding1DPacked(flat: torch.Tensor, lengths: torch.Tensor, max_len: int = None, value: int = 0, group: int = 1,
-                    group_mode: str = 'oracle', seed: int = None):
+                    group_mode: str = 'oracle', seed: int = None, validate: bool = False):
     """flat (sum(lengths),) fp32, lengths (n,) int64 on the same GPU -> (new_x (n,max_len) fp32, mask (n,max_len) int32).
     Row i of new_x holds flat[offset_i : offset_i + lengths[i]] followed by ``value``.  The offsets are an exclusive scan
     done on the device inside the extension; ``max_len=None`` costs the only host sync (lengths.max()).
@@ -100,7 +110,12 @@ def Padding1DPacked(flat: torch.Tensor, lengths: torch.Tensor, max_len: int = No
     hpc_rll/origin/padding.py:11-50 with its tie rule; 'sample': random cuts) and every bucket is padded to its own
     width by ONE launch.  Returns ``[tuple(new_x_g), tuple(mask_g), tuple(lengths_g), order]``: bucket g holds the
     original rows ``order[cut_g : cut_{g+1}]``, ``lengths_g`` their lengths.  ``max_len`` <= 16384; one host sync (the
-    bucket shapes)."""
+    bucket shapes).
+
+    Preconditions (unchecked unless ``validate=True``, which costs a host sync): 0 <= lengths[i] <= max_len and
+    sum(lengths) == flat.numel(); a longer row is truncated to ``max_len`` columns, a sum beyond ``flat`` reads past it."""
+    if validate:
+        _validate_packed(flat.numel(), lengths, max_len, "Padding1DPacked")
     if group > 1:
         xs, ms, ls, (order,) = hpc_rl_utils.pad1d_packed_grouped(flat, lengths, max_len, value, group, group_mode, seed)
         return [tuple(xs), tuple(ms), tuple(ls), order]
@@ -108,6 +123,10 @@ def Padding1DPacked(flat: torch.Tensor, lengths: torch.Tensor, max_len: int = No
     return new_x, mask
 
 
-def UnPadding1DPacked(x: torch.Tensor, lengths: torch.Tensor, total: int = None) -> torch.Tensor:
-    """Inverse of :func:`Padding1DPacked`: x (n,max_len), lengths (n,) int64 -> flat (sum(lengths),)."""
+def UnPadding1DPacked(x: torch.Tensor, lengths: torch.Tensor, total: int = None, validate: bool = False) -> torch.Tensor:
+    """Inverse of :func:`Padding1DPacked`: x (n,max_len), lengths (n,) int64 -> flat (sum(lengths),).  ``total`` (the sum
+    of the lengths) saves the host sync; elements of a too large ``total`` are left unwritten, lengths beyond
+    ``x.shape[1]`` are not read (``validate=True`` raises instead)."""
+    if validate:
+        _validate_packed(total, lengths, x.shape[1], "UnPadding1DPacked")
     return hpc_rl_utils.unpad1d_packed(x, lengths, total)

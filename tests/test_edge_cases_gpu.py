@@ -255,3 +255,32 @@ def test_loss_ops_capture_into_a_hip_graph():
         assert torch.equal(e, c)
     for e, p in zip(grads_e, (to, v, q, x)):
         assert torch.equal(e, p.grad)
+
+
+def test_loss_outputs_can_be_modified_in_place():
+    """the three V-trace / PPO losses are separate autograd outputs over ONE buffer; they are independent
+    tensors (not views), so `loss += ...` on a returned loss works as it does with the reference's module buffers."""
+    from hpc_rll.rl_utils.ppo import PPO
+    from hpc_rll.rl_utils.vtrace import VTrace
+    g = torch.Generator(device=DEV).manual_seed(2)
+    T, B, N = 6, 40, 5
+    to = torch.randn(T, B, N, device=DEV, generator=g, requires_grad=True)
+    v = torch.randn(T + 1, B, device=DEV, generator=g, requires_grad=True)
+    args = (torch.randn(T, B, N, device=DEV, generator=g), torch.randint(0, N, (T, B), device=DEV, generator=g), v,
+            torch.randn(T, B, device=DEV, generator=g))
+    ref = VTrace(T, B, N)(to, *args)
+    want = [x.item() for x in ref]
+    out = VTrace(T, B, N)(to, *args)
+    pl = out.policy_loss
+    pl += 1.0
+    pl *= 2.0
+    assert abs(pl.item() - 2.0 * (want[0] + 1.0)) < 1e-5 and abs(out.value_loss.item() - want[1]) < 1e-7
+    (pl + out.value_loss).sum().backward()
+    assert torch.isfinite(to.grad).all() and to.grad.abs().max() > 0
+    ln = torch.randn(B, N, device=DEV, generator=g, requires_grad=True)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    loss, info = PPO(B, N)(ln, r(B, N), torch.randint(0, N, (B,), device=DEV, generator=g), r(B), r(B), r(B), r(B))
+    e = loss.entropy_loss
+    e -= 0.5
+    (loss.policy_loss + e).sum().backward()
+    assert torch.isfinite(ln.grad).all()

@@ -176,3 +176,22 @@ def test_run_level_split_equals_element_level_dp_on_long_lists(n, hi, group):
     a = _split_pos_np(nl, group, 0)
     b = _split_pos_np(nl, group, 1)
     assert a == b
+
+
+def test_lstm_loads_a_reference_checkpoint_and_keeps_its_own_small():
+    """the reference LSTM registers ~17 scratch buffers (rnn.py:117-141) that land in its state_dict; a
+    checkpoint written by it must load (strict) into this module, which itself saves the five parameters only."""
+    from hpc_rll.torch_utils.network.rnn import LSTM, _REFERENCE_SCRATCH
+    m = LSTM(4, 2, 3, 5, 2)
+    sd = m.state_dict()
+    assert sorted(sd) == ["bias", "ln_beta", "ln_gamma", "wh", "wx"]
+    orig = {k: v.clone() for k, v in sd.items()}
+    ref_sd = {k: v + 1.0 for k, v in orig.items()}
+    for name in _REFERENCE_SCRATCH:
+        ref_sd[name] = torch.zeros(3)
+    m.load_state_dict(ref_sd, strict=True)
+    assert torch.equal(m.wx, orig["wx"] + 1.0)
+    net = torch.nn.Sequential(torch.nn.Linear(2, 2), LSTM(4, 2, 3, 5, 1))            # nested prefix
+    nsd = net.state_dict()
+    nsd["1.xbuf"] = torch.zeros(1)
+    net.load_state_dict(nsd, strict=True)

@@ -417,20 +417,27 @@ with torch.no_grad():
     bad, _ = m(x, None)                     # the resident workgroups give up waiting for the others
 torch.cuda.synchronize()                    # ... and the HIP context is still alive
 assert NW.async_error() == -4, NW.async_error()
-try:
-    with torch.no_grad():
-        m(x, None)
-except RuntimeError as e:
-    assert "gave up waiting" in str(e), str(e)
-else:
-    raise SystemExit("the sticky asynchronous status was not reported")
-NW.clear_async_error()
+# ADVICE r02: the next LSTM call does not raise -- it acknowledges the status, warns, and RE-RUNS ITSELF on the step kernels
+import warnings
+xg = x.clone().requires_grad_(True)
+with warnings.catch_warnings(record=True) as wlist:
+    warnings.simplefilter("always")
+    again, _ = m(xg, None)
+    torch.cuda.synchronize()
+assert any("gave up waiting" in str(w.message) for w in wlist), [str(w.message) for w in wlist]
 assert NW.async_error() == 0
-with torch.no_grad():
-    again, _ = m(x, None)                   # step kernels from now on
-torch.cuda.synchronize()
-err = ((again - ref).abs().max() / ref.abs().max()).item()
+err = ((again.detach() - ref).abs().max() / ref.abs().max()).item()
 assert err < 1e-5, err
+again.sum().backward()                      # a graph built AFTER the recovery backpropagates normally
+assert torch.isfinite(xg.grad).all()
+# ... and with check_persistent=True the offending call itself is detected and recomputed before it returns
+NW.tune_set(3, 1)
+m2 = LSTM(S, B, I, H, L, check_persistent=True).to(dev)
+m2.load_state_dict(m.state_dict())
+with torch.no_grad():
+    chk, _ = m2(x, None)
+torch.cuda.synchronize()
+assert ((chk - ref).abs().max() / ref.abs().max()).item() < 1e-5
 print("starved-ok", err)
 """
 
@@ -440,8 +447,10 @@ def test_starved_persistent_kernel_reports_instead_of_trapping():
     paths off for the rest of a process): the wait limit is lowered to ~ms through the test hook and most of the device
     (480 of its 512 half-CU slots: waves and LDS) are held for 1.5 s on a second stream, so only part of the persistent grid
     becomes resident.  Those workgroups give
-    up: no trap, the context survives, `async_error()` turns HPC_RLL_ETIMEOUT, the next LSTM call raises RuntimeError,
-    and after `clear_async_error()` the same module runs on the step kernels and reproduces the quiet result."""
+    up: no trap, the context survives, `async_error()` turns HPC_RLL_ETIMEOUT; the next LSTM call acknowledges it, warns
+    that the results since the last synchronisation are invalid, and re-runs itself on the step kernels (no
+    silent garbage from the calls that follow), reproducing the quiet result; a module built with
+    check_persistent=True synchronises and checks inside the call."""
     import os
     import subprocess
     import sys
