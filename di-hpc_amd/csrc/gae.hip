@@ -508,6 +508,83 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, ONE TRAJECTORY PER WAVEFRONT (the mapping BASELINE.json's north_star names; SURVEY.md 7.3 (ii) asked for both
+// mappings to be measured).  A workgroup of 16 waves owns 64 columns and walks T in tiles of 64 steps: the (65 x 64)
+// value rows and (64 x 64) reward rows of a tile are loaded COALESCED along B and staged through LDS, then a wave takes
+// one trajectory (column) at a time -- four per wave -- with its 64 LANES ALONG TIME: delta_t from three conflict-free
+// LDS reads (row stride 65), an inclusive suffix scan of the affine pairs (c_t, delta_t) in log2(64) = 6 wavefront-
+// shuffle steps (the coefficient products are shared by the wave's four trajectories), the carry from the later tile
+// applied through the product, the result written back through LDS and stored coalesced.
+// Kept as a measured alternative (flags bit 4 of hpc_rll_gae_forward_ex), not the shipped mapping: the lane-per-column
+// kernels need ONE fma per element where the shuffle scan needs 6 shuffles + 6 fmas, no LDS round trip of the payload,
+// and their time parallelism (NW*LC = 256-512 steps per barrier) is larger than a 64-step tile's.  Numbers in DESIGN.md
+// section 4.1 (tests/tools/r03_gae_wpt_probe.py).
+// ------------------------------------------------------------------------------------------------
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(1024) void gae_fwd_wpt_kernel(const float* __restrict__ value,
+                                                           const float* __restrict__ reward,
+                                                           float* __restrict__ adv, const float* __restrict__ coef,
+                                                           int T, int B, float gamma) {
+    constexpr int TT = 64, LD = 65;
+    __shared__ float sv[(TT + 1) * LD], sr[TT * LD], so[TT * LD];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long c0 = (long)blockIdx.x * 64;
+    const bool col_ok = c0 + lane < (long)B;
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t1 = T; t1 > 0; t1 -= TT) {
+        const int t0 = t1 - TT;                      // may be negative in the last (earliest) tile
+        // ---- load phase: wave w takes rows w, w+16, ... (lane <-> column: 256-byte coalesced rows)
+        for (int r = w; r <= TT; r += 16) {
+            const int t = t0 + r;
+            if (t >= 0 && col_ok) sv[r * LD + lane] = ld<NTL>(value + (size_t)t * B + c0 + lane);
+        }
+        for (int r = w; r < TT; r += 16) {
+            const int t = t0 + r;
+            if (t >= 0 && col_ok) sr[r * LD + lane] = ld<NTL>(reward + (size_t)t * B + c0 + lane);
+        }
+        __syncthreads();
+        // ---- scan phase: lane <-> time step t0 + lane, wave <-> trajectories 4w .. 4w+3
+        const int t = t0 + lane;
+        const bool valid = t >= 0;
+        float P = valid ? coef[t] : 1.f;
+        float b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * w + k;
+            const float v0 = sv[lane * LD + c], v1 = sv[(lane + 1) * LD + c], rr = sr[lane * LD + c];
+            b[k] = valid ? fmaf(gamma, v1, rr) - v0 : 0.f;
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float an = __shfl_down(P, d, 64);
+            const bool ok = lane + d < 64;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float bn = __shfl_down(b[k], d, 64);
+                if (ok) b[k] = fmaf(P, bn, b[k]);
+            }
+            if (ok) P *= an;
+        }
+        const int first = t0 < 0 ? -t0 : 0;          // the earliest valid lane holds the tile's head
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b[k] = fmaf(P, carry[k], b[k]);
+            carry[k] = __shfl(b[k], first, 64);
+            so[lane * LD + 4 * w + k] = b[k];
+        }
+        __syncthreads();
+        // ---- store phase: coalesced rows
+        for (int r = w; r < TT; r += 16) {
+            const int tt = t0 + r;
+            if (tt >= 0 && col_ok) st<NTS>(adv + (size_t)tt * B + c0 + lane, so[r * LD + lane]);
+        }
+        // the next tile's loads write sv / sr, which this tile's scan phase finished reading before the barrier above;
+        // its scan phase writes `so` only after ITS first barrier, behind this store phase
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward, software-pipelined (round 3): the mirror image of gae_fwd_pf_kernel.  Both gradients are written
 // (grad_value and grad_reward non-null; the dispatcher falls back to gae_bwd_kernel otherwise).  Same arithmetic
 // order as gae_bwd_kernel: bit-identical results.
@@ -911,6 +988,12 @@ extern "C" int hpc_rll_gae_forward_ex(const float* value, const float* reward, f
     if (!aligned(value, 4) || !aligned(reward, 4) || !aligned(adv, 4) || !aligned(coef, 4)) return HPC_RLL_EALIGN;
     const Cfg cfg = choose_cfg(true, T, B, max_vec(B, {value, reward, adv}), vec, lc, nw, flags);
     hipStream_t st = (hipStream_t)stream;
+    if (flags >= 0 && (flags & 16)) {   // one trajectory per wavefront (measured alternative, see gae_fwd_wpt_kernel)
+        const dim3 grid((unsigned)((B + 63) / 64)), block(1024);
+        if (flags & 1) launch(gae_fwd_wpt_kernel<true, true>, grid, block, st, 0, value, reward, adv, coef, T, B, gamma);
+        else launch(gae_fwd_wpt_kernel<false, true>, grid, block, st, 0, value, reward, adv, coef, T, B, gamma);
+        return check_launch();
+    }
     if (cfg.pf) {
         int* lc_ = g_kt.last_cfg[0];
         lc_[0] = cfg.v; lc_[1] = cfg.lc; lc_[2] = cfg.nw; lc_[3] = cfg.flags; lc_[4] = 0; lc_[5] = 1;
