@@ -418,13 +418,9 @@ with torch.no_grad():
 torch.cuda.synchronize()                    # ... and the HIP context is still alive
 assert NW.async_error() == -4, NW.async_error()
 # ADVICE r02: the next LSTM call does not raise -- it acknowledges the status, warns, and RE-RUNS ITSELF on the step kernels
-import warnings
 xg = x.clone().requires_grad_(True)
-with warnings.catch_warnings(record=True) as wlist:
-    warnings.simplefilter("always")
-    again, _ = m(xg, None)
-    torch.cuda.synchronize()
-assert any("gave up waiting" in str(w.message) for w in wlist), [str(w.message) for w in wlist]
+again, _ = m(xg, None)                      # (the warning is a C++ TORCH_WARN on stderr: the parent test looks for it)
+torch.cuda.synchronize()
 assert NW.async_error() == 0
 err = ((again.detach() - ref).abs().max() / ref.abs().max()).item()
 assert err < 1e-5, err
@@ -457,3 +453,4 @@ def test_starved_persistent_kernel_reports_instead_of_trapping():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _STARVED], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "starved-ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "gave up waiting" in r.stderr and "re-run on the step kernels" in r.stderr, r.stderr[-1500:]

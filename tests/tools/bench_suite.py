@@ -66,6 +66,52 @@ def fwd_bwd(make_loss, grads_of):
     return t_f, t_b
 
 
+def timed_graph(fn, n=10, rounds=3):
+    """GPU time per call of `fn` with the host taken out: n calls captured into ONE hipGraph, replayed.  For ops whose
+    kernels take a few microseconds the eager figures above are the host's (torch's autograd engine: ~27 us per
+    backward), not the kernels'."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) / n * 1e-3)
+    return statistics.median(ts)
+
+
+def fwd_bwd_graph(make_loss, grads_of):
+    """forward alone / backward alone as hipGraph replays (see timed_graph)"""
+    t_f = timed_graph(make_loss)
+    loss = make_loss()
+    g = torch.ones_like(loss)
+
+    def bwd():
+        torch.autograd.grad([loss], grads_of, [g], retain_graph=True)
+
+    return t_f, timed_graph(bwd)
+
+
+def add_kernel_times(t_f, bytes_f, t_b, bytes_b):
+    """attach the graph-replay (kernel-bound) readings to the row `report` just appended"""
+    rows[-1].update(fwd_kernel_ms=t_f * 1e3, fwd_kernel_frac=bytes_f / t_f / 1e9 / HBM, bwd_kernel_ms=t_b * 1e3,
+                    bwd_kernel_frac=bytes_b / t_b / 1e9 / HBM)
+    if not QUIET:
+        print(json.dumps(rows[-1]), flush=True)
+
+
 def suite_c3(T=256, B=16384, N=128):
     from hpc_rll.rl_utils.td import TDLambda
     from hpc_rll.rl_utils.upgo import UPGO
@@ -83,6 +129,7 @@ def suite_c3(T=256, B=16384, N=128):
     m = TDLambda(T, B)
     t_f, t_b = fwd_bwd(lambda: m(value, reward, weight), [value])
     report("td_lambda", shape, t_f, 16 * TB, t_b, 8 * TB)
+    add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(value, reward, weight), [value]), (16 * TB, 8 * TB)) for x in pair])
     m = VTrace(T, B, N)
     t_f, t_b = fwd_bwd(lambda: sum(m(target, behaviour, action, value, reward)), [target, value])
     # algorithmic minimum: two logits reads (+ action + O(TB)) forward; logits read + grad write backward
@@ -152,6 +199,8 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     m = QNStepTD(nstep, B, N)
     t_f, t_b = fwd_bwd(lambda: m(q, nq, a, na, reward, done, weight, 0.99)[0], [q])
     report("q_nstep_td", f"B={B} N={N} nstep={nstep}", t_f, B * (2 * 128 + per_sample), t_b, B * (4 * N + 4))
+    add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(q, nq, a, na, reward, done, weight, 0.99)[0], [q]),
+                                         (B * (2 * 128 + per_sample), B * (4 * N + 4))) for x in pair])
     del q, nq
 
     d = torch.softmax(torch.randn(B, N, n_atom, device=dev, generator=g), -1).requires_grad_(True)
@@ -160,6 +209,9 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     t_f, t_b = fwd_bwd(lambda: m(d, nd, a, na, reward, done, weight, 0.99, -10.0, 10.0)[0], [d])
     report("dist_nstep_td", f"B={B} N={N} atoms={n_atom}", t_f, B * (2 * line(4 * n_atom) + 128 + per_sample + 4 * n_atom),
            t_b, B * (4 * N * n_atom + 4 * n_atom))
+    add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(d, nd, a, na, reward, done, weight, 0.99, -10.0, 10.0)[0], [d]),
+                                         (B * (2 * line(4 * n_atom) + 128 + per_sample + 4 * n_atom), B * (4 * N * n_atom + 4 * n_atom)))
+                       for x in pair])
     del d, nd
 
     Bi = B // 4
@@ -172,6 +224,9 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
                                  weight[:Bi].contiguous())[0], [qi])
     report("iqn_nstep_td", f"tau=tau'={tau} B={Bi} N={N}", t_f, Bi * (2 * tau * 128 + 8 * tau + per_sample), t_b,
            Bi * (4 * tau * N + 4 * tau))
+    ri, di, wi = reward[:, :Bi].contiguous(), done[:Bi].contiguous(), weight[:Bi].contiguous()
+    add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(qi, nqi, ai, nai, ri, di, rq, 0.99, 1.0, wi)[0], [qi]),
+                                         (Bi * (2 * tau * 128 + 8 * tau + per_sample), Bi * (4 * tau * N + 4 * tau))) for x in pair])
     del qi, nqi
 
     qq = torch.randn(B, N, tau, device=dev, generator=g, requires_grad=True)
@@ -180,6 +235,8 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     t_f, t_b = fwd_bwd(lambda: m(qq, nqq, a, na, reward, done, 0.99, weight)[0], [qq])
     report("qrdqn_nstep_td", f"B={B} N={N} tau={tau}", t_f, B * (2 * line(4 * tau) + per_sample + 4 * tau), t_b,
            B * (4 * N * tau + 4 * tau))
+    add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(qq, nqq, a, na, reward, done, 0.99, weight)[0], [qq]),
+                                         (B * (2 * line(4 * tau) + per_sample + 4 * tau), B * (4 * N * tau + 4 * tau))) for x in pair])
 
 
 def suite_gemm():
