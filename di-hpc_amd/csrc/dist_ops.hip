@@ -31,26 +31,27 @@ inline int last_error() {
 }
 
 // n-step discounted reward sum R = sum_t gamma^t r[t, b] for S samples at once, in the SAME order of operations as the
-// plain loop `R = fmaf(f, r_t, R); f *= gamma` -- but the loads of four time steps x S samples are all issued before the
+// plain loop `R = fmaf(f, r_t, R); f *= gamma` -- but the loads of four (one sample: eight) time steps x S samples are all issued before the
 // first use.  In a loop with a run-time trip count the compiler waits for every load before the fma that consumes it: the
 // plain form costs one dependent memory round trip PER STEP (nstep = 5: five round trips before the sample's rows can
 // even be addressed), which is what these per-sample kernels were bound by at large batch.
 template <int S>
 __device__ __forceinline__ void nstep_returns(const float* __restrict__ reward, int B, int nstep, float gamma,
                                               const long (&bb)[S], float (&R)[S]) {
+    constexpr int CH = S == 1 ? 8 : 4;          // time steps requested together (x S samples)
 #pragma unroll
     for (int s = 0; s < S; ++s) R[s] = 0.f;
     float f = 1.f;
-    for (int t0 = 0; t0 < nstep; t0 += 4) {
-        float r[4][S];
+    for (int t0 = 0; t0 < nstep; t0 += CH) {
+        float r[CH][S];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < CH; ++k) {
             const int t = t0 + k < nstep ? t0 + k : nstep - 1;     // clamped: the load is unconditional
 #pragma unroll
             for (int s = 0; s < S; ++s) r[k][s] = reward[(size_t)t * B + bb[s]];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < CH; ++k) {
             if (t0 + k < nstep) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) R[s] = fmaf(f, r[k][s], R[s]);
@@ -491,13 +492,13 @@ extern "C" int hpc_rll_dist_nstep_td_forward(const float* dist, const float* nex
     if (!dist || !next_n_dist || !action || !next_n_action || (nstep && !reward) || !done || !td_err || !buf ||
         !partials)
         return HPC_RLL_EINVAL;
-    int blocks = (B + 3) / 4;
+    const bool multi = n_atom <= 64 && B >= 32768;   // 4 samples per wave once every SIMD still gets >= 2 waves
+    const int blocks = multi ? (B + 15) / 16 : (B + 3) / 4;
     // delta_z is a python double in the oracle, rounded to fp32 when it meets the fp32 tensor
     const float dz = (float)(((double)v_max - (double)v_min) / (double)(n_atom - 1));
-    const ScanFold fold = make_fold(st, 1, &scale, loss);
+    const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);
     const float gamma_n = (float)pow((double)gamma, (double)nstep);
-    if (n_atom <= 64 && B >= 32768) {          // 4 samples per wave once every SIMD still gets >= 2 waves
-        blocks = (B + 15) / 16;
+    if (multi) {
         hipLaunchKernelGGL(dist_nstep_fwd64_kernel<4>, dim3(blocks), dim3(256), 0, st, dist, next_n_dist, action,
                            next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma, gamma_n,
                            v_min, v_max, dz, scale, fold);
@@ -537,10 +538,10 @@ extern "C" int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_
     int blocks = (B + 3) / 4;
     const float gamma_n = (float)pow((double)gamma, (double)nstep);
     const int gmax = tau > tau_prime ? tau : tau_prime;
-    const ScanFold fold = make_fold(st, 1, &scale, loss);
+    if (gmax <= 64) blocks = (B + 4 * (64 / group_lanes(gmax)) - 1) / (4 * (64 / group_lanes(gmax)));
+    const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);
     if (gmax <= 64) {
         const int G = group_lanes(gmax);
-        blocks = (B + 4 * (64 / G) - 1) / (4 * (64 / G));
 #define HPC_RLL_IQN_G(G_)                                                                                               \
         if (G == G_)                                                                                                    \
             hipLaunchKernelGGL(iqn_fwd_group_kernel<G_>, dim3(blocks), dim3(256), 0, st, q, next_n_q, action,            \
@@ -585,10 +586,10 @@ extern "C" int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_
         return HPC_RLL_EINVAL;
     int blocks = (B + 3) / 4;
     const float gamma_n = (float)pow((double)gamma, (double)nstep);
-    const ScanFold fold = make_fold(st, 1, &scale, loss);
+    if (tau <= 64) blocks = (B + 4 * (64 / group_lanes(tau)) - 1) / (4 * (64 / group_lanes(tau)));
+    const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);
     if (tau <= 64) {
         const int G = group_lanes(tau);
-        blocks = (B + 4 * (64 / G) - 1) / (4 * (64 / G));
 #define HPC_RLL_QR_G(G_)                                                                                              \
         if (G == G_)                                                                                                  \
             hipLaunchKernelGGL(qrdqn_fwd_group_kernel<G_>, dim3(blocks), dim3(256), 0, st, q, next_n_q, action,        \

@@ -230,7 +230,7 @@ extern "C" int hpc_rll_ppo_forward(const float* logits_new, const float* logits_
     const int blocks = (B + 255) / 256;
     // approx_kl and clipfrac are plain (unweighted) means over the LOCAL batch: scale by 1/B
     const float sc[5] = {scale, 0.5f * scale, scale, 1.f / (float)B, 1.f / (float)B};
-    const ScanFold fold = make_fold(st, 5, sc, out5);
+    const ScanFold fold = make_fold(st, 5, sc, out5, blocks);
     hipLaunchKernelGGL(sample_kernel<PpoOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials, fold);
     rc = last_error();
     if (rc || fold.out) return rc;
@@ -272,7 +272,7 @@ extern "C" int hpc_rll_q_nstep_td_forward(const float* q, const float* next_n_q,
     QNStepOp op{q, next_n_q, action, next_n_action, reward, done, weight, td_err, grad_buf,
                 nstep, B, N, gamma, (float)pow((double)gamma, (double)nstep), scale, rescale};
     const int blocks = (B + 255) / 256;
-    const ScanFold fold = make_fold(st, 1, &scale, loss);
+    const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);
     hipLaunchKernelGGL(sample_kernel<QNStepOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials, fold);
     const int rc = last_error();
     if (rc || fold.out) return rc;

@@ -82,7 +82,7 @@ inline unsigned* scan_ticket(hipStream_t st) {
 template <class Op, bool ALLOW_V2>
 inline int scan_and_finalize(const Op& op, const ScanCfg& c, int T, int B, float* partials, int nacc, const float* scale,
                              float* out, hipStream_t st) {
-    const ScanFold fold = make_fold(st, nacc, scale, out);
+    const ScanFold fold = make_fold(st, nacc, scale, out, (long)scan_grid(c, B));
     launch_colscan<Op, ALLOW_V2>(op, c, T, B, partials, st, fold);
     const int rc = last_error();
     if (rc || fold.out) return rc;
@@ -269,9 +269,9 @@ struct UpgoOp {
 
 }  // namespace
 
-ScanFold make_fold(hipStream_t st, int nacc, const float* scale, float* out) {
+ScanFold make_fold(hipStream_t st, int nacc, const float* scale, float* out, long grid) {
     ScanFold fold{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
-    if (nacc < 1 || nacc > 8) return fold;
+    if (nacc < 1 || nacc > 8 || grid > kFoldMaxGrid) return fold;
     fold.ticket = scan_ticket(st);
     if (!fold.ticket) return fold;
     fold.out = out;
