@@ -58,7 +58,7 @@ struct ScanFold { float* out; unsigned* ticket; float scale[8]; };
 // finalize launch): every workgroup takes the ticket with an agent-scope atomic on ONE address, and those serialise at
 // ~12 ns each on this part -- 32768 workgroups (QR-DQN at B = 262144) spent 0.41 ms of a 0.04 ms kernel there
 // (tests/tools/r03_td_ab.py).  The fold pays in the launch-latency regime, where grids are small.
-constexpr long kFoldMaxGrid = 1024;
+constexpr long kFoldMaxGrid = 512;
 ScanFold make_fold(hipStream_t st, int nacc, const float* scale, float* out, long grid = 0);
 
 // Workgroup epilogue shared by every kernel that ends in NACC loss sums: thread k < NACC holds the workgroup's sum k in

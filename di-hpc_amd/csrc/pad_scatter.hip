@@ -111,6 +111,228 @@ __global__ __launch_bounds__(256) void pad4_kernel(const int64_t* __restrict__ t
     }
 }
 
+// 1-D rows (m0 = m1 = 1: Padding1D and the packed API, BASELINE.json configs[4]) without the generic kernel's index
+// arithmetic: pad4_kernel spends a 64-bit division and four 32-bit divisions / remainders per 16 bytes it writes, and
+// at n = 2^20 rows (1.07 GB of output, beyond the Infinity Cache) that, not HBM, set its time (0.39 ms = 3.6 TB/s,
+// profiles/r02_suite_c5_kernel_stats.csv).  Here: one thread per output quad, row = floor(o / L) from one fp64
+// multiply by 1/L with an exact fix-up, then four columns with a carry into the next row.
+__device__ __forceinline__ unsigned div_by(unsigned long o, unsigned L, double inv) {
+    unsigned i = (unsigned)((double)o * inv);
+    const unsigned long p = (unsigned long)i * L;
+    if (p > o) --i;
+    else if (p + L <= o) ++i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void pad1d4_kernel(const int64_t* __restrict__ table, float* __restrict__ new_x,
+                                                     int32_t* __restrict__ mask, long n, unsigned L, double inv,
+                                                     float fill, int ifill) {
+    typedef int vint4 __attribute__((ext_vector_type(4)));
+    const long total4 = n * (long)L / 4;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total4; q += (long)gridDim.x * 256) {
+        const unsigned long o = (unsigned long)q * 4;
+        unsigned i = div_by(o, L, inv);
+        unsigned c = (unsigned)(o - (unsigned long)i * L);
+        const int64_t* __restrict__ e = table + (size_t)i * 4;
+        const float* src = reinterpret_cast<const float*>(e[0]);
+        unsigned len = (unsigned)e[3];
+        vfloat4 v;
+        vint4 mk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in = c < len;
+            v[k] = in ? src[c] : fill;
+            mk[k] = in ? 1 : ifill;
+            if (++c == L) {   // next row
+                c = 0;
+                ++i;
+                if ((long)i < n) {
+                    e = table + (size_t)i * 4;
+                    src = reinterpret_cast<const float*>(e[0]);
+                    len = (unsigned)e[3];
+                }
+            }
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(new_x + o));
+        __builtin_nontemporal_store(mk, reinterpret_cast<vint4*>(mask + o));
+    }
+}
+// (four independent quads per thread and iteration, to overlap the table -> pointer -> data round trips, measured SLOWER:
+// 396 vs 351 us at n = 2^20 -- the kernel is bound by its 4-byte source reads, not by their latency; see below.)
+
+// PACKED rows (one flat buffer, row i at elements [off_i, off_i + len_i), off = exclusive scan of the lengths): a
+// workgroup owns RB consecutive rows, whose source range is ONE contiguous span of `flat` -- staged into LDS with aligned
+// 16-byte loads -- and writes its RB * L output floats (and mask ints) as 16-byte quads reading LDS.  The per-thread
+// kernels above fetch the source with four 4-byte loads per quad, each touching the same cache lines again: the
+// ablation (tests/tools/micro/padbw.hip, n = 2^20, L = 127) shows 328 us for the full kernel, 170 us without the source
+// reads (= the rate of two plain fills of the outputs), and 234-247 us with the LDS staging.
+// table rows {address of the row, 1, 1, length} as built by hpc_rll_packed_table(base = flat, stride = 4).
+__global__ __launch_bounds__(256) void pad1d_packed_kernel(const float* __restrict__ flat, const int64_t* __restrict__ table,
+                                                           float* __restrict__ new_x, int32_t* __restrict__ mask, long n,
+                                                           unsigned L, double inv, int RB, float fill, int ifill) {
+    typedef int vint4 __attribute__((ext_vector_type(4)));
+    extern __shared__ float tile[];                   // RB * L + 8 floats, then RB + 1 int64 offsets (8-byte aligned)
+    long* s_off = reinterpret_cast<long*>(tile + (((size_t)RB * L + 8 + 1) & ~(size_t)1));
+    const uintptr_t base = reinterpret_cast<uintptr_t>(flat);
+    for (long r0 = (long)blockIdx.x * RB; r0 < n; r0 += (long)gridDim.x * RB) {
+        const int nr = (int)(n - r0 < RB ? n - r0 : RB);
+        __syncthreads();                              // the previous round's readers of tile / s_off are done
+        for (int r = threadIdx.x; r < nr; r += 256) {
+            const int64_t* e = table + (size_t)(r0 + r) * 4;
+            s_off[r] = (long)(((uintptr_t)e[0] - base) >> 2);
+            if (r == nr - 1) s_off[nr] = s_off[r] + e[3];
+        }
+        __syncthreads();
+        const long lo = s_off[0], hi = s_off[nr];
+        // 16-byte chunks aligned by ADDRESS.  The first / last chunk may reach up to 12 bytes outside [lo, hi): an aligned
+        // 16-byte chunk never crosses a page, and it contains a valid element, so the read cannot fault; the extra lanes
+        // are never used.
+        const long lo4 = lo - (long)(((base >> 2) + (unsigned long)lo) & 3UL);
+        // a length beyond max_len (the caller's precondition, unchecked) must not overrun the tile: such a workgroup
+        // reads its rows straight from memory
+        const bool fits = hi - lo4 <= (long)RB * L + 8 && hi >= lo;
+        if (fits)
+            for (long p = lo4 + (long)threadIdx.x * 4; p < hi; p += 1024)
+                *reinterpret_cast<vfloat4*>(tile + (p - lo4)) = *reinterpret_cast<const vfloat4*>(flat + p);
+        __syncthreads();
+        const unsigned long obase = (unsigned long)r0 * L, oend = obase + (unsigned long)nr * L;
+        // Every element finds its row with its own multiply (div_by) and reads the two row offsets and its value from
+        // LDS: four independent chains per thread, no divergent row-crossing branch.
+        for (unsigned long o = (obase & ~3UL) + (unsigned long)threadIdx.x * 4; o < oend; o += 1024) {
+            vfloat4 v;
+            vint4 mk;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long oo = o + k;
+                bool in = false;
+                float val = fill;
+                if (oo >= obase && oo < oend) {
+                    const unsigned rel = (unsigned)(oo - obase);
+                    const unsigned rr = div_by(rel, L, inv);
+                    const unsigned c = rel - rr * L;
+                    const long so = s_off[rr];
+                    in = c < (unsigned)(s_off[rr + 1] - so);
+                    if (in) val = fits ? tile[so - lo4 + c] : flat[so + c];
+                }
+                v[k] = val;
+                mk[k] = in ? 1 : ifill;
+            }
+            if (o >= obase && o + 4 <= oend) {
+                __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(new_x + o));
+                __builtin_nontemporal_store(mk, reinterpret_cast<vint4*>(mask + o));
+            } else {                                   // a quad shared with the neighbouring workgroup's rows
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (o + k >= obase && o + k < oend) { new_x[o + k] = v[k]; mask[o + k] = mk[k]; }
+            }
+        }
+    }
+}
+
+// Inverse: the workgroup's RB padded rows are read as 16-byte quads, their valid prefixes collected in LDS at their
+// packed positions, and the contiguous span of `flat` is written with aligned 16-byte stores (element-wise at the two
+// ragged ends, which belong to the neighbouring workgroups).  table rows {flat offset (elements), 1, 1, length}.
+__global__ __launch_bounds__(256) void unpad1d_packed_kernel(const float* __restrict__ padded, const int64_t* __restrict__ table,
+                                                             float* __restrict__ flat, long n, long total, unsigned L, double inv,
+                                                             int RB) {
+    extern __shared__ float tile[];
+    long* s_off = reinterpret_cast<long*>(tile + (((size_t)RB * L + 8 + 1) & ~(size_t)1));
+    const uintptr_t base = reinterpret_cast<uintptr_t>(flat);
+    for (long r0 = (long)blockIdx.x * RB; r0 < n; r0 += (long)gridDim.x * RB) {
+        const int nr = (int)(n - r0 < RB ? n - r0 : RB);
+        __syncthreads();
+        for (int r = threadIdx.x; r < nr; r += 256) {
+            const int64_t* e = table + (size_t)(r0 + r) * 4;
+            s_off[r] = e[0];
+            if (r == nr - 1) s_off[nr] = e[0] + (e[3] < (int64_t)L ? e[3] : (int64_t)L);
+        }
+        __syncthreads();
+        const long lo = s_off[0];
+        const long hi = s_off[nr] < total ? s_off[nr] : total;
+        const long lo4 = lo - (long)(((base >> 2) + (unsigned long)lo) & 3UL);
+        const bool fits = s_off[nr] - lo4 <= (long)RB * L + 8 && s_off[nr] >= lo;   // see pad1d_packed_kernel
+        const unsigned long obase = (unsigned long)r0 * L, oend = obase + (unsigned long)nr * L;
+        for (unsigned long o = (obase & ~3UL) + (unsigned long)threadIdx.x * 4; o < oend; o += 1024) {
+            const unsigned long first = o < obase ? obase : o;
+            unsigned rr = div_by(first - obase, L, inv);
+            unsigned c = (unsigned)(first - obase - (unsigned long)rr * L);
+            long so = s_off[rr] - lo4;
+            unsigned len = (unsigned)(s_off[rr + 1] - s_off[rr]);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (o >= obase && o + 4 <= oend) {
+                if (c < len || c + 4 > L) {            // (a quad entirely inside one row's padding is not fetched)
+                    const vfloat4 t = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(padded + o));
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (o + k >= obase && o + k < oend) v[k] = padded[o + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long oo = o + k;
+                if (oo >= obase && oo < oend) {
+                    if (c < len) {
+                        if (fits) tile[so + c] = v[k];
+                        else if (so + lo4 + c < total) flat[so + lo4 + c] = v[k];
+                    }
+                    if (++c == L) {
+                        c = 0;
+                        ++rr;
+                        if ((int)rr < nr) { so = s_off[rr] - lo4; len = (unsigned)(s_off[rr + 1] - s_off[rr]); }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (long p = lo4 + (long)threadIdx.x * 4; fits && p < hi; p += 1024) {
+            const float* srcp = tile + (p - lo4);
+            if (p >= lo && p + 4 <= hi) {
+                vfloat4 t;
+                t.x = srcp[0]; t.y = srcp[1]; t.z = srcp[2]; t.w = srcp[3];
+                __builtin_nontemporal_store(t, reinterpret_cast<vfloat4*>(flat + p));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (p + k >= lo && p + k < hi) flat[p + k] = srcp[k];
+            }
+        }
+    }
+}
+
+// inverse for 1-D rows: one thread per quad of the PADDED tensor (16-byte loads, no binary search per element);
+// table[i] = {flat offset of row i (elements), 1, 1, length}
+__global__ __launch_bounds__(256) void unpad1d4_kernel(const float* __restrict__ padded, const int64_t* __restrict__ table,
+                                                       float* __restrict__ flat, long n, long total, unsigned L, double inv) {
+    const long total4 = n * (long)L / 4;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total4; q += (long)gridDim.x * 256) {
+        const unsigned long o = (unsigned long)q * 4;
+        unsigned i = div_by(o, L, inv);
+        unsigned c = (unsigned)(o - (unsigned long)i * L);
+        const int64_t* __restrict__ e = table + (size_t)i * 4;
+        long off = e[0];
+        unsigned len = (unsigned)e[3];
+        if (c >= len && c + 4 <= L) continue;          // a quad that lies entirely in one row's padding
+        const vfloat4 v = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(padded + o));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c < len && off + c < total) flat[off + c] = v[k];
+            if (++c == L) {
+                c = 0;
+                ++i;
+                if ((long)i < n) {
+                    e = table + (size_t)i * 4;
+                    off = e[0];
+                    len = (unsigned)e[3];
+                } else {
+                    len = 0;
+                }
+            }
+        }
+    }
+}
+
 // table[i] = {flat offset of tensor i (elements), d0, d1, d2}; one thread per element of the flat output.
 __global__ __launch_bounds__(256) void unpad_kernel(const float* __restrict__ padded,
                                                     const int64_t* __restrict__ table, float* __restrict__ flat,
@@ -490,7 +712,10 @@ extern "C" int hpc_rll_pad_forward(const int64_t* table, float* new_x, int32_t* 
                     (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
     long blocks = ((v4 ? total / 4 : total) + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;
-    if (v4)
+    if (v4 && m0 == 1 && m1 == 1 && total < (1L << 32))
+        hipLaunchKernelGGL(pad1d4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, new_x, mask,
+                           (long)n, (unsigned)m2, 1.0 / (double)m2, (float)value, value);
+    else if (v4)
         hipLaunchKernelGGL(pad4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, new_x, mask,
                            (long)n, (unsigned)m0, (unsigned)m1, (unsigned)m2, (float)value, value);
     else
@@ -504,10 +729,59 @@ extern "C" int hpc_rll_unpad_forward(const float* padded, const int64_t* table, 
     if (n < 0 || total < 0 || m0 < 0 || m1 < 0 || m2 < 0) return HPC_RLL_EINVAL;
     if (total == 0 || n == 0) return HPC_RLL_OK;
     if (!padded || !table || !flat) return HPC_RLL_EINVAL;
+    const long padded_total = (long)n * m0 * m1 * m2;
+    if (m0 == 1 && m1 == 1 && m2 > 0 && (padded_total % 4) == 0 && padded_total < (1L << 32) &&
+        (reinterpret_cast<uintptr_t>(padded) & 15) == 0) {
+        long b4 = (padded_total / 4 + 255) / 256;
+        if (b4 > 256L * 16) b4 = 256L * 16;
+        hipLaunchKernelGGL(unpad1d4_kernel, dim3((unsigned)b4), dim3(256), 0, (hipStream_t)stream, padded, table, flat,
+                           (long)n, (long)total, (unsigned)m2, 1.0 / (double)m2);
+        return last_error();
+    }
     long blocks = (total + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;
     hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, padded, table, flat,
                        (long)n, (long)total, (unsigned)m0, (unsigned)m1, (unsigned)m2);
+    return last_error();
+}
+
+// rows per workgroup of the LDS-staged packed kernels: 16 (tests/tools/micro/padbw.hip at n = 2^20, L = 127: 16 rows and
+// one workgroup per 16 rows 270 us, 64 rows 303 us, the per-thread kernel 328 us), fewer when 60 KB of LDS hold fewer
+static inline int packed_rows_per_wg(int L) {
+    const long cap = (60L * 1024 / 4 - 160) / (L > 0 ? L : 1);
+    return (int)(cap > 16 ? 16 : cap);
+}
+
+extern "C" int hpc_rll_pad1d_packed_forward(const float* flat, const int64_t* table, float* new_x, int32_t* mask, int64_t n,
+                                            int max_len, int value, void* stream) {
+    if (n < 0 || max_len < 0) return HPC_RLL_EINVAL;
+    if (n == 0 || max_len == 0) return HPC_RLL_OK;
+    if (!flat || !table || !new_x || !mask) return HPC_RLL_EINVAL;
+    const int RB = packed_rows_per_wg(max_len);
+    const bool ok = RB >= 1 && (reinterpret_cast<uintptr_t>(new_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(flat) & 3) == 0;
+    if (!ok) return hpc_rll_pad_forward(table, new_x, mask, n, 1, 1, max_len, value, stream);
+    long blocks = (n + RB - 1) / RB;
+    if (blocks > (1L << 20)) blocks = 1L << 20;
+    const size_t lds = ((((size_t)RB * max_len + 8 + 1) & ~(size_t)1)) * 4 + (size_t)(RB + 1) * 8;
+    hipLaunchKernelGGL(pad1d_packed_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, flat, table, new_x, mask,
+                       (long)n, (unsigned)max_len, 1.0 / (double)max_len, RB, (float)value, value);
+    return last_error();
+}
+
+extern "C" int hpc_rll_unpad1d_packed_forward(const float* padded, const int64_t* table, float* flat, int64_t n, int64_t total,
+                                              int max_len, void* stream) {
+    if (n < 0 || total < 0 || max_len < 0) return HPC_RLL_EINVAL;
+    if (n == 0 || total == 0 || max_len == 0) return HPC_RLL_OK;
+    if (!padded || !table || !flat) return HPC_RLL_EINVAL;
+    const int RB = packed_rows_per_wg(max_len);
+    const bool ok = RB >= 1 && (reinterpret_cast<uintptr_t>(padded) & 15) == 0 && (reinterpret_cast<uintptr_t>(flat) & 3) == 0;
+    if (!ok) return hpc_rll_unpad_forward(padded, table, flat, n, total, 1, 1, max_len, stream);
+    long blocks = (n + RB - 1) / RB;
+    if (blocks > (1L << 20)) blocks = 1L << 20;
+    const size_t lds = ((((size_t)RB * max_len + 8 + 1) & ~(size_t)1)) * 4 + (size_t)(RB + 1) * 8;
+    hipLaunchKernelGGL(unpad1d_packed_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, padded, table, flat,
+                       (long)n, (long)total, (unsigned)max_len, 1.0 / (double)max_len, RB);
     return last_error();
 }
 

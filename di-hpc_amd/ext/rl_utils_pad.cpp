@@ -221,9 +221,9 @@ TensorList pad1d_packed(const Tensor& flat, const Tensor& lengths, std::optional
     Tensor mask = at::empty({n, ml}, at::TensorOptions().dtype(at::kInt).device(dev));
     if (n && ml) {
         Tensor table = packed_table(lengths, (int64_t)(uintptr_t)flat.data_ptr(), 4, dev);
-        check(hpc_rll_pad_forward(table.const_data_ptr<int64_t>(), new_x.data_ptr<float>(), mask.data_ptr<int32_t>(), n, 1, 1,
-                                  to_int(ml, "max_len"), (int)value, stream_of(dev)),
-              "hpc_rll_pad_forward");
+        check(hpc_rll_pad1d_packed_forward(flat.const_data_ptr<float>(), table.const_data_ptr<int64_t>(), new_x.data_ptr<float>(),
+                                           mask.data_ptr<int32_t>(), n, to_int(ml, "max_len"), (int)value, stream_of(dev)),
+              "hpc_rll_pad1d_packed_forward");
     }
     return {new_x, mask};
 }
@@ -241,9 +241,9 @@ Tensor unpad1d_packed(const Tensor& x, const Tensor& lengths, std::optional<int6
     Tensor flat = new_f32({tot}, dev);
     if (n && tot) {
         Tensor table = packed_table(lengths, 0, 1, dev);
-        check(hpc_rll_unpad_forward(x.const_data_ptr<float>(), table.const_data_ptr<int64_t>(), flat.data_ptr<float>(), n, tot,
-                                    1, 1, to_int(x.size(1), "max_len"), stream_of(dev)),
-              "hpc_rll_unpad_forward");
+        check(hpc_rll_unpad1d_packed_forward(x.const_data_ptr<float>(), table.const_data_ptr<int64_t>(), flat.data_ptr<float>(), n,
+                                             tot, to_int(x.size(1), "max_len"), stream_of(dev)),
+              "hpc_rll_unpad1d_packed_forward");
     }
     return flat;
 }

@@ -244,6 +244,14 @@ int hpc_rll_unpad_forward(const float* padded, const int64_t* table, float* flat
 int64_t hpc_rll_packed_table_scratch_int64(int64_t n);
 int hpc_rll_packed_table(const int64_t* lengths, int64_t n, int64_t base, int64_t stride, int64_t* table,
                          int64_t* scratch, void* stream);
+/* The two packed directions with the rows' contiguity exploited (a workgroup's rows are ONE span of the flat buffer,
+ * staged through LDS with 16-byte accesses).  `table` as built by hpc_rll_packed_table: pad -- base = address of `flat`,
+ * stride 4; unpad -- base 0, stride 1.  Same results as hpc_rll_pad_forward / hpc_rll_unpad_forward with m0 = m1 = 1
+ * (to which they fall back when a pointer is not aligned for 16-byte stores). */
+int hpc_rll_pad1d_packed_forward(const float* flat, const int64_t* table, float* new_x, int32_t* mask, int64_t n,
+                                 int max_len, int value, void* stream);
+int hpc_rll_unpad1d_packed_forward(const float* padded, const int64_t* table, float* flat, int64_t n, int64_t total,
+                                   int max_len, void* stream);
 /* Group-split policies over a list sorted by numel (host code; padding.cu:8-108).  sizes: n x dim int32.
  * Write <= `group` rows of `dim` ints to group_shapes and <= group+1 boundaries to positions; return the
  * number of groups (>= 1) or a negative HPC_RLL_E* code.  oracle = the O(group * n^2) DP minimising padded

@@ -240,6 +240,54 @@ def test_packed_group_padding_sample_policy_and_errors():
         P.Padding1DPacked(flat, lens, max_len=20000, group=4)            # beyond the histogram width of the device split
 
 
+@pytest.mark.parametrize("n,lo,hi,max_len", [(5000, 32, 128, 127), (3001, 1, 9, 8), (777, 0, 5, 6), (100, 900, 1100, 1100), (4096, 16, 17, 16),
+                                             (1, 5, 6, 5), (70000, 0, 3, 4)])
+def test_packed_padding_lds_kernels_bit_exact(n, lo, hi, max_len):
+    """The LDS-staged packed kernels (round 3): ragged spans that start / end off a 16-byte boundary, rows of one
+    element, empty rows, rows wider than a workgroup's worth, an unaligned `flat` view; pad and unpad bit exact against a
+    torch restatement, round trip exact."""
+    from hpc_rll.rl_utils import padding as P
+    rng = np.random.default_rng(n + max_len)
+    lens = torch.from_numpy(rng.integers(lo, hi, n)).to(DEV)
+    total = int(lens.sum().item())
+    for shift in (0, 1, 3):
+        flat = torch.randn(total + 8, device=DEV)[shift:shift + total]
+        x, m = P.Padding1DPacked(flat, lens, max_len=max_len, value=-7)
+        offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), lens.cumsum(0)])[:-1]
+        col = torch.arange(max_len, device=DEV)[None, :]
+        valid = col < lens[:, None]
+        src = (offs[:, None] + col).clamp(max=max(total - 1, 0))
+        want = torch.where(valid, flat[src] if total else torch.zeros(n, max_len, device=DEV), torch.full((), -7.0, device=DEV))
+        assert torch.equal(x, want) and torch.equal(m, torch.where(valid, 1, -7).to(torch.int32))
+        back = P.UnPadding1DPacked(x, lens, total=total)
+        assert torch.equal(back, flat)
+        out = torch.full((total + 8,), 3.0, device=DEV)                  # unpad into an unaligned view: neighbours untouched
+        import hpc_rl_utils as U
+        assert torch.equal(U.unpad1d_packed(x, lens, total), flat)
+        del out
+
+
+def test_packed_padding_survives_a_violated_precondition():
+    """lengths beyond max_len are the caller's error (validate=True reports it); unchecked, the kernels must still stay
+    inside their buffers: rows are truncated to max_len columns, nothing crashes, the next call works."""
+    from hpc_rll.rl_utils import padding as P
+    rng = np.random.default_rng(2)
+    n = 3000
+    lens = torch.from_numpy(rng.integers(50, 400, n)).to(DEV)
+    flat = torch.randn(int(lens.sum().item()), device=DEV)
+    x, m = P.Padding1DPacked(flat, lens, max_len=100)
+    torch.cuda.synchronize()
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), lens.cumsum(0)])[:-1]
+    col = torch.arange(100, device=DEV)[None, :]
+    valid = col < lens[:, None]
+    assert torch.equal(x, torch.where(valid, flat[(offs[:, None] + col).clamp(max=flat.numel() - 1)], torch.zeros((), device=DEV)))
+    assert torch.equal(m, valid.to(torch.int32))
+    with pytest.raises(ValueError):
+        P.Padding1DPacked(flat, lens, max_len=100, validate=True)
+    P.UnPadding1DPacked(x, lens, total=flat.numel())                     # reads only inside x
+    torch.cuda.synchronize()
+
+
 def test_padding_errors():
     from hpc_rll.rl_utils import padding as P
     with pytest.raises(RuntimeError):
