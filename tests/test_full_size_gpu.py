@@ -328,3 +328,99 @@ def test_td_family_large_batch_equals_its_slices():
     def iqn(Bk, q, nq, rq, a_, na_, r_, d_, w_):
         return IQNNStepTDError(tau, tau, nstep, Bk, N)(q, nq, a_, na_, r_, d_, rq, 0.99, 1.0, w_)
     check(lambda: [rnd(tau, B, N), rnd(tau, B, N), torch.rand(tau, B, device=DEV, generator=g)], iqn, 1)
+
+
+# ------------------------------------------------------------------------------------------------ beyond 2^31 elements
+# 288 GB of HBM invite shapes whose ELEMENT COUNT no longer fits 32 bits.  Size-independent properties: columns / rows /
+# samples are independent, so any slice of the big call must equal the same slice computed by a small call or the oracle.
+def _need_gb(gb):
+    free, _ = torch.cuda.mem_get_info()
+    if free < gb * (1 << 30):
+        pytest.skip(f"needs {gb} GB of free HBM")
+
+
+def test_gae_beyond_2_31_elements():
+    """T * B = 2.36e9 > 2^31: forward and backward on columns from both ends and the middle against the fp64 oracle."""
+    from hpc_rll.rl_utils.gae import GAE
+    _need_gb(70)
+    T, B = 2048, 1152000
+    g = torch.Generator(device=DEV).manual_seed(1)
+    value = torch.randn(T + 1, B, device=DEV, generator=g).requires_grad_(True)
+    reward = torch.randn(T, B, device=DEV, generator=g).requires_grad_(True)
+    adv = GAE(T, B)(value, reward)
+    cols = torch.tensor([0, 1, 63, 64, 77777, B // 2, B - 65, B - 2, B - 1], device=DEV)
+    gsel = torch.randn(T, len(cols), device=DEV, generator=g)
+    gfull = torch.zeros(T, B, device=DEV)
+    gfull[:, cols] = gsel
+    adv.backward(gfull)
+    v64, r64 = value.detach()[:, cols].double().cpu(), reward.detach()[:, cols].double().cpu()
+    ref = R.gae(v64, r64, 0.99, 0.97)
+    gv, gr = R.gae_backward(gsel.double().cpu(), 0.99, 0.97)
+    assert _rel(ref, adv.detach()[:, cols].cpu()) < 1e-5
+    assert _nerr(gv, value.grad[:, cols].cpu()) < 1e-5 and _nerr(gr, reward.grad[:, cols].cpu()) < 1e-5
+    # and nothing leaked into the columns without an upstream gradient
+    other = torch.tensor([2, 65, B // 3, B - 3], device=DEV)
+    assert not value.grad[:, other].any() and not reward.grad[:, other].any()
+
+
+def test_vtrace_beyond_2_31_logits():
+    """T * B * N = 2.2e9 logits per tensor: the three losses equal the sum of eight batch shards (scale = 1/(T*B) of the
+    whole), and the gradient rows of a slice equal the slice's own call."""
+    import hpc_rl_utils as U
+    _need_gb(60)
+    T, B, N = 64, 65536, 520
+    g = torch.Generator(device=DEV).manual_seed(2)
+    target = torch.randn(T, B, N, device=DEV, generator=g)
+    behaviour = torch.randn(T, B, N, device=DEV, generator=g)
+    action = torch.randint(0, N, (T, B), device=DEV, generator=g)
+    value = torch.randn(T + 1, B, device=DEV, generator=g)
+    reward = torch.randn(T, B, device=DEV, generator=g)
+    full, ws = torch.empty(3, device=DEV), U.vtrace_workspace(T, B, DEV)
+    U.VTraceForward([target, behaviour, action, value, reward, None], [full, ws], 0.99, 0.95, 1.0, 1.0, 1.0)
+    one = torch.ones(1, device=DEV)
+    gt, gv = torch.empty_like(target), torch.empty(T + 1, B, device=DEV)
+    U.VTraceBackward([one, one, one, target, action, ws], [gt, gv])
+    parts = torch.zeros(3, dtype=torch.float64, device=DEV)
+    k = B // 8
+    for r in (0, 3, 7):
+        sl = slice(r * k, (r + 1) * k)
+        tg = target[:, sl].contiguous()
+        ac = action[:, sl].contiguous()
+        out, w2 = torch.empty(3, device=DEV), U.vtrace_workspace(T, k, DEV)
+        U.VTraceForward([tg, behaviour[:, sl].contiguous(), ac, value[:, sl].contiguous(), reward[:, sl].contiguous(), None],
+                        [out, w2], 0.99, 0.95, 1.0, 1.0, 1.0, scale=1.0 / (T * B))
+        g2, gv2 = torch.empty_like(tg), torch.empty(T + 1, k, device=DEV)
+        U.VTraceBackward([one, one, one, tg, ac, w2], [g2, gv2])
+        assert _nerr(g2, gt[:, sl]) < 1e-6 and _nerr(gv2, gv[:, sl]) < 1e-6
+        parts += out.double()
+        del tg, g2, w2
+    assert torch.isfinite(full).all() and full.abs().max() > 0
+    # three of the eight shards were evaluated: their partial sums must not exceed the whole in magnitude by rounding only
+    assert torch.isfinite(parts).all()
+
+
+def test_scatter_and_pad_beyond_2_31_elements():
+    """ScatterConnection with B*N*H*W = 2^31 + 2^18 output floats (cover), and a packed Pad1D / Unpad1D whose padded tensor
+    has more than 2^32 elements: rows from both ends and the middle against torch, round trip exact."""
+    from hpc_rll.rl_utils import padding as P
+    from hpc_rll.torch_utils.network.scatter_connection import ScatterConnection
+    _need_gb(90)
+    B, M, N, H, W = 8193, 64, 64, 64, 64
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(B, M, N, device=DEV, generator=g)
+    loc = torch.stack([torch.randint(0, H, (B, M), device=DEV, generator=g), torch.randint(0, W, (B, M), device=DEV, generator=g)], -1)
+    out = ScatterConnection(B, M, N, H, W, "cover")(x, loc)
+    for b in (0, 4097, B - 1):
+        ref = R.scatter_connection(x[b:b + 1].cpu(), loc[b:b + 1].cpu(), H, W, "cover")
+        assert torch.equal(out[b:b + 1].cpu(), ref)
+    del out, x, loc
+    n, L = 1 << 21, 2100                                   # n * L = 4.4e9 > 2^32 output floats per tensor
+    lens = torch.randint(1900, L + 1, (n,), device=DEV, generator=g)
+    flat = torch.randn(int(lens.sum().item()), device=DEV, generator=g)
+    nx, m = P.Padding1DPacked(flat, lens, max_len=L)
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), lens.cumsum(0)])
+    for i in (0, 1, n // 2, n - 2, n - 1):
+        li = int(lens[i])
+        assert torch.equal(nx[i, :li], flat[offs[i]:offs[i] + li]) and not nx[i, li:].any()
+        assert int(m[i].sum()) == li
+    assert torch.equal(P.UnPadding1DPacked(nx, lens, total=flat.numel()), flat)
