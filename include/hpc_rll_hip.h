@@ -244,7 +244,8 @@ int hpc_rll_unpad_forward(const float* padded, const int64_t* table, float* flat
 int64_t hpc_rll_packed_table_scratch_int64(int64_t n);
 int hpc_rll_packed_table(const int64_t* lengths, int64_t n, int64_t base, int64_t stride, int64_t* table,
                          int64_t* scratch, void* stream);
-/* The two packed directions with the rows' contiguity exploited (a workgroup's rows are ONE span of the flat buffer,
+/* Pad1DForward / Unpad1DForward (src/rl_utils/padding.cu:111-140, 228-260; kernels padding_kernel.h:92-127) for PACKED
+ * rows: the two directions with the rows' contiguity exploited (a workgroup's rows are ONE span of the flat buffer,
  * staged through LDS with 16-byte accesses).  `table` as built by hpc_rll_packed_table: pad -- base = address of `flat`,
  * stride 4; unpad -- base 0, stride 1.  Same results as hpc_rll_pad_forward / hpc_rll_unpad_forward with m0 = m1 = 1
  * (to which they fall back when a pointer is not aligned for 16-byte stores). */
