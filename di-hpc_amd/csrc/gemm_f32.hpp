@@ -48,6 +48,7 @@ struct GemmArgs {
     long c_split = 0;  //      C + z*c_split; the consumer adds the slices in a fixed order (deterministic)
     int big = 0;       // 1: a long-K product that brings its own split-K (gemm_splitk_big): 128x128 tiles
     int xcd_swizzle = 0;   // set by launch_gemm_tile
+    int prio = 0;          // 1: s_setprio(1) around the MFMA clusters (tune key 23 bit 0; experiment)
 };
 
 enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2 };
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
             for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const gf4*>(as + a_off[q] + i * 32 * BK);
 #pragma unroll
             for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const gf4*>(bs + b_off[q] + j * 32 * BK);
+            if (NW == 16 && g.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+            if (NW == 16 && g.prio) __builtin_amdgcn_s_setprio(0);
         }
     };
     if constexpr (INTERIOR) {
@@ -485,9 +488,14 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
             const dim3 grid(g.N / 256, g.M / 256, sk);
             GemmArgs h = g;
             h.xcd_swizzle = 0;   // measured neutral for this tile (136.5 vs 136.7)
+            extern int g_gemm_exp;   // tune key 23 (experiments): bit 0 s_setprio around the MFMA clusters, bit 1 BK = 32
+            h.prio = g_gemm_exp & 1;
 #define HPC_RLL_GEMM256(AM, BMD)                                                                                          \
             if (am == AM && bm == BMD) {                                                                                  \
-                hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 16, 2, 2, AM, BMD, true, 0, 16>), grid, dim3(1024), 0, st, h); \
+                if ((g_gemm_exp & 2) && g.K % 32 == 0)                                                                    \
+                    hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 32, 2, 2, AM, BMD, true, 0, 16>), grid, dim3(1024), 0, st, h); \
+                else                                                                                                      \
+                    hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 16, 2, 2, AM, BMD, true, 0, 16>), grid, dim3(1024), 0, st, h); \
                 return;                                                                                                   \
             }
             HPC_RLL_GEMM256(kContigK, kContigMN) HPC_RLL_GEMM256(kContigK, kContigK) HPC_RLL_GEMM256(kContigMN, kContigMN)

@@ -26,6 +26,7 @@
 
 namespace hpc_rll {
 int g_gemm_bk = 0;
+int g_gemm_exp = 0;   // hpc_rll_tune_set key 23: GEMM experiments (bit 0 s_setprio around MFMA clusters, bit 1 BK = 32 for 256x256 tiles)
 int g_gemm_tile256 = 1;   // 256x256x16 tiles (16 waves) for interior products that fill the chip in whole rounds (tune key 16)
 int g_cell_vec4 = 3;   // smallest ceil(H/256) that takes the 16-byte forward cell kernel (tune key 15; 0 = never)
 int g_gemm_xcd = 1;

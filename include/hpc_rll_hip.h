@@ -133,6 +133,8 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * the last workgroup of its last launch; 0 = a separate finalize launch (the same partials, summed in fp64 either way).
  * key 22: group-split algorithm of hpc_rll_oracle_split_group for key-sorted lists: 0 (default) = DP over the runs of
  * equal keys, 1 = the round-2 element-level paths (cross-check; identical results).
+ * key 23: fp32 GEMM experiments on the 256x256 tile, a bit mask (default 0): bit 0 = s_setprio(1) around the MFMA
+ * clusters, bit 1 = k-depth 32 instead of 16 (128 KB of LDS per workgroup); same k order, identical results.
  */
 int hpc_rll_tune_set(int key, int value);
 
