@@ -799,7 +799,7 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
     // Round 3 sweeps (tests/tools/r03_gae_pf_sweep.py -> profiles/r03_gae_pf_sweep_*.txt; forward and backward
     // alternating, kernel begin/end timestamps, shipped round-2 configuration -> pipelined one in the same process):
     //   T=1024 B=32768  fwd (1,8,4) 65.7 -> (2,16,8)p 63.8      bwd (1,8,8) 59.5 -> (4,4,4)p 56.3
-    //   T=1024 B=65536  fwd (2,8,2) 132.1 -> (2,4,2)p 128.8     bwd (2,2,4) 116.1 -> (4,2,4)p 112.4
+    //   T=1024 B=65536  fwd (2,8,2) 132.1 -> (2,4,2)p 128.8 / (4,4,8)p 128.7 (shipped: see below)   bwd (2,2,4) 116.1 -> (4,2,4)p 112.4
     //   T=1024 B=131072 fwd (2,16,8) 272.7, no pipelined gain   bwd (4,2,4) 305.1 -> (4,2,4)p 288.9
     //   T=256  B=262144 fwd (2,16,8) 131.6 -> (2,16,4)p 129.2   bwd (2,16,16) 135.4 -> (1,8,8)p 115.4
     // (plain loads in the forward are 0.3 us faster but cost the next backward 25 us: forward loads stay nontemporal)
@@ -812,7 +812,16 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
         afl = 3;
         if (vmax >= 2) {
             if (B < 65536) { if (B >= 32768) { av = 2; alc = 16; anw = 8; apf = true; } }   // narrower: keep the round-2 choice
-            else if (B < 131072) { av = 2; alc = 4; anw = 2; apf = true; }
+            // B = 65536: (2,4,2)p is the fastest on a good day (124-127 us) but PLACEMENT-SENSITIVE: over ten independent
+            // buffer sets in one process it reads 125 / 142 / 160 us (min / mean / max), the slow sets being slow for good
+            // -- it is the physical placement of the OUTPUT buffer (swap `adv` for another allocation and the same inputs
+            // run fast), and the r02 (2,8,2) configuration behaves the same (this is the "slow box" of round 2).  With 16-byte
+            // stores and 8 waves per workgroup, (4,4,8)p reads 126 / 129 / 132 over the same sets
+            // (tests/tools/r03_gae_placement_probe.py, profiles/r03_gae_placement_probe.txt).
+            else if (B < 131072) {
+                if (vmax >= 4) { av = 4; alc = 4; anw = 8; } else { av = 2; alc = 4; anw = 4; }
+                apf = true;
+            }
             else if (B >= 262144) { av = 2; alc = 16; anw = 4; apf = true; }
         }
     } else if (streaming) {
@@ -828,6 +837,14 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
         av = 1; alc = 16; anw = 4;
         while (anw < 16 && wgs_for(1) * anw < 2048) anw <<= 1;
         afl = 2;
+        // round 3 (profiles/r03_gae_pf_sweep_1024x16384.txt / _1024x8192.txt): with one workgroup per CU and several
+        // iterations the pipelined kernels pay in the cache-resident regime too -- T=1024, B=16384: forward (1,16,8)
+        // 32.9 -> 29.3 us, backward (1,16,8) 30.5 -> (1,8,8)p 28.7 us (plain loads: the data is in the Infinity Cache);
+        // at B = 8192 (half-wave tiles, two iterations) there is nothing to pipeline: 17.8 / 16.7 vs 17.0 / 16.4 us
+        if (T >= 512 && wgs_for(1) >= 256 && anw == 8) {
+            apf = true;
+            if (!fwd) alc = 8;
+        }
     }
     if (v == 0) v = av;
     if (v > vmax) v = vmax;

@@ -14,7 +14,8 @@ into hipGraphs".
         adv, (d_value, d_reward) = step()                           # one hipGraphLaunch: forward + backward
 
 Constraints (those of stream capture): the module's forward must not synchronise with the host -- ``PPO`` returns
-python floats (``.tolist()``, reference rl_utils/ppo.py:148) and cannot be captured; shapes are fixed at capture time.
+python floats by default (``.tolist()``, reference rl_utils/ppo.py:148); construct it with ``PPO(B, N, sync_info=False)``
+(monitors stay device tensors) to capture it; shapes are fixed at capture time.
 The extension's own caches are capture-safe (a cold ``gae_coef`` table is filled inside the capture).
 """
 from typing import Any, List, Optional, Sequence, Tuple

@@ -1,6 +1,10 @@
 """``hpc_rll.rl_utils.ppo`` -- drop-in for /root/reference/hpc_rll/rl_utils/ppo.py (``PPO(B,N)``, forward signature
 ppo.py:89, returns ``(hpc_ppo_loss, hpc_ppo_info)`` with python-float info like the reference, ppo.py:148).
-The autograd node is ``hpc_rl_utils.ppo`` (compiled torch::autograd::Function)."""
+The autograd node is ``hpc_rl_utils.ppo`` (compiled torch::autograd::Function).
+
+``PPO(B, N, sync_info=False)`` (keyword-only addition) returns the two monitors as 0-d device tensors instead of python
+floats: no host synchronisation in ``forward``, which makes the module capturable by ``hpc_rll.graphed`` (one hipGraph
+per training step) and keeps an eager training loop asynchronous."""
 from collections import namedtuple
 from typing import Optional
 
@@ -16,9 +20,9 @@ hpc_ppo_info = namedtuple('hpc_ppo_info', ['approx_kl', 'clipfrac'])
 class PPO(torch.nn.Module):
     """PPO clipped surrogate (+ optional dual clip), clipped value loss and entropy (arXiv:1707.06347)."""
 
-    def __init__(self, B, N, sharded: bool = False, group=None):
+    def __init__(self, B, N, sharded: bool = False, group=None, *, sync_info: bool = True):
         super().__init__()
-        self.B, self.N, self.sharded, self.group = B, N, sharded, group
+        self.B, self.N, self.sharded, self.group, self.sync_info = B, N, sharded, group, sync_info
 
     def forward(self, logits_new, logits_old, action, value_new, value_old, adv, return_, weight=None,
                 clip_ratio: float = 0.2, use_value_clip: bool = True, dual_clip: Optional[float] = None):
@@ -40,5 +44,8 @@ class PPO(torch.nn.Module):
         if self.sharded:   # the five scalars in ONE all-reduce; the two monitors are per-rank means -> averaged
             policy_loss, value_loss, entropy_loss, info = _dp.all_reduce_sum(
                 (policy_loss, value_loss, entropy_loss, info), self.group, mean_slots=(3, 4))
-        approx_kl, clipfrac = info.tolist()  # one host sync for both monitors (the reference does two .item())
+        if self.sync_info:
+            approx_kl, clipfrac = info.tolist()  # one host sync for both monitors (the reference does two .item())
+        else:
+            approx_kl, clipfrac = info.detach().unbind(0)
         return hpc_ppo_loss(policy_loss, value_loss, entropy_loss), hpc_ppo_info(approx_kl, clipfrac)

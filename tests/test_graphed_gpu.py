@@ -79,3 +79,25 @@ def test_graphed_lstm_parameters_are_differentiated():
     assert torch.equal(out[0], y.detach())
     for a, b in zip(grads, ref):
         assert torch.equal(a, b)
+
+
+def test_graphed_ppo_with_device_side_monitors():
+    """PPO(..., sync_info=False) keeps approx_kl / clipfrac on the device: no host sync in forward, so the whole PPO
+    forward + backward is capturable; results equal the default (python-float) module bit for bit."""
+    import hpc_rll
+    from hpc_rll.rl_utils.ppo import PPO
+    g = torch.Generator(device=DEV).manual_seed(6)
+    B, N = 4096, 18
+    ln = _randn(g, B, N).requires_grad_(True)
+    vn = _randn(g, B).requires_grad_(True)
+    args = (ln, ln.detach() + 0.3 * _randn(g, B, N), torch.randint(0, N, (B,), device=DEV, generator=g), vn,
+            _randn(g, B), _randn(g, B), _randn(g, B))
+    m = PPO(B, N, sync_info=False)
+    step = hpc_rll.graphed(m, *args, None, 0.2, True, 3.0)
+    (loss, info), (dln, dvn) = step()
+    assert isinstance(info.approx_kl, torch.Tensor) and info.approx_kl.is_cuda
+    ref_loss, ref_info = PPO(B, N)(*args, None, 0.2, True, 3.0)
+    sum(ref_loss).sum().backward()
+    assert all(torch.equal(a, b.detach()) for a, b in zip(loss, ref_loss))
+    assert info.approx_kl.item() == ref_info.approx_kl and info.clipfrac.item() == ref_info.clipfrac
+    assert torch.equal(dln, ln.grad) and torch.equal(dvn, vn.grad)
