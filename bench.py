@@ -394,7 +394,8 @@ def main():
     suite = None
     if world == 1 and not args.no_suite:
         del step, keep, value, reward, grad_adv, v_d, r_d
-        torch.cuda.empty_cache()
+        if os.environ.get("HPC_RLL_BENCH_KEEP_CACHE") != "1":
+            torch.cuda.empty_cache()
         suite = run_suite(dev)
 
     if rank == 0:

@@ -338,15 +338,23 @@ if __name__ == "__main__":
     import faulthandler
     faulthandler.enable()
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    # steady-state clocks / temperature: bench.py runs these suites after seconds of streaming work, where the
-    # VALU-heavy categorical kernels read ~10 % slower than on a cold, freshly leased GPU; pre-roll to the same state
-    _pre = torch.empty(1 << 28, device=dev)
+    # steady-state power / clock state: bench.py runs these suites after seconds of GAE work, where the VALU-heavy
+    # categorical kernels read ~10 % slower than on a freshly leased GPU (335 -> 365 us per 2.15 GB head; not placement:
+    # tests/tools/r03_cat_placement_probe.py shows eight input allocations within 1 % of each other).  Pre-roll with the
+    # same work so that this tool and bench.py's `suite` object describe the same state.
+    from hpc_rll.rl_utils.gae import GAE as _GAE
+    _v = torch.randn(1025, 65536, device=dev, requires_grad=True)
+    _r = torch.randn(1024, 65536, device=dev, requires_grad=True)
+    _g = torch.randn(1024, 65536, device=dev)
+    _m = _GAE(1024, 65536)
     _t0 = __import__("time").time()
-    while __import__("time").time() - _t0 < float(os.environ.get("SUITE_PREROLL_S", "2.0")):
-        for _ in range(50):
-            _pre.add_(1.0)
+    while __import__("time").time() - _t0 < float(os.environ.get("SUITE_PREROLL_S", "4.0")):
+        for _ in range(200):
+            _v.grad = _r.grad = None
+            _m(_v, _r).backward(_g)
         torch.cuda.synchronize()
-    del _pre
+    del _v, _r, _g, _m
+    torch.cuda.empty_cache()
     if which in ("c3", "all"):
         suite_c3()
         suite_ppo()
