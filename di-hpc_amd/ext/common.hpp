@@ -114,11 +114,11 @@ inline float loss_scale(std::optional<double> scale, int64_t local_count) {
 // this library's recompute-in-backward kernels need (the logits, ONE workspace).  The forward therefore parks the
 // tensors under the address of one of the reference's own scratch buffers that also appears in the backward list,
 // and the backward picks them up.  An entry lives until the next forward with the same buffer replaces it
-// (backward may run more than once: retain_graph); the table keeps the kCap most recently written entries, so modules
-// that are created and dropped in a loop cannot pin their workspaces for ever.
+// (backward may run more than once: retain_graph); entries whose module buffer has been freed are purged at every put()
+// (modules created and dropped in a loop pin nothing), and the table keeps at most the kCap most recently written ones.
 class SavedByBuffer {
   public:
-    static constexpr size_t kCap = 256;
+    static constexpr size_t kCap = 4096;   // LIVE module buffers with a pending backward (entries of freed buffers are purged in put())
     struct Entry {
         std::vector<Tensor> tensors;
         double scalar = 0.0;

@@ -424,3 +424,27 @@ def test_scatter_and_pad_beyond_2_31_elements():
         assert torch.equal(nx[i, :li], flat[offs[i]:offs[i] + li]) and not nx[i, li:].any()
         assert int(m[i].sum()) == li
     assert torch.equal(P.UnPadding1DPacked(nx, lens, total=flat.numel()), flat)
+
+
+def test_c51_four_samples_per_wave_ragged_tail():
+    """The large-batch C51 forward holds four samples per wave from B = 32768 (csrc/dist_ops.hip); a batch that is not a
+    multiple of 16 ends in a partly filled workgroup: per-sample TD errors and the loss against the one-sample-per-wave
+    path on slices (bit exact) and their sum."""
+    from hpc_rll.rl_utils.td import DistNStepTD
+    B, N, nstep, n_atom = 32768 + 7, 9, 3, 51
+    g = torch.Generator(device=DEV).manual_seed(12)
+    d = torch.softmax(torch.randn(B, N, n_atom, device=DEV, generator=g), -1)
+    nd = torch.softmax(torch.randn(B, N, n_atom, device=DEV, generator=g), -1)
+    a, na = (torch.randint(0, N, (B,), device=DEV, generator=g) for _ in range(2))
+    rew = torch.randn(nstep, B, device=DEV, generator=g)
+    done = (torch.rand(B, device=DEV, generator=g) < 0.2).float()
+    w = torch.rand(B, device=DEV, generator=g)
+    loss, per = DistNStepTD(nstep, B, N, n_atom)(d, nd, a, na, rew, done, w, 0.97, -10.0, 10.0)
+    parts = []
+    for s0, s1 in ((0, 16384), (16384, 32768), (32768, B)):
+        sl = slice(s0, s1)
+        l2, p2 = DistNStepTD(nstep, s1 - s0, N, n_atom)(d[sl].contiguous(), nd[sl].contiguous(), a[sl].contiguous(), na[sl].contiguous(),
+                                                        rew[:, sl].contiguous(), done[sl].contiguous(), w[sl].contiguous(), 0.97, -10.0, 10.0)
+        assert torch.equal(per[sl], p2), (s0, s1)
+        parts.append(l2.double() * (s1 - s0))
+    assert abs(loss.item() - (sum(parts) / B).item()) < 1e-6 * max(1.0, abs(loss.item()))
