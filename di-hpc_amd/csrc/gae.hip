@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // FULLB: B is a multiple of the tile width, no lane is ever out of range -- no exec-masked region around the stores
 // (which would make the compiler's vmcnt bookkeeping pessimistic again, see GUARD below).
-template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB>
+template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB, bool XCD_REMAP = false>
 __global__ __launch_bounds__(NW * 64) void gae_fwd_pf_kernel(const float* __restrict__ value,
                                                              const float* __restrict__ reward,
                                                              float* __restrict__ adv,
@@ -229,7 +229,12 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_pf_kernel(const float* __rest
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    // XCD-aware column tiles (experiment, coef-table argument untouched: T < 0 requests it): workgroups are dealt round
+    // robin to the 8 XCDs, so with the identity mapping XCD x streams every 8th tile; remapped, XCD x owns a contiguous
+    // eighth of the columns (its L2 / fabric port sees contiguous 8-32 KiB per row instead of 1 KiB pieces 8 KiB apart)
+    long tile_id = blockIdx.x;
+    if (XCD_REMAP && (gridDim.x & 7) == 0) tile_id = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long col = tile_id * TILE + (long)lane * V;
     const bool col_ok = FULLB || col < (long)B;
 
     float carry[V];
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(1024) void gae_fwd_wpt_kernel(const float* __restri
 // (grad_value and grad_reward non-null; the dispatcher falls back to gae_bwd_kernel otherwise).  Same arithmetic
 // order as gae_bwd_kernel: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB>
+template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB, bool XCD_REMAP = false>
 __global__ __launch_bounds__(NW * 64) void gae_bwd_pf_kernel(const float* __restrict__ grad_adv,
                                                              float* __restrict__ grad_value,
                                                              float* __restrict__ grad_reward,
@@ -602,7 +607,12 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_pf_kernel(const float* __rest
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long col = (long)blockIdx.x * TILE + (long)lane * V;
+    // XCD-aware column tiles (experiment, coef-table argument untouched: T < 0 requests it): workgroups are dealt round
+    // robin to the 8 XCDs, so with the identity mapping XCD x streams every 8th tile; remapped, XCD x owns a contiguous
+    // eighth of the columns (its L2 / fabric port sees contiguous 8-32 KiB per row instead of 1 KiB pieces 8 KiB apart)
+    long tile_id = blockIdx.x;
+    if (XCD_REMAP && (gridDim.x & 7) == 0) tile_id = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long col = tile_id * TILE + (long)lane * V;
     const bool col_ok = FULLB || col < (long)B;
 
     float carry[V];
@@ -739,7 +749,7 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_pf_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // host side: configuration choice + dispatch
 // ------------------------------------------------------------------------------------------------
-struct Cfg { int v, lc, nw, flags; bool half; bool pf; };
+struct Cfg { int v, lc, nw, flags; bool half; bool pf; bool xcd = false; };
 
 // Kernel timing (hpc_rll_ktime_begin / _end): while armed, every GAE launch goes through hipExtLaunchKernelGGL with a
 // start/stop event pair that brackets the KERNEL ITSELF (the dispatch packet's begin / end timestamps -- what
@@ -873,7 +883,9 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
     if (pf && fwd && !((lc == 4 || lc == 8 || lc == 16) && !(v == 4 && lc == 16) && !(v == 1 && lc == 4))) pf = false;
     if (pf && !fwd && !((lc == 2 || lc == 4 || lc == 8) && !(v == 1 && lc != 8))) pf = false;
     if (pf) flags |= 2;
-    return Cfg{v, lc, nw, flags & 3, half, pf};
+    Cfg out{v, lc, nw, flags & 3, half, pf};
+    out.xcd = explicit_flags >= 0 && (explicit_flags & 32);      // experiment: XCD-contiguous column tiles
+    return out;
 }
 
 template <int N> using I = std::integral_constant<int, N>;
@@ -936,7 +948,9 @@ inline bool dispatch_fwd_pf(const Cfg& cfg, int B, hipStream_t st, A... args) {
         if (!hit && cfg.v == V && cfg.lc == LC && cfg.nw == NW) {
             const dim3 grid((unsigned)((B + 64 * V - 1) / (64 * V))), block(NW * 64);
             const bool full = (B % (64 * V)) == 0;
-            if (cfg.flags & 1) {
+            if (cfg.xcd && full && V == 4 && LC == 4 && NW == 8 && (cfg.flags & 1)) {
+                launch(gae_fwd_pf_kernel<4, 4, 8, true, true, true, true>, grid, block, st, 0, args...);
+            } else if (cfg.flags & 1) {
                 if (full) launch(gae_fwd_pf_kernel<V, LC, NW, true, true, true>, grid, block, st, 0, args...);
                 else launch(gae_fwd_pf_kernel<V, LC, NW, true, true, false>, grid, block, st, 0, args...);
             } else {
@@ -961,7 +975,9 @@ inline bool dispatch_bwd_pf(const Cfg& cfg, int B, hipStream_t st, A... args) {
         if (!hit && cfg.v == V && cfg.lc == LC && cfg.nw == NW) {
             const dim3 grid((unsigned)((B + 64 * V - 1) / (64 * V))), block(NW * 64);
             const bool full = (B % (64 * V)) == 0;
-            if (cfg.flags & 1) {
+            if (cfg.xcd && full && V == 4 && LC == 2 && NW == 4 && !(cfg.flags & 1)) {
+                launch(gae_bwd_pf_kernel<4, 2, 4, false, true, true, true>, grid, block, st, 1, args...);
+            } else if (cfg.flags & 1) {
                 if (full) launch(gae_bwd_pf_kernel<V, LC, NW, true, true, true>, grid, block, st, 1, args...);
                 else launch(gae_bwd_pf_kernel<V, LC, NW, true, true, false>, grid, block, st, 1, args...);
             } else {

@@ -72,7 +72,8 @@ int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value, float* gra
 /* Forward flags bit 3 (value 8, with explicit vec/lc/nw): the software-pipelined forward kernel (the next chunk's row
  * loads are issued before the current chunk's barrier / stores); bit-identical results.  Forward flags bit 4 (value
  * 16): the one-trajectory-per-wavefront mapping (tile staged through LDS, 64-lane shuffle scan along time) -- a
- * measured alternative, results equal up to fp32 re-association.
+ * measured alternative, results equal up to fp32 re-association.  Flags bit 5 (value 32, with the shipped B = 65536
+ * configurations (4,4,8) forward / (4,2,4) backward): XCD-contiguous column tiles (experiment; identical results).
  *
  * Diagnostics (no reference counterpart; the reference times whole python calls, tests/test_gae.py:31-52).
  * hpc_rll_ktime_begin(capacity) arms per-launch KERNEL timing for the next `capacity` GAE launches of this process

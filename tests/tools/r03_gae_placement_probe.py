@@ -130,14 +130,14 @@ def run_cfg2(bs, cf, cb, n=16):
 
 AUTO = (0, 0, 0, -1)
 print("--- forward candidates over all sets: min / mean / max us", flush=True)
-for c in (AUTO, (2, 4, 2, 11), (4, 4, 8, 11), (4, 8, 4, 11), (4, 4, 4, 11), (4, 8, 8, 11), (4, 8, 4, 3), (2, 8, 4, 11), (2, 4, 4, 11), (2, 16, 4, 11)):
+for c in (AUTO, (4, 4, 8, 43), (2, 4, 2, 11), (4, 4, 8, 11), (4, 8, 4, 11), (4, 4, 4, 11), (4, 8, 8, 11), (4, 8, 4, 3), (2, 8, 4, 11), (2, 4, 4, 11), (2, 16, 4, 11)):
     ts = [run_cfg2(bs, c, AUTO) for bs in sets]
     if ts[0] is None:
         continue
     f_ = [t_[0] for t_ in ts]
     print(f"fwd {c}: {min(f_):6.1f} / {sum(f_)/len(f_):6.1f} / {max(f_):6.1f}", flush=True)
 print("--- backward candidates over all sets: min / mean / max us", flush=True)
-for c in (AUTO, (4, 2, 4, 10), (4, 4, 2, 10), (2, 2, 4, 10), (2, 4, 2, 10), (2, 2, 4, 2), (4, 2, 8, 10)):
+for c in (AUTO, (4, 2, 4, 42), (4, 2, 4, 10), (4, 4, 2, 10), (2, 2, 4, 10), (2, 4, 2, 10), (2, 2, 4, 2), (4, 2, 8, 10)):
     ts = [run_cfg2(bs, AUTO, c) for bs in sets]
     if ts[0] is None:
         continue
