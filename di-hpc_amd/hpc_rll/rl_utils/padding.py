@@ -130,3 +130,21 @@ def UnPadding1DPacked(x: torch.Tensor, lengths: torch.Tensor, total: int = None,
     if validate:
         _validate_packed(total, lengths, x.shape[1], "UnPadding1DPacked")
     return hpc_rl_utils.unpad1d_packed(x, lengths, total)
+
+
+def UnPadding1DPackedGrouped(xs, lengths_groups, order: torch.Tensor, total: int = None) -> torch.Tensor:
+    """Inverse of ``Padding1DPacked(..., group > 1)``: the buckets ``xs[g]`` (cnt_g, width_g), their row lengths
+    ``lengths_groups[g]`` (cnt_g,) and ``order`` (n,) as returned by it -> the flat values in the ORIGINAL row order.
+    The buckets are laid side by side as (n, max width) sorted rows, the rows are put back in their original order with
+    one ``index_select`` through the inverse permutation, and the packed unpad kernel does the rest."""
+    n = order.numel()
+    width = max([int(x.shape[1]) for x in xs] + [0])
+    rows = xs[0].new_zeros((n, width)) if len(xs) else order.new_zeros((0, 0), dtype=torch.float32)
+    k = 0
+    for x in xs:
+        rows[k:k + x.shape[0], :x.shape[1]] = x
+        k += x.shape[0]
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(n, device=order.device, dtype=order.dtype)
+    lengths_sorted = torch.cat(list(lengths_groups)) if len(lengths_groups) else order.new_zeros((0,))
+    return hpc_rl_utils.unpad1d_packed(rows.index_select(0, inv), lengths_sorted.index_select(0, inv), total)

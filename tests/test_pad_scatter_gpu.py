@@ -216,6 +216,18 @@ def test_packed_group_padding_equals_host_dp_at_200k_and_runs_at_one_million():
             assert best < 5e-3, f"grouped packed pad of 2^20 rows took {best * 1e3:.2f} ms"
 
 
+def test_packed_group_padding_round_trip():
+    """Padding1DPacked(group > 1) followed by UnPadding1DPackedGrouped returns the flat values in their original order."""
+    from hpc_rll.rl_utils import padding as P
+    for n, lo, hi, group, mode in ((5000, 32, 128, 8, "oracle"), (333, 0, 7, 4, "oracle"), (70000, 1, 300, 12, "sample"), (1, 4, 5, 3, "oracle")):
+        rng = np.random.default_rng(n + group)
+        lens = torch.from_numpy(rng.integers(lo, hi, n)).to(DEV)
+        flat = torch.randn(int(lens.sum().item()), device=DEV)
+        xs, ms, ls, order = P.Padding1DPacked(flat, lens, group=group, group_mode=mode, seed=3)
+        back = P.UnPadding1DPackedGrouped(xs, ls, order, total=flat.numel())
+        assert torch.equal(back, flat), (n, group, mode)
+
+
 def test_packed_group_padding_sample_policy_and_errors():
     from hpc_rll.rl_utils import padding as P
     rng = np.random.default_rng(3)
