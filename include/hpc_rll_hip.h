@@ -33,7 +33,7 @@ extern "C" {
 #define HPC_RLL_EUNSUPPORTED (-3) /* shape outside what the kernels implement   */
 #define HPC_RLL_ETIMEOUT (-4)   /* a persistent LSTM kernel gave up waiting for its co-resident workgroups */
 
-/* ABI version, bumped on any signature change. */
+/* ABI version, bumped on any signature change or added entry point (3 = round 3: kernel timing, packed / grouped pad). */
 int hpc_rll_abi_version(void);
 /* Human readable message for a status returned by any entry point (static storage). */
 const char* hpc_rll_status_string(int status);

@@ -60,7 +60,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     _fn.restype = _res
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 if lib.hpc_rll_abi_version() != ABI_VERSION:
     raise ImportError(f"libhpc_rll_hip.so ABI {lib.hpc_rll_abi_version()} != expected {ABI_VERSION}; rebuild")
 
