@@ -372,6 +372,126 @@ __global__ __launch_bounds__(256) void dist_nstep_fwd64_kernel(
     publish_sums<1, 256>(tot, partials, fold);
 }
 
+// The projection for large batches.  (A first version scattered with LDS float atomics, two ds_add_f32 per sample in the
+// oracle's order: bit-identical to the sequential scatter, but ds_add_f32 runs at about one lane per two clocks on this
+// part -- 110 of the kernel's 154 us at B = 262144, tests/tools/r03_batch_probe.py.)
+// j -> floor(bp_j) is monotone for any sign of nd_scale (correctly rounded mul / add / div, clamp, floor), so the sources
+// that share a floor atom are ONE contiguous run of lanes, and target atom k receives the floor weights of run(k) and the
+// ceil weights of run(k-1) (a source whose position is integral has weight 0 both ways, like the reference's l == u case).
+//   1. run boundaries: a lane whose neighbour (DPP wave shift) has another floor atom marks start / end of its run in a
+//      64-entry LDS table indexed by atom (plain stores, no two lanes write the same word);
+//   2. both weight streams are summed along the runs by a segmented doubling scan (ds_bpermute; offsets 8..32 only when
+//      some run is that long: clamped returns make runs of 10+ sources common, terminal samples one run of all atoms);
+//   3. target k fetches the totals at end(run(k)) and end(run(k-1)).
+// Fixed cost whatever the run lengths (the search-and-gather form above walks the longest run of the wave with five
+// ds_bpermute per step).  The sum of a run is formed in doubling order, not source order: deterministic, equal to the
+// oracle's sequential scatter up to fp32 rounding of a few terms (tests/test_losses_gpu.py pins it at 4e-7 of the maximum).
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, 0xF, false); }
+
+__device__ __forceinline__ float c51_project_scan(int* __restrict__ se, int lane, int n_atom, float R, float nd_scale,
+                                                  float pn_j, float v_min, float v_max, float dz) {
+    const bool src = lane < n_atom;
+    const int j = src ? lane : n_atom - 1;
+    const float step = (v_max - v_min) / (float)(n_atom - 1);
+    const float sup = (j < n_atom / 2) ? (v_min + step * (float)j) : (v_max - step * (float)(n_atom - 1 - j));
+    float tz = __fadd_rn(R, __fmul_rn(nd_scale, sup));
+    tz = fminf(fmaxf(tz, v_min), v_max);
+    const float bp = __fdiv_rn(__fsub_rn(tz, v_min), dz);
+    const float lo = floorf(bp), up = ceilf(bp);
+    int i_lo = (int)lo;
+    i_lo = i_lo < 0 ? 0 : i_lo > 63 ? 63 : i_lo;              // NaN inputs must not leave the table
+    float yl = src ? __fmul_rn(pn_j, up - bp) : 0.f, yu = src ? __fmul_rn(pn_j, bp - lo) : 0.f;
+    const int prev = dpp_mov<0x138>(-1, i_lo), next = dpp_mov<0x130>(-1, i_lo);     // wave_shr:1 / wave_shl:1
+    const bool is_start = src && (lane == 0 || prev != i_lo), is_end = src && (lane == n_atom - 1 || next != i_lo);
+    int2* __restrict__ se2 = reinterpret_cast<int2*>(se);
+    se2[lane] = int2{0, -1};                                  // empty run
+    __builtin_amdgcn_wave_barrier();
+    if (is_start) se[2 * i_lo] = lane;
+    if (is_end) se[2 * i_lo + 1] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const int d = src ? lane - se[2 * i_lo] : 0;              // distance to the start of my run
+    const int2 mine = se2[lane];                              // run of target atom k = lane
+    int2 below = se2[lane > 0 ? lane - 1 : 0];
+    if (lane == 0) below = int2{0, -1};
+    __builtin_amdgcn_wave_barrier();                          // the table is reused by the wave's next sample
+#pragma unroll
+    for (int off = 1; off <= 4; off <<= 1) {
+        const float tl = __shfl_up(yl, off, 64), tu = __shfl_up(yu, off, 64);
+        if (off <= d) { yl += tl; yu += tu; }
+    }
+    if (__builtin_amdgcn_ballot_w64(d >= 8)) {
+#pragma unroll
+        for (int off = 8; off <= 32; off <<= 1) {
+            const float tl = __shfl_up(yl, off, 64), tu = __shfl_up(yu, off, 64);
+            if (off <= d) { yl += tl; yu += tu; }
+        }
+    }
+    const float fsum = __shfl(yl, mine.y < 0 ? 0 : mine.y, 64), csum = __shfl(yu, below.y < 0 ? 0 : below.y, 64);
+    return (mine.y >= mine.x ? fsum : 0.f) + (below.y >= below.x ? csum : 0.f);
+}
+
+// Large batches: SW consecutive samples per wave, per-sample scalars loaded coalesced by their owner lanes (as
+// qrdqn_fwd_batch_kernel below), the rows of U samples requested together, projection by run sums (c51_project_scan).
+template <int SW>
+__global__ __launch_bounds__(256) void dist_nstep_fwd_batch_kernel(
+    const float* __restrict__ dist, const float* __restrict__ next_dist, const int64_t* __restrict__ action,
+    const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
+    const float* __restrict__ weight, float* __restrict__ td_err, float* __restrict__ buf,
+    float* __restrict__ partials, int nstep, int B, int N, int n_atom, float gamma, float gamma_n, float v_min,
+    float v_max, float dz, float scale, const ScanFold fold) {
+    constexpr int U = 8;
+    static_assert(SW % U == 0, "samples per wave");
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(8))) int runs[4][128];       // per wave: {start, end} lane of the run of every atom
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long b0 = ((long)blockIdx.x * 4 + w) * SW;
+    const long bown = b0 + lane % SW;
+    const long bl = bown < (long)B ? bown : (long)B - 1;
+    // element offsets of the two rows of the owned sample (64-bit: B * N * n_atom may pass 2^31)
+    const long row_l = ((long)bl * N + action[bl]) * n_atom, rown_l = ((long)bl * N + next_action[bl]) * n_atom;
+    const float w_l = weight ? weight[bl] : 1.f;
+    const float nd_l = (1.f - done[bl]) * gamma_n;
+    const float R_l = nstep_return1(reward, B, nstep, gamma, bl);
+    const int jl = lane < n_atom ? lane : n_atom - 1;
+    auto bcast = [](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
+    auto bcast64 = [](long x, int l) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x & 0xffffffffL), l);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long)x >> 32), l);
+        return (long)(((unsigned long)hi << 32) | lo);
+    };
+    float mine = 0.f;
+    for (int c = 0; c < SW; c += U) {
+        float pk[U], pnj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                           // sample c+u is owned by lane c+u: uniform row addresses
+            pk[u] = dist[bcast64(row_l, c + u) + jl];
+            pnj[u] = next_dist[bcast64(rown_l, c + u) + jl];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = b0 + c + u < (long)B;
+            const float proj = c51_project_scan(runs[w], lane, n_atom, bcast(R_l, c + u), bcast(nd_l, c + u), pnj[u],
+                                                v_min, v_max, dz);
+            float ce = 0.f;
+            if (lane < n_atom) {
+                ce = proj * logf(pk[u]);
+                if (live) buf[(size_t)(b0 + c + u) * n_atom + lane] = -bcast(w_l, c + u) * proj / pk[u] * scale;
+            }
+            const float tot = bcast(group_sum_last<64>(ce), 63);      // DPP sum: no LDS round trips
+            if (lane % SW == c + u) mine = -tot;
+        }
+    }
+    const bool own = lane < SW && bown < (long)B;
+    if (own) td_err[bown] = mine;
+    const float contrib = wave_sum(own ? mine * w_l : 0.f);
+    if (lane == 0) red[w] = contrib;
+    __syncthreads();
+    float tot = 0.f;
+    if (threadIdx.x == 0) tot = (red[0] + red[1]) + (red[2] + red[3]);
+    publish_sums<1, 256>(tot, partials, fold);
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void iqn_fwd_group_kernel(
     const float* __restrict__ q, const float* __restrict__ next_q, const int64_t* __restrict__ action,
@@ -474,9 +594,117 @@ __global__ __launch_bounds__(256) void qrdqn_fwd_group_kernel(
     });
 }
 
+// Round 3, large batches: a wave takes SW CONSECUTIVE samples.  The group kernel above is a chain of dependent round trips
+// per sample (action -> row address -> row) with 64/G samples in flight per wave: at B = 262144, tau = 32 it ran 0.128 ms
+// for 16 rounds of resident waves -- ~8 us per round against ~1.7 us of pair-loop arithmetic.  Here
+//   phase A: lane l holds the per-sample scalars of sample b0 + l (action, next action, done, weight, n-step return):
+//            coalesced loads, ONE round trip for all SW samples;
+//   phase B: the groups of G lanes walk the samples 64/G at a time; a sample's scalars come from its owner lane through
+//            ds_bpermute, and the rows of U iterations are requested before the first pair loop runs.
+// Per-sample arithmetic as in qrdqn_fwd_group_kernel (td_err / buf bit-identical); the workgroup partial adds its samples
+// in butterfly order.
+template <int G, int SW, bool FULL>
+__global__ __launch_bounds__(256, 4) void qrdqn_fwd_batch_kernel(
+    const float* __restrict__ q, const float* __restrict__ next_q, const int64_t* __restrict__ action,
+    const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
+    const float* __restrict__ weight, const float* __restrict__ value_gamma, float* __restrict__ td_err,
+    float* __restrict__ buf, float* __restrict__ partials, int tau, int nstep, int B, int N, float gamma,
+    float gamma_n, float tau_value, float scale, const ScanFold fold) {
+    constexpr int SPW = 64 / G, NIT = SW / SPW, U = NIT < 4 ? NIT : 4;
+    static_assert(SW % SPW == 0 && NIT % U == 0, "samples per wave");
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float tg[4][U][64];   // the targets of U iterations, per wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gl = lane % G, gs = lane / G;
+    const long b0 = ((long)blockIdx.x * 4 + w) * SW;
+    // phase A (lanes >= SW repeat the first SW samples: harmless)
+    const long bown = b0 + lane % SW;
+    const long bl = bown < (long)B ? bown : (long)B - 1;
+    const long row_l = ((long)bl * N + action[bl]) * tau, rown_l = ((long)bl * N + next_action[bl]) * tau;   // element offsets
+    const float dn_l = done[bl], vgm_l = value_gamma ? value_gamma[bl] : gamma_n;
+    const float w_l = weight ? weight[bl] : 1.f;
+    const float R_l = nstep_return1(reward, B, nstep, gamma, bl);
+    const float vg_l = vgm_l * (1.f - dn_l);
+    const int glc = gl < tau ? gl : tau - 1;                  // clamped: the row loads are unconditional
+    const float inv_tau = 1.f / (float)tau;
+    float qneg = fabsf(tau_value - 1.f), qpos = fabsf(tau_value);
+    asm volatile("" : "+v"(qneg), "+v"(qpos));         // opaque: else the compiler selects first and takes |.| per pair
+    const vfloat2 mh2 = {-0.5f, -0.5f};
+    float mine = 0.f;                                         // td_err of the sample this lane owns
+    for (int c = 0; c < NIT; c += U) {
+        float qv[U], nv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sl = (c + u) * SPW + gs;                // sample of this group, as a lane index of phase A
+            qv[u] = q[__shfl(row_l, sl, 64) + glc];
+            nv[u] = next_q[__shfl(rown_l, sl, 64) + glc];
+        }
+        // Targets go through LDS: a group then reads FOUR of them with one broadcast ds_read_b128 (a ds_bpermute per
+        // target plus its lane arithmetic was half of the loop's instructions, and its latency was exposed in every iteration).
+        // One wave writes and reads its own slots: LDS operations of a wave execute in order, no barrier needed.
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sl = (c + u) * SPW + gs;
+            tg[w][u][lane] = fmaf(__shfl(vg_l, sl, 64), nv[u], __shfl(R_l, sl, 64));
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sl = (c + u) * SPW + gs;
+            const bool ok = b0 + sl < (long)B;
+            const float* tgs = &tg[w][u][gs * G];
+            const vfloat2 q2 = {qv[u], qv[u]};
+            vfloat2 li2 = {0.f, 0.f}, gi2 = {0.f, 0.f};
+            // as qrdqn_fwd_group_kernel: packed pairs, du = med3(e, -1, 1), smooth_l1 = du * (e - 0.5 du), hoisted weights;
+            // even targets accumulate in .x, odd ones in .y, in target order
+            auto pair = [&](vfloat2 t2, bool two) {
+                const vfloat2 e = t2 - q2;
+                vfloat2 du, qw;
+                du.x = __builtin_amdgcn_fmed3f(e.x, -1.f, 1.f);
+                du.y = __builtin_amdgcn_fmed3f(e.y, -1.f, 1.f);
+                const vfloat2 uu = du * __builtin_elementwise_fma(mh2, du, e);
+                qw.x = e.x <= 0.f ? qneg : qpos;
+                qw.y = two ? (e.y <= 0.f ? qneg : qpos) : 0.f;
+                li2 = __builtin_elementwise_fma(qw, uu, li2);
+                gi2 = __builtin_elementwise_fma(qw, du, gi2);
+            };
+            if constexpr (FULL) {                             // tau == G: no tail, fully unrolled
+#pragma unroll
+                for (int j = 0; j < G; j += 4) {
+                    const vfloat4 t = *reinterpret_cast<const vfloat4*>(tgs + j);
+                    pair(vfloat2{t.x, t.y}, true);
+                    pair(vfloat2{t.z, t.w}, true);
+                }
+            } else {
+                for (int j = 0; j < tau; j += 2) {
+                    const vfloat2 t = *reinterpret_cast<const vfloat2*>(tgs + j);
+                    pair(t, j + 1 < tau);
+                }
+            }
+            const float li = li2.x + li2.y, gi = gi2.x + gi2.y;
+            const float wu = __shfl(w_l, sl, 64);             // outside the branch: a masked-off owner lane would read as 0
+            if (ok && gl < tau) buf[(size_t)(b0 + sl) * tau + gl] = -gi * inv_tau * wu * scale;
+            const float loss = group_sum_last<G>(gl < tau ? li : 0.f);  // DPP: the group's LAST lane holds the sum
+            const float theirs = __shfl(loss, (lane % SPW) * G + G - 1, 64);   // the group that holds my sample in this iteration
+            if ((lane % SW) / SPW == c + u) mine = theirs * inv_tau;
+            __builtin_amdgcn_sched_barrier(0);                // one sample's 32 target registers at a time (else: spills)
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const bool own = lane < SW && bown < (long)B;
+    if (own) td_err[bown] = mine;
+    const float contrib = wave_sum(own ? mine * w_l : 0.f);
+    if (lane == 0) red[w] = contrib;
+    __syncthreads();
+    float tot = 0.f;
+    if (threadIdx.x == 0) tot = (red[0] + red[1]) + (red[2] + red[3]);
+    publish_sums<1, 256>(tot, partials, fold);
+}
+
 inline int group_lanes(int n) { return n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : 64; }
 
 }  // namespace
+
+int g_sample_batch = 0;   // hpc_rll_tune_set key 24: samples per wave of the large-batch QR-DQN forward (0 = by batch size, 1 = off)
 }  // namespace hpc_rll
 
 using namespace hpc_rll;
@@ -492,16 +720,23 @@ extern "C" int hpc_rll_dist_nstep_td_forward(const float* dist, const float* nex
     if (!dist || !next_n_dist || !action || !next_n_action || (nstep && !reward) || !done || !td_err || !buf ||
         !partials)
         return HPC_RLL_EINVAL;
-    const bool multi = n_atom <= 64 && B >= 32768;   // 4 samples per wave once every SIMD still gets >= 2 waves
-    const int blocks = multi ? (B + 15) / 16 : (B + 3) / 4;
+    // large batches: SW samples per wave (dist_nstep_fwd_batch_kernel); widths from tests/tools/r03_batch_probe.py
+    int sw = g_sample_batch;
+    if (sw == 0) sw = B >= 262144 ? 32 : B >= 65536 ? 16 : B >= 16384 ? 8 : 1;
+    if (n_atom > 64) sw = 1;
+    const int blocks = sw > 1 ? (int)(((long)B + 4 * sw - 1) / (4 * sw)) : (B + 3) / 4;
     // delta_z is a python double in the oracle, rounded to fp32 when it meets the fp32 tensor
     const float dz = (float)(((double)v_max - (double)v_min) / (double)(n_atom - 1));
     const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);
     const float gamma_n = (float)pow((double)gamma, (double)nstep);
-    if (multi) {
-        hipLaunchKernelGGL(dist_nstep_fwd64_kernel<4>, dim3(blocks), dim3(256), 0, st, dist, next_n_dist, action,
-                           next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma, gamma_n,
-                           v_min, v_max, dz, scale, fold);
+    if (sw > 1) {
+#define HPC_RLL_C51_B(SW_)                                                                                            \
+        if (sw == SW_)                                                                                                \
+            hipLaunchKernelGGL(dist_nstep_fwd_batch_kernel<SW_>, dim3(blocks), dim3(256), 0, st, dist, next_n_dist,    \
+                               action, next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, \
+                               gamma, gamma_n, v_min, v_max, dz, scale, fold);
+        HPC_RLL_C51_B(8) HPC_RLL_C51_B(16) HPC_RLL_C51_B(32) HPC_RLL_C51_B(64)
+#undef HPC_RLL_C51_B
     } else if (n_atom <= 64)
         hipLaunchKernelGGL(dist_nstep_fwd64_kernel<1>, dim3(blocks), dim3(256), 0, st, dist, next_n_dist, action,
                            next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, gamma, gamma_n,
@@ -587,8 +822,30 @@ extern "C" int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_
     int blocks = (B + 3) / 4;
     const float gamma_n = (float)pow((double)gamma, (double)nstep);
     if (tau <= 64) blocks = (B + 4 * (64 / group_lanes(tau)) - 1) / (4 * (64 / group_lanes(tau)));
+    // large batches: SW consecutive samples per wave (qrdqn_fwd_batch_kernel); widths from tests/tools/r03_batch_probe.py
+    int sw = g_sample_batch;
+    if (sw == 0) sw = B >= 262144 ? 64 : B >= 131072 ? 32 : B >= 65536 ? 16 : B >= 32768 ? 8 : 1;
+    if (tau > 64 || sw < 64 / group_lanes(tau)) sw = 1;
+    if (sw > 1) blocks = (int)(((long)B + 4 * sw - 1) / (4 * sw));
     const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);
-    if (tau <= 64) {
+    if (sw > 1) {
+        const int G = group_lanes(tau);
+#define HPC_RLL_QR_B(G_, SW_)                                                                                         \
+        if (G == G_ && sw == SW_) {                                                                                   \
+            if (tau == G_)                                                                                            \
+                hipLaunchKernelGGL((qrdqn_fwd_batch_kernel<G_, SW_, true>), dim3(blocks), dim3(256), 0, st, q, next_n_q, \
+                                   action, next_n_action, reward, done, weight, value_gamma, td_err, buf, partials, tau, \
+                                   nstep, B, N, gamma, gamma_n, tau_value, scale, fold);                              \
+            else                                                                                                      \
+                hipLaunchKernelGGL((qrdqn_fwd_batch_kernel<G_, SW_, false>), dim3(blocks), dim3(256), 0, st, q, next_n_q, \
+                                   action, next_n_action, reward, done, weight, value_gamma, td_err, buf, partials, tau, \
+                                   nstep, B, N, gamma, gamma_n, tau_value, scale, fold);                              \
+        }
+        HPC_RLL_QR_B(8, 8) HPC_RLL_QR_B(8, 16) HPC_RLL_QR_B(8, 32) HPC_RLL_QR_B(8, 64) HPC_RLL_QR_B(16, 8) HPC_RLL_QR_B(16, 16)
+        HPC_RLL_QR_B(16, 32) HPC_RLL_QR_B(16, 64) HPC_RLL_QR_B(32, 8) HPC_RLL_QR_B(32, 16) HPC_RLL_QR_B(32, 32) HPC_RLL_QR_B(32, 64)
+        HPC_RLL_QR_B(64, 8) HPC_RLL_QR_B(64, 16) HPC_RLL_QR_B(64, 32) HPC_RLL_QR_B(64, 64)
+#undef HPC_RLL_QR_B
+    } else if (tau <= 64) {
         const int G = group_lanes(tau);
 #define HPC_RLL_QR_G(G_)                                                                                              \
         if (G == G_)                                                                                                  \

@@ -147,23 +147,7 @@ __device__ __forceinline__ void xchg_gather(const u64* src, int n, uint32_t tag,
     }
 }
 
-// ---- DPP-only sums (no LDS traffic).  After the steps for a group of GL lanes (8, 16, 32 or 64, aligned) the LAST
-// lane of every group holds the group total.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float x) {
-    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK,
-                                                                     0xF, false));
-}
-template <int GL>
-__device__ __forceinline__ float group_sum_last(float x) {
-    x = dpp_add<0xB1, 0xF>(x);                  // quad_perm [1,0,3,2]
-    x = dpp_add<0x4E, 0xF>(x);                  // quad_perm [2,3,0,1]
-    x = dpp_add<0x141, 0xF>(x);                 // row_half_mirror: 8-lane sums in every lane
-    if (GL >= 16) x = dpp_add<0x140, 0xF>(x);   // row_mirror: 16-lane row sums in every lane
-    if (GL >= 32) x = dpp_add<0x142, 0xA>(x);   // row_bcast:15 -> rows 1 and 3 hold 32-lane sums
-    if (GL >= 64) x = dpp_add<0x143, 0xC>(x);   // row_bcast:31 -> row 3 holds the wave total
-    return x;
-}
+// DPP-only sums: dpp_add / group_sum_last live in wave.hpp
 __device__ __forceinline__ float wave_sum_last(float x) { return group_sum_last<64>(x); }
 // the same, broadcast to every lane of the group (one ds_bpermute)
 template <int GL>

@@ -136,6 +136,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * equal keys, 1 = the round-2 element-level paths (cross-check; identical results).
  * key 23: fp32 GEMM experiments on the 256x256 tile, a bit mask (default 0): bit 0 = s_setprio(1) around the MFMA
  * clusters, bit 1 = k-depth 32 instead of 16 (128 KB of LDS per workgroup); same k order, identical results.
+ * key 24: samples per wave of the large-batch C51 / QR-DQN forwards (a wave loads the per-sample scalars of that many
+ * consecutive samples coalesced, then walks them): 0 (default) = by batch size, 1 = never (the wave- / group-per-sample
+ * kernels), or 8 / 16 / 32 / 64.
  */
 int hpc_rll_tune_set(int key, int value);
 

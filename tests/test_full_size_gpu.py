@@ -285,7 +285,7 @@ def test_c5_list_api_round_trip_at_two_to_the_twenty_tensors():
 
 def test_td_family_large_batch_equals_its_slices():
     """Size-independent property of the per-sample ops at a batch where the large-batch kernels run (B = 2^17: group-per-
-    sample IQN / QR-DQN, one-pass C51, 16-byte one-hot gradients with 64-bit offsets): the per-sample TD error of sample b
+    sample IQN, samples-per-wave QR-DQN and C51, 16-byte one-hot gradients with 64-bit offsets): the per-sample TD error of sample b
     does not depend on what else is in the batch, and the mean-reduced loss scales its gradient by 1/B -- so a slice of
     1024 samples computed ALONE must reproduce td_err bit for bit and the gradient rows times 2^7 (an exact scaling)."""
     from hpc_rll.rl_utils.td import DistNStepTD, IQNNStepTDError, QNStepTD, QRDQNNStepTDError
@@ -296,7 +296,12 @@ def test_td_family_large_batch_equals_its_slices():
     rew, done, w = rnd(nstep, B), (torch.rand(B, device=DEV, generator=g) < 0.1).float(), torch.rand(B, device=DEV, generator=g)
     starts = [0, 37 * 1024, B - SL]
 
-    def check(make_inputs, run, batch_dim):
+    import hpc_rl_utils as U
+
+    def check(make_inputs, run, batch_dim, sw=0):
+        """sw: the samples-per-wave width the full batch gets by itself (C51 / QR-DQN, csrc/dist_ops.hip); the slices are
+        run with that width forced (tune key 24), else a 1024-sample batch takes the small-batch kernels, whose per-sample
+        sums are formed in another order."""
         full_in = make_inputs()
         leaf = full_in[0].requires_grad_(True)
         loss, per = run(B, leaf, *full_in[1:], a, na, rew, done, w)
@@ -305,8 +310,12 @@ def test_td_family_large_batch_equals_its_slices():
             sl = slice(s0, s0 + SL)
             cut = lambda t: t.detach().narrow(batch_dim, s0, SL).contiguous()  # noqa: E731
             sub = cut(leaf).requires_grad_(True)
-            l2, p2 = run(SL, sub, *[cut(t) for t in full_in[1:]], a[sl].contiguous(), na[sl].contiguous(),
-                         rew[:, sl].contiguous(), done[sl].contiguous(), w[sl].contiguous())
+            U.tune_set(24, sw)
+            try:
+                l2, p2 = run(SL, sub, *[cut(t) for t in full_in[1:]], a[sl].contiguous(), na[sl].contiguous(),
+                             rew[:, sl].contiguous(), done[sl].contiguous(), w[sl].contiguous())
+            finally:
+                U.tune_set(24, 0)
             l2.backward()
             assert torch.equal(per[sl], p2), (run.__name__, s0)
             assert torch.equal(leaf.grad.narrow(batch_dim, s0, SL) * float(B // SL), sub.grad), (run.__name__, s0)
@@ -319,11 +328,11 @@ def test_td_family_large_batch_equals_its_slices():
 
     def c51(Bk, d, nd, a_, na_, r_, d_, w_):
         return DistNStepTD(nstep, Bk, N, n_atom)(d, nd, a_, na_, r_, d_, w_, 0.99, -10.0, 10.0)
-    check(lambda: [torch.softmax(rnd(B, N, n_atom), -1), torch.softmax(rnd(B, N, n_atom), -1)], c51, 0)
+    check(lambda: [torch.softmax(rnd(B, N, n_atom), -1), torch.softmax(rnd(B, N, n_atom), -1)], c51, 0, sw=16)
 
     def qr(Bk, q, nq, a_, na_, r_, d_, w_):
         return QRDQNNStepTDError(tau, nstep, Bk, N)(q, nq, a_, na_, r_, d_, 0.99, w_)
-    check(lambda: [rnd(B, N, tau), rnd(B, N, tau)], qr, 0)
+    check(lambda: [rnd(B, N, tau), rnd(B, N, tau)], qr, 0, sw=32)
 
     def iqn(Bk, q, nq, rq, a_, na_, r_, d_, w_):
         return IQNNStepTDError(tau, tau, nstep, Bk, N)(q, nq, a_, na_, r_, d_, rq, 0.99, 1.0, w_)
@@ -426,10 +435,11 @@ def test_scatter_and_pad_beyond_2_31_elements():
     assert torch.equal(P.UnPadding1DPacked(nx, lens, total=flat.numel()), flat)
 
 
-def test_c51_four_samples_per_wave_ragged_tail():
-    """The large-batch C51 forward holds four samples per wave from B = 32768 (csrc/dist_ops.hip); a batch that is not a
-    multiple of 16 ends in a partly filled workgroup: per-sample TD errors and the loss against the one-sample-per-wave
-    path on slices (bit exact) and their sum."""
+def test_c51_samples_per_wave_ragged_tail():
+    """The large-batch C51 forward walks 8+ consecutive samples per wave from B = 16384 (csrc/dist_ops.hip:
+    dist_nstep_fwd_batch_kernel); a batch that is no multiple of 32 ends in a partly filled wave: per-sample TD errors and
+    the loss against slices computed alone with the same kernel (tune key 24 = 8; bit exact) and their sum."""
+    import hpc_rl_utils as U
     from hpc_rll.rl_utils.td import DistNStepTD
     B, N, nstep, n_atom = 32768 + 7, 9, 3, 51
     g = torch.Generator(device=DEV).manual_seed(12)
@@ -443,8 +453,12 @@ def test_c51_four_samples_per_wave_ragged_tail():
     parts = []
     for s0, s1 in ((0, 16384), (16384, 32768), (32768, B)):
         sl = slice(s0, s1)
-        l2, p2 = DistNStepTD(nstep, s1 - s0, N, n_atom)(d[sl].contiguous(), nd[sl].contiguous(), a[sl].contiguous(), na[sl].contiguous(),
-                                                        rew[:, sl].contiguous(), done[sl].contiguous(), w[sl].contiguous(), 0.97, -10.0, 10.0)
+        U.tune_set(24, 8)
+        try:
+            l2, p2 = DistNStepTD(nstep, s1 - s0, N, n_atom)(d[sl].contiguous(), nd[sl].contiguous(), a[sl].contiguous(), na[sl].contiguous(),
+                                                            rew[:, sl].contiguous(), done[sl].contiguous(), w[sl].contiguous(), 0.97, -10.0, 10.0)
+        finally:
+            U.tune_set(24, 0)
         assert torch.equal(per[sl], p2), (s0, s1)
         parts.append(l2.double() * (s1 - s0))
     assert abs(loss.item() - (sum(parts) / B).item()) < 1e-6 * max(1.0, abs(loss.item()))

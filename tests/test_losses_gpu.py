@@ -318,6 +318,53 @@ def test_dntd_oracle_reference_shape():
     assert grad_err(d32.grad.numpy(), dd.grad.cpu().numpy()) < 1e-4
 
 
+def test_c51_run_sum_projection_against_the_gather_kernel_and_the_oracle():
+    """Large batches project by run sums (csrc/dist_ops.hip: c51_project_scan): the sources that share a floor atom are one
+    contiguous run of lanes, summed by a segmented doubling scan.  Pinned (a) against the small-batch kernel, which gathers
+    every target's sources one by one in source order (tune key 24 = 1 forces it): equal up to the rounding of a run's few
+    additions, 4e-7 of the maximum, most elements bit for bit; (b) against the fp32 oracle's two sequential scatter_add_
+    passes (origin/td.py:100-103 as restated in oracle/ref_torch.py).  Inputs hold terminal samples (all sources on the same
+    two atoms: one run of 51) and clamped returns (runs of 10+ sources at the ends of the support)."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.td import DistNStepTD
+    T, B, N, n_atom = 3, 65536, 4, 51
+    v_min, v_max, gamma = -10., 10., 0.95
+    rng = np.random.default_rng(11)
+    dist = (np.abs(f32(rng, B, N, n_atom)) + 1e-3).astype(np.float32)
+    nd = np.abs(f32(rng, B, N, n_atom))
+    a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+    r = (f32(rng, T, B) * 4.0).astype(np.float32)                       # some returns leave [v_min, v_max]: clamped atoms
+    done = (rng.random(B) < 0.3).astype(np.float32)
+    w = rng.random(B).astype(np.float32)
+    res = {}
+    try:
+        for key in (1, 0):
+            U.tune_set(24, key)
+            dd = G(dist, True)
+            loss, per = DistNStepTD(T, B, N, n_atom)(dd, G(nd), G(a), G(na), G(r), G(done), G(w), gamma, v_min, v_max)
+            loss.backward()
+            res[key] = (loss.item(), per.detach().cpu(), dd.grad.cpu())
+    finally:
+        U.tune_set(24, 0)
+    (l1, p1, g1), (l0, p0, g0) = res[1], res[0]
+    assert float((g0 - g1).abs().max()) < 4e-7 * float(g1.abs().max())
+    assert float((p0 - p1).abs().max()) < 1e-6 * float(p1.abs().max())
+    assert abs(l0 - l1) < 1e-6 * abs(l1)
+    assert float((g0 == g1).float().mean()) > 0.9                      # the summation order only matters for runs >= 3
+    d32 = torch.from_numpy(dist).requires_grad_(True)
+    l32, p32 = R.dist_nstep_td_error(d32, torch.from_numpy(nd), torch.from_numpy(a), torch.from_numpy(na),
+                                     torch.from_numpy(r), torch.from_numpy(done), torch.from_numpy(w), gamma, v_min, v_max, n_atom)
+    l32.backward()
+    # The reference drops the mass of a source whose projected position is integral (l == u: both weights 0), so a position
+    # that is integral on one side and one ulp off on the other (the oracle sums the n-step return in another order) moves
+    # a whole p_j: at 3.3e6 projected atoms a few hundred samples meet that discontinuity.  Everything else agrees to 1e-4.
+    assert rel_err(l32.item(), l0) < 1e-4
+    bad = (p32.detach() - p0).abs() > 1e-4 * float(p32.detach().abs().max())
+    assert float(bad.float().mean()) < 5e-3, float(bad.float().mean())
+    ok = ~bad
+    assert grad_err(d32.grad[ok].numpy(), g0[ok].numpy()) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ IQN / QR-DQN
 def test_iqn_golden(golden):
     from hpc_rll.rl_utils.td import IQNNStepTDError
@@ -385,6 +432,71 @@ def test_qrdqn_oracle_reference_shape():
     assert rel_err(l64.item(), loss.item()) < 2e-5
     assert rel_err(p64.detach().numpy(), per.cpu().numpy()) < 2e-5
     assert grad_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("tau,B,sw", [(32, 65536 + 37, 0), (32, 40000, 64), (20, 33000, 64), (51, 33000, 64), (5, 70001, 0),
+                                      (16, 33001, 32), (64, 20000, 8), (3, 9000, 64), (40, 140000, 0)])
+def test_qrdqn_samples_per_wave_kernel_equals_group_kernel(tau, B, sw):
+    """Large batches: a wave walks SW consecutive samples (csrc/dist_ops.hip: qrdqn_fwd_batch_kernel; scalars loaded
+    coalesced by owner lanes, targets staged through LDS).  Against the group-per-sample kernel (tune key 24 = 1) on ragged
+    batches, every group width, full and partial groups: unit gradients bit for bit, per-sample errors up to the order of
+    the tau-term sum (DPP instead of butterfly), and both against the fp64 oracle."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.td import QRDQNNStepTDError
+    T, N = 3, 6
+    rng = np.random.default_rng(tau * 1000 + sw)
+    q, nq = f32(rng, B, N, tau), f32(rng, B, N, tau)
+    a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+    r, done, w = f32(rng, T, B), (rng.random(B) < 0.3).astype(np.float32), rng.random(B).astype(np.float32)
+    vg = (0.9 + 0.1 * rng.random(B)).astype(np.float32)
+    res = {}
+    try:
+        for key in (1, sw):
+            U.tune_set(24, key)
+            dq = G(q, True)
+            loss, per = QRDQNNStepTDError(tau, T, B, N)(dq, G(nq), G(a), G(na), G(r), G(done), 0.95, G(w), G(vg))
+            loss.backward()
+            res[key] = (loss.item(), per.detach().cpu(), dq.grad.cpu())
+    finally:
+        U.tune_set(24, 0)
+    (l1, p1, g1), (l0, p0, g0) = res[1], res[sw]
+    assert torch.equal(g0, g1), (float((g0 - g1).abs().max()), float(g1.abs().max()), int((g0 != g1).sum()), (g0 != g1).nonzero()[:4].tolist())
+    assert float((p0 - p1).abs().max()) < 2e-6 * float(p1.abs().max())
+    assert abs(l0 - l1) < 2e-6 * abs(l1)
+    n = 4096                                                           # fp64 oracle on the ragged tail
+    q64 = D(q[-n:], True)
+    l64, p64 = R.qrdqn_nstep_td_error(q64, D(nq[-n:]), torch.from_numpy(a[-n:]), torch.from_numpy(na[-n:]), D(r[:, -n:]),
+                                      D(done[-n:]), tau, D(w[-n:]), 0.95, D(vg[-n:]))
+    l64.backward()
+    assert rel_err(p64.detach().numpy(), p0[-n:].numpy()) < 2e-5
+    assert grad_err(q64.grad.numpy() * (n / B), g0[-n:].numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("B,sw", [(70001, 0), (20011, 0), (9000, 8), (33000, 64)])
+def test_c51_samples_per_wave_kernel_ragged(B, sw):
+    """dist_nstep_fwd_batch_kernel on batches that are no multiple of the wave's sample count, against the gather kernel."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.td import DistNStepTD
+    T, N, n_atom = 2, 3, 51
+    rng = np.random.default_rng(B)
+    dist = (np.abs(f32(rng, B, N, n_atom)) + 1e-3).astype(np.float32)
+    nd = np.abs(f32(rng, B, N, n_atom))
+    a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+    r, done, w = f32(rng, T, B), (rng.random(B) < 0.3).astype(np.float32), rng.random(B).astype(np.float32)
+    res = {}
+    try:
+        for key in (1, sw):
+            U.tune_set(24, key)
+            dd = G(dist, True)
+            loss, per = DistNStepTD(T, B, N, n_atom)(dd, G(nd), G(a), G(na), G(r), G(done), G(w), 0.97, -5., 5.)
+            loss.backward()
+            res[key] = (loss.item(), per.detach().cpu(), dd.grad.cpu())
+    finally:
+        U.tune_set(24, 0)
+    (l1, p1, g1), (l0, p0, g0) = res[1], res[sw]
+    assert float((g0 - g1).abs().max()) < 4e-7 * float(g1.abs().max())
+    assert float((p0 - p1).abs().max()) < 1e-6 * float(p1.abs().max())
+    assert abs(l0 - l1) < 1e-6 * abs(l1)
 
 
 # ------------------------------------------------------------------------------------------------ misc
