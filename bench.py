@@ -229,7 +229,25 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # The data path has NO collective (batch-sharded GAE); the process group only carries the barriers and the
+            # gather of the per-rank times.  If RCCL cannot come up on a box (IPC mode, container limits) the measurement
+            # is still valid over gloo: fall back, and say so in the line (`scaling_detail.backend`).
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench rank {rank}] RCCL unavailable ({type(e).__name__}: {str(e)[:200]}); control plane over gloo",
+                      file=sys.stderr, flush=True)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                backend = "gloo"
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

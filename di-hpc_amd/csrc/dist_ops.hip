@@ -722,7 +722,7 @@ extern "C" int hpc_rll_dist_nstep_td_forward(const float* dist, const float* nex
         return HPC_RLL_EINVAL;
     // large batches: SW samples per wave (dist_nstep_fwd_batch_kernel); widths from tests/tools/r03_batch_probe.py
     int sw = g_sample_batch;
-    if (sw == 0) sw = B >= 262144 ? 32 : B >= 65536 ? 16 : B >= 16384 ? 8 : 1;
+    if (sw == 0) sw = B >= 262144 ? 16 : B >= 16384 ? 8 : 1;
     if (n_atom > 64) sw = 1;
     const int blocks = sw > 1 ? (int)(((long)B + 4 * sw - 1) / (4 * sw)) : (B + 3) / 4;
     // delta_z is a python double in the oracle, rounded to fp32 when it meets the fp32 tensor
@@ -824,7 +824,7 @@ extern "C" int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_
     if (tau <= 64) blocks = (B + 4 * (64 / group_lanes(tau)) - 1) / (4 * (64 / group_lanes(tau)));
     // large batches: SW consecutive samples per wave (qrdqn_fwd_batch_kernel); widths from tests/tools/r03_batch_probe.py
     int sw = g_sample_batch;
-    if (sw == 0) sw = B >= 262144 ? 64 : B >= 131072 ? 32 : B >= 65536 ? 16 : B >= 32768 ? 8 : 1;
+    if (sw == 0) sw = B >= 262144 ? 32 : B >= 32768 ? 8 : 1;
     if (tau > 64 || sw < 64 / group_lanes(tau)) sw = 1;
     if (sw > 1) blocks = (int)(((long)B + 4 * sw - 1) / (4 * sw));
     const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);

@@ -328,11 +328,11 @@ def test_td_family_large_batch_equals_its_slices():
 
     def c51(Bk, d, nd, a_, na_, r_, d_, w_):
         return DistNStepTD(nstep, Bk, N, n_atom)(d, nd, a_, na_, r_, d_, w_, 0.99, -10.0, 10.0)
-    check(lambda: [torch.softmax(rnd(B, N, n_atom), -1), torch.softmax(rnd(B, N, n_atom), -1)], c51, 0, sw=16)
+    check(lambda: [torch.softmax(rnd(B, N, n_atom), -1), torch.softmax(rnd(B, N, n_atom), -1)], c51, 0, sw=8)
 
     def qr(Bk, q, nq, a_, na_, r_, d_, w_):
         return QRDQNNStepTDError(tau, nstep, Bk, N)(q, nq, a_, na_, r_, d_, 0.99, w_)
-    check(lambda: [rnd(B, N, tau), rnd(B, N, tau)], qr, 0, sw=32)
+    check(lambda: [rnd(B, N, tau), rnd(B, N, tau)], qr, 0, sw=8)
 
     def iqn(Bk, q, nq, rq, a_, na_, r_, d_, w_):
         return IQNNStepTDError(tau, tau, nstep, Bk, N)(q, nq, a_, na_, r_, d_, rq, 0.99, 1.0, w_)
