@@ -301,8 +301,12 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-        barrier()
+        # closing bracket: this rank's own completion (synchronize), THEN the barrier -- the reported time is the max
+        # over ranks of completion times measured from a common start, so a straggler still counts in full, but the
+        # latency of the barrier collective itself (tens of us, against K x 40 us at 8 ranks) is not billed to the steps
+        torch.cuda.synchronize()
         mine = time.perf_counter() - t0
+        barrier()
         if dist is None:
             return mine, [mine]
         t = torch.tensor([mine], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
