@@ -876,6 +876,14 @@ extern "C" int64_t hpc_rll_lstm_workspace_floats(int S, int B, int I, int H, int
     return (int64_t)carve(nullptr, S, B, I, H, L, dropout_p > 0.f).total;
 }
 
+// Float offset, inside the workspace, of the last layer's h sequence (S,B,H) -- which IS y.  A caller that passes
+// y = ws + this offset gets y written in place by the cells and no copy (2.1 GB each way at C4: 0.8 ms of a 74 ms forward).
+extern "C" int64_t hpc_rll_lstm_workspace_y_offset(int S, int B, int I, int H, int L, float dropout_p) {
+    if (S < 0 || B < 0 || I < 0 || H < 0 || L <= 0 || L > 16) return -1;
+    float* const fake = reinterpret_cast<float*>((uintptr_t)1 << 20);
+    return (int64_t)(carve(fake, S, B, I, H, L, dropout_p > 0.f).layer[L - 1].hseq - fake);
+}
+
 extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float* c0, const float* wx,
                                     const float* wh, const float* bias, const float* ln_gamma, const float* ln_beta,
                                     float* y, float* hn, float* cn, float* ws, int S, int B, int I, int H, int L,
@@ -930,7 +938,7 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
                                    1.f / (1.f - dropout_p));
             }
         }
-        if ((rc = copy_async(y, w.layer[L - 1].hseq, SB * H, st))) return rc;
+        if (y != w.layer[L - 1].hseq && (rc = copy_async(y, w.layer[L - 1].hseq, SB * H, st))) return rc;
         return last_error();
     }
     PersistCfg pc{};
@@ -994,7 +1002,7 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
         }
         wx_off += (size_t)in_l * G;
     }
-    if (S > 0) {
+    if (S > 0 && y != w.layer[L - 1].hseq) {   // y inside the workspace (hpc_rll_lstm_workspace_y_offset): already written
         const int rc = copy_async(y, w.layer[L - 1].hseq, SB * H, st);
         if (rc) return rc;
     }

@@ -201,13 +201,24 @@ void LstmBackward(const OptList& in, const OptList& out, double dropout, std::op
 struct LstmFn : public ag::Function<LstmFn> {
     static ag::tensor_list forward(ag::AutogradContext* ctx, const Tensor& x, const Tensor& wx, const Tensor& wh,
                                    const Tensor& bias, const Tensor& gamma, const Tensor& beta, const Tensor& h0,
-                                   const Tensor& c0, double dropout, int64_t seed) {
+                                   const Tensor& c0, double dropout, int64_t seed, bool y_in_ws) {
         const LstmDims d = lstm_dims(x, h0, wx, wh);
         lstm_check_params(d, c0, bias, gamma, beta);
         c10::DeviceGuard g(d.dev);
-        Tensor y = new_f32({d.S, d.B, d.H}, d.dev), hn = new_f32({d.L, d.B, d.H}, d.dev),
-               cn = new_f32({d.L, d.B, d.H}, d.dev);
+        Tensor hn = new_f32({d.L, d.B, d.H}, d.dev), cn = new_f32({d.L, d.B, d.H}, d.dev);
         Tensor ws = new_f32({lstm_ws_floats(d, dropout)}, d.dev);
+        // Training: y is the last layer's h sequence where the cells wrote it -- a view of the workspace, which the graph
+        // keeps alive anyway (no (S,B,H) copy: 0.8 ms at C4; autograd refuses in-place writes to such
+        // an output view on the spot, so the saved workspace cannot be corrupted through y).  Without a graph y is its own tensor, so that it does not
+        // pin the workspace.
+        Tensor y;
+        if (y_in_ws && d.S > 0) {
+            const int64_t off = hpc_rll_lstm_workspace_y_offset((int)d.S, (int)d.B, (int)d.I, (int)d.H, (int)d.L, (float)dropout);
+            TORCH_CHECK(off >= 0, "lstm: workspace_y_offset failed");
+            y = ws.narrow(0, off, d.S * d.B * d.H).view({d.S, d.B, d.H});
+        } else {
+            y = new_f32({d.S, d.B, d.H}, d.dev);
+        }
         lstm_forward_launch(d, x, h0, c0, wx, wh, bias, gamma, beta, y, hn, cn, ws, dropout, (uint64_t)seed);
         ctx->save_for_backward({x, h0, c0, wx, wh, gamma, ws});
         ctx->saved_data["dropout"] = dropout;
@@ -235,7 +246,7 @@ struct LstmFn : public ag::Function<LstmFn> {
         lstm_backward_launch(d, cont(grads[0]), cont(grads[1]), cont(grads[2]), x, h0, c0, wx, wh, gamma, ws, gr,
                              ctx->saved_data["dropout"].toDouble(), (uint64_t)ctx->saved_data["seed"].toInt(),
                              ctx->saved_data["persist_epoch"].toInt());
-        return {gr.dx, gr.dwx, gr.dwh, gr.dbias, gr.dgamma, gr.dbeta, gr.dh0, gr.dc0, undef(), undef()};
+        return {gr.dx, gr.dwx, gr.dwh, gr.dbias, gr.dgamma, gr.dbeta, gr.dh0, gr.dc0, undef(), undef(), undef()};
     }
 };
 
@@ -371,7 +382,10 @@ PYBIND11_MODULE(hpc_torch_utils_network, m) {
 
     m.def("lstm", [](const Tensor& x, const Tensor& wx, const Tensor& wh, const Tensor& bias, const Tensor& gamma,
                      const Tensor& beta, const Tensor& h0, const Tensor& c0, double dropout, int64_t seed) {
-        return LstmFn::apply(x, wx, wh, bias, gamma, beta, h0, c0, dropout, seed);
+        const bool graph = at::GradMode::is_enabled() && (x.requires_grad() || wx.requires_grad() || wh.requires_grad() ||
+                                                          bias.requires_grad() || gamma.requires_grad() ||
+                                                          beta.requires_grad() || h0.requires_grad() || c0.requires_grad());
+        return LstmFn::apply(x, wx, wh, bias, gamma, beta, h0, c0, dropout, seed, graph);
     }, py::arg("x"), py::arg("wx"), py::arg("wh"), py::arg("bias"), py::arg("ln_gamma"), py::arg("ln_beta"), py::arg("h0"),
           py::arg("c0"), py::arg("dropout") = 0.0, py::arg("seed") = 0,
           "(y, hn, cn) = LayerNorm-LSTM(x (S,B,I), h0, c0 (L,B,H)); differentiable wrt x, the parameters, h0 and c0");

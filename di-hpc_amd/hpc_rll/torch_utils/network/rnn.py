@@ -63,7 +63,9 @@ class LSTM(nn.Module):
         self.register_parameter('ln_beta', nn.Parameter(torch.zeros(num_layers, hidden_size * 4 * 2)))
 
     def forward(self, inputs, prev_state):
-        """inputs (S,B,input_size); prev_state None or (h0, c0) each (num_layers,B,H) -> (y (S,B,H), [h, c])."""
+        """inputs (S,B,input_size); prev_state None or (h0, c0) each (num_layers,B,H) -> (y (S,B,H), [h, c]).
+        When a graph is recorded, y is handed out where the last layer's cells wrote it (a view of the op's saved
+        workspace: no (S,B,H) copy); autograd refuses in-place writes to it -- use out-of-place ops on y."""
         assert inputs.is_cuda
         if prev_state is None:
             zeros = torch.zeros(self.num_layers, inputs.shape[1], self.hidden_size, dtype=inputs.dtype,

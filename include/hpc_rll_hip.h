@@ -309,6 +309,10 @@ int hpc_rll_scatter_connection_backward(const float* grad_out, const int64_t* lo
  * S*B x I x 4H input-gradient product of layer 0 is then skipped.
  * ------------------------------------------------------------------------------------------ */
 int64_t hpc_rll_lstm_workspace_floats(int S, int B, int I, int H, int L, float dropout_p);
+/* Float offset of the last layer's h sequence inside ws.  It IS y (the reference keeps it the same way: ym[L-1],
+ * rnn.py:27-31): a forward called with y = ws + offset writes y in place and skips the (S,B,H) copy; any other y is
+ * filled by a copy as before.  -1 on invalid arguments. */
+int64_t hpc_rll_lstm_workspace_y_offset(int S, int B, int I, int H, int L, float dropout_p);
 int hpc_rll_lstm_forward(const float* x, const float* h0, const float* c0, const float* wx, const float* wh,
                          const float* bias, const float* ln_gamma, const float* ln_beta, float* y, float* hn,
                          float* cn, float* ws, int S, int B, int I, int H, int L, float dropout_p, uint64_t seed,

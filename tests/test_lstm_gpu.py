@@ -187,6 +187,32 @@ def test_lstm_reference_usage_pattern():
     assert torch.equal(out[-1], h[-1])
 
 
+@pytest.mark.parametrize("S,B,I,H,L,p", [(12, 3, 40, 48, 3, 0.0), (8, 20, 36, 64, 2, 0.0), (6, 40, 32, 64, 2, 0.25)])
+def test_lstm_training_output_is_written_in_place(S, B, I, H, L, p):
+    """With a graph, y is the last layer's h sequence where the cells wrote it (a view of the workspace,
+    hpc_rll_lstm_workspace_y_offset): no (S,B,H) copy.  Without one, y is its own tensor (it must not pin the workspace).
+    Same bits both ways; an in-place write to y is refused by autograd (use an out-of-place op)."""
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(5)
+    m = LSTM(S, B, I, H, L, dropout=p).to(DEV)
+    x = torch.randn(S, B, I, device=DEV, requires_grad=True)
+    torch.manual_seed(9)
+    y, (hn, cn) = m(x, None)
+    with torch.no_grad():
+        torch.manual_seed(9)
+        y0, (hn0, cn0) = m(x, None)
+    assert y._base is not None and y0._base is None
+    assert y0.untyped_storage().nbytes() == y0.numel() * 4 and y.untyped_storage().nbytes() > y.numel() * 4
+    if p == 0.0:
+        assert torch.equal(y, y0) and torch.equal(hn, hn0) and torch.equal(cn, cn0)
+    assert torch.equal(y[-1], hn[-1])
+    y.sum().backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    y2, _ = m(x, None)
+    with pytest.raises(RuntimeError, match="inplace"):      # refused on the spot: y is a view handed out by the node
+        y2.mul_(2.0)
+
+
 @pytest.mark.parametrize("S,B,I,H,L", [(12, 3, 40, 48, 3), (10, 2, 24, 320, 2), (8, 20, 36, 64, 2)])   # wavefront / per-layer / step kernels
 def test_lstm_input_without_grad(S, B, I, H, L):
     """x.requires_grad = False: the C ABI gets dx = NULL and skips the layer-0 input-gradient product; every other
