@@ -319,6 +319,8 @@ __device__ __forceinline__ float c51_project64(int lane, int n_atom, float R, fl
 // the number of waves a SIMD can hold (0.26 ms for 248 + 59 MB at B = 262144): here the per-sample
 // scalars of all S samples are fetched together, then the 2*S rows, then the S projections run back to back.  The
 // arithmetic of a sample is unchanged (bit-identical td_err / buf); the workgroup partial adds 4*S contributions in order.
+// (Dispatched with S = 1 since dist_nstep_fwd_batch_kernel took over the large batches; S = 4 measured 0.187 ms at
+// B = 262144 against 0.069 ms for the batch kernel, tests/tools/r03_batch_probe.py.)
 template <int S>
 __global__ __launch_bounds__(256) void dist_nstep_fwd64_kernel(
     const float* __restrict__ dist, const float* __restrict__ next_dist, const int64_t* __restrict__ action,
