@@ -1,3 +1,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_lstm_gpu.py tests/test_graphed_gpu.py tests/test_reference_lists_gpu.py tests/test_fuzz_gpu.py tests/test_dist.py tests/test_models_gpu.py -q -p no:cacheprovider -x -m gpu 2>&1 | grep -v amdgpu | tail -8
+for i in 1 2; do
+for L in tests/tools/micro/libhpc_rll_hip_v2.so ""; do
+  echo "== lib ${L:-current}"
+  HPC_RLL_LIB=$L PROBE_B=262144,131072,32768 PROBE_SW=0,8,32,64 python tests/tools/r03_batch_probe.py 2>&1 | grep qrdqn | cut -c1-48
+done
+done
