@@ -51,7 +51,7 @@ struct GemmArgs {
     int prio = 0;          // 1: s_setprio(1) around the MFMA clusters (tune key 23 bit 0; experiment)
 };
 
-enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2 };
+enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2, kDmaK = 3 };   // kDmaK: k-contiguous, staged by LDS-DMA (DmaStage)
 
 // LDS address (in floats) of position pp (0..BK-1) of the PERMUTED row x of a tile with BK floats per row.
 template <int BK> __device__ __forceinline__ int lds_sw(int x) { return BK == 16 ? ((x >> 2) & 3) : ((x >> 1) & 7); }
@@ -62,6 +62,43 @@ template <int BK> __device__ __forceinline__ int lds_pos(int x, int pp) {
 template <int BK> __device__ __forceinline__ int kperm(int k) { return (k & 1) * (BK / 2) + (k >> 1); }
 
 typedef float gf2 __attribute__((ext_vector_type(2)));
+
+// Round 3: a k-contiguous operand staged by LDS-DMA (global_load_lds_dwordx4, gfx950): no staging registers, no ds_write,
+// and -- what the ablation of round 2 had isolated as the cost of the HBM/L2 stream -- no register-returning vector-memory
+// instruction between the MFMAs (tests/tools/micro/gemm_ablate.hip ABL 4, profiles/r03_gemm_ablate_dma.txt: 4096^3
+// 132.7 -> 138-139 TFLOP/s, the C4 x-branch shape 130.9 -> 136-137).  A DMA piece lands as 64 lanes x 16 bytes CONTIGUOUS at
+// a wave-uniform LDS base, so the tile's layout is dictated: 16-byte slot e of the tile <-> (row e / CPR, physical chunk
+// e % CPR).  What stays free is WHICH 16 bytes of global memory a lane asks for, and that is enough for the XOR swizzle of
+// lds_pos(): the lane of slot (row, pc) fetches the row's logical chunk pc ^ lds_sw(row).  What is NOT possible at 16-byte
+// granularity is the even/odd k permutation inside a row, so rows are kept RAW (k in memory order) and the permutation
+// moves into the meaning of the MFMA steps: lane half h still reads the h-th half of its row with ds_read_b128, but that
+// half is now k = 8h .. 8h+7 of the k-tile (BK = 16), i.e. MFMA step s multiplies k = s and k = 8 + s.  Both operands must
+// use the convention (kDmaK x kDmaK only); each output is still one exact fp32 fma chain, in another k order than the
+// register-staged kernels (same order for every tile shape that takes this path).
+template <int X, int BK, int NT>
+struct DmaStage {
+    static constexpr int CPR = BK / 4;                   // 16-byte chunks per row
+    static constexpr int NP = X * CPR / NT;              // pieces per thread and k-tile
+    static_assert((X * CPR) % NT == 0 && NT % 64 == 0, "DMA staging thread set");
+    const float* p[NP];
+    __device__ __forceinline__ void init(const float* __restrict__ base, long sx, int x0, int k0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int e = j * NT + (int)threadIdx.x, r = e / CPR, pc = e % CPR;
+            p[j] = base + (long)(x0 + r) * sx + k0 + 4 * (pc ^ lds_sw<BK>(r));
+        }
+    }
+    __device__ __forceinline__ void issue(float* tile) {     // one k-tile: NP pieces, then step to the next k-tile
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* gl_ptr;
+        const int wave = (int)threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            __builtin_amdgcn_global_load_lds((gl_ptr)p[j], (lds_ptr)(tile + (j * NT + wave * 64) * 4), 16, 0, 0);
+            p[j] += BK;
+        }
+    }
+};
 
 // Stages one operand tile (X rows-of-the-operand by BK k) through registers, using threads [T0, T0+NT) of the workgroup.
 //   MODE kContigMN: element (x,k) at base[x + k*sk]        (unit stride along x)
@@ -117,6 +154,28 @@ struct TileStage {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     v[i * 4 + r] = *reinterpret_cast<const gf4*>(p + (long)(i * 4 * (NT / KQ) + r) * sx);
+            }
+        }
+    }
+
+    // ABL 4 (tests/tools/micro/gemm_ablate.hip only, WRONG results): the loads of load_fast as LDS-DMA pieces
+    // (global_load_lds_dwordx4: 64 lanes x 16 bytes land contiguously at an M0 base, no VGPRs, no ds_write) -- what the
+    // staging would cost if the tile layout were the DMA's.  The LDS positions are arbitrary inside the tile.
+    __device__ __forceinline__ void dma_fast(long sx, long sk, float* lds_tile) {
+        if (!active()) return;
+        const int lt = (int)threadIdx.x - T0;
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* gl_ptr;
+        const int wv = lt >> 6;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (lt + i * NT >= NBLK) break;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float* src = MODE == kContigMN ? p + (long)(2 * t) * sk + i * 4 * (NT / NSET)
+                                                     : p + (long)(i * 4 * (NT / KQ) + t) * sx;
+                float* dst = lds_tile + (((i * 4 + t) * (NT / 64) + wv) * 256) % (X * BK);
+                __builtin_amdgcn_global_load_lds((gl_ptr)src, (lds_ptr)dst, 16, 0, 0);
             }
         }
     }
@@ -218,7 +277,8 @@ template <int BM, int BN, int BK, int NW = 4> struct GemmOcc {
 // loop (see TileStage::load_fast) or the guarded one.  (Both loops in one kernel behind a uniform branch cost 20-40
 // registers and spilled in the NT variants.)
 // ABL != 0: ablation builds for tests/tools/micro/gemm_ablate.hip only (WRONG results): 1 = MFMAs + LDS operand reads
-// only; 2 = + global prefetch (waited for where the LDS store would be); 3 = + LDS store + barrier, no global loads.
+// only; 2 = + global prefetch (waited for where the LDS store would be); 3 = + LDS store + barrier, no global loads;
+// 4 = staging by LDS-DMA (global_load_lds_dwordx4) + barrier instead of register prefetch + ds_write.
 // Where the time goes (tests/tools/micro/gemm_ablate.hip, profiles/r02_gemm_ablate.txt; 4096^3 NN, full-entropy data,
 // shader clock measured in-run at 2.41 GHz): MFMAs + the b128 operand reads alone 150 TFLOP/s (95 % of the matrix
 // rate; 136 with the first version's b32 reads); + LDS store and barrier 141; + the global prefetch 129 -- the same
@@ -262,8 +322,8 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
     // who stages what: both tiles together <= 256 blocks -> disjoint wave sets, one block per thread
     constexpr int NBA = BM * BK / 16, NBB = BN * BK / 16;
     constexpr bool SPLIT = NBA + NBB <= NTH && NBA % 64 == 0 && NBB % 64 == 0;
-    TileStage<BM, BK, AMODE, 0, SPLIT ? NBA : NTH> sa;
-    TileStage<BN, BK, BMODE, SPLIT ? NBA : 0, SPLIT ? NBB : NTH> sb;
+    TileStage<BM, BK, AMODE == kDmaK ? kContigK : AMODE, 0, SPLIT ? NBA : NTH> sa;     // (unused with LDS-DMA staging)
+    TileStage<BN, BK, BMODE == kDmaK ? kContigK : BMODE, SPLIT ? NBA : 0, SPLIT ? NBB : NTH> sb;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -280,10 +340,25 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
     const int KE = min(g.K, kbeg + per * BK);            // exclusive k end of this slice
     const int ktiles = KE > kbeg ? (KE - kbeg + BK - 1) / BK : 0;
     float* const Cz = g.C + (long)blockIdx.z * g.c_split;
-    sa.load(g.A, g.a_sm, g.a_sk, m0, kbeg, g.M, KE);
-    sb.load(g.B, g.b_sn, g.b_sk, n0, kbeg, g.N, KE);
-    sa.store(As);
-    sb.store(Bs);
+    constexpr bool DMA = AMODE == kDmaK;
+    static_assert((AMODE == kDmaK) == (BMODE == kDmaK), "LDS-DMA staging: both operands or none (k convention)");
+    static_assert(!DMA || (INTERIOR && BK == 16 && ABL == 0), "LDS-DMA staging: interior tiles, 64-byte rows");
+    DmaStage<BM, BK, NTH> da;
+    DmaStage<BN, BK, NTH> db;
+    if constexpr (DMA) {
+        da.init(g.A, g.a_sm, m0, kbeg);
+        db.init(g.B, g.b_sn, n0, kbeg);
+        if (ktiles > 0) {
+            da.issue(As);
+            db.issue(Bs);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        sa.load(g.A, g.a_sm, g.a_sk, m0, kbeg, g.M, KE);
+        sb.load(g.B, g.b_sn, g.b_sk, n0, kbeg, g.N, KE);
+        sa.store(As);
+        sb.store(Bs);
+    }
     __syncthreads();
     // operand fetch: lane (x = lane & 31, h = lane >> 5) reads the h-th half of its permuted row, 16 bytes = 4 MFMA steps
     // at a time; block i of the wave sits 32 rows further (same swizzle): an immediate offset
@@ -319,7 +394,20 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
             if (NW == 16 && g.prio) __builtin_amdgcn_s_setprio(0);
         }
     };
-    if constexpr (INTERIOR) {
+    if constexpr (DMA) {
+        // next k-tile requested straight into the other LDS buffer (every wave has passed the barrier that ended the last
+        // reads of that buffer), MFMAs of this one, then: my pieces have landed (vmcnt) + everyone's (barrier)
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < ktiles) {
+                da.issue(As + (buf ^ 1) * BK * BM);
+                db.issue(Bs + (buf ^ 1) * BK * BN);
+            }
+            mfma_tile(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else if constexpr (INTERIOR) {
         sa.init(g.A, g.a_sm, g.a_sk, m0, kbeg + BK);
         sb.init(g.B, g.b_sn, g.b_sk, n0, kbeg + BK);
         for (int kt = 0; kt < ktiles; ++kt) {
@@ -331,7 +419,19 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
                 sa.advance(g.a_sk);
                 sb.advance(g.b_sk);
             }
+            if constexpr (ABL == 4) {
+                if (kt + 1 < ktiles) {
+                    sa.dma_fast(g.a_sm, g.a_sk, As + (buf ^ 1) * BK * BM);
+                    sb.dma_fast(g.b_sn, g.b_sk, Bs + (buf ^ 1) * BK * BN);
+                    sa.advance(g.a_sk);
+                    sb.advance(g.b_sk);
+                }
+            }
             mfma_tile(buf);
+            if constexpr (ABL == 4) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
             if (kt + 1 < ktiles && (ABL == 0 || ABL == 3)) {
                 sa.store(As + (buf ^ 1) * BK * BM);
                 sb.store(Bs + (buf ^ 1) * BK * BN);
@@ -378,6 +478,19 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
 }
 
 inline bool gemm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Would launch_gemm take the 256x256x16 tile for this problem (and, with both operands k-contiguous, its LDS-DMA form)?
+// Callers that can present an operand either way (lstm.hip: a weight or its transposed copy) ask before choosing.
+inline bool gemm_tile256_ok(int M, int N, int K, int splitk) {
+    extern int g_gemm_tile256;
+    const int sk = splitk > 1 ? splitk : 1;
+    const long wgs = (long)(M / 256) * (N / 256) * sk;
+    return g_gemm_tile256 && M > 0 && N > 0 && M % 256 == 0 && N % 256 == 0 && K % 16 == 0 && (wgs % 256 == 0 || wgs >= 4096);
+}
+inline bool gemm_dma_ok(int M, int N, int K, int splitk) {
+    extern int g_gemm_dma;   // tuning knob (hpc_rll_tune_set key 25)
+    return g_gemm_dma && gemm_tile256_ok(M, N, K, splitk) && (splitk <= 1 || (K / 16) % splitk == 0);
+}
 
 // Staging mode an operand admits.  x = the operand's non-k axis (m for A, n for B).
 inline int gemm_mode(const float* p, long sx, long sk, int XD, int KD) {
@@ -490,6 +603,11 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
             h.xcd_swizzle = 0;   // measured neutral for this tile (136.5 vs 136.7)
             extern int g_gemm_exp;   // tune key 23 (experiments): bit 0 s_setprio around the MFMA clusters, bit 1 BK = 32
             h.prio = g_gemm_exp & 1;
+            extern int g_gemm_dma;   // tune key 25: LDS-DMA staging for NT products (both operands k-contiguous)
+            if (g_gemm_dma && am == kContigK && bm == kContigK && (sk == 1 || (g.K / 16) % sk == 0)) {
+                hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 16, 2, 2, kDmaK, kDmaK, true, 0, 16>), grid, dim3(1024), 0, st, h);
+                return;
+            }
 #define HPC_RLL_GEMM256(AM, BMD)                                                                                          \
             if (am == AM && bm == BMD) {                                                                                  \
                 if ((g_gemm_exp & 2) && g.K % 32 == 0)                                                                    \

@@ -27,6 +27,7 @@
 namespace hpc_rll {
 int g_gemm_bk = 0;
 int g_gemm_exp = 0;   // hpc_rll_tune_set key 23: GEMM experiments (bit 0 s_setprio around MFMA clusters, bit 1 BK = 32 for 256x256 tiles)
+int g_gemm_dma = 1;   // LDS-DMA staging of NT products on the 256x256x16 tile (hpc_rll_tune_set key 25; gemm_f32.hpp: DmaStage)
 int g_gemm_tile256 = 1;   // 256x256x16 tiles (16 waves) for interior products that fill the chip in whole rounds (tune key 16)
 int g_cell_vec4 = 3;   // smallest ceil(H/256) that takes the 16-byte forward cell kernel (tune key 15; 0 = never)
 int g_gemm_xcd = 1;
@@ -953,8 +954,12 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
         const LayerWs& lw = w.layer[l];
         if (S > 0) {
             const int skf = gemm_splitk((int)SB, (int)G, in_l);
-            GemmArgs g{xin, wx_l, skf > 1 ? w.wpart : lw.xw, (int)SB, (int)G, in_l, in_l, 1, (long)G, 1, (long)G, 0, skf,
-                       (long)(SB * G)};
+            // Products whose tiles take the LDS-DMA kernel run as NT against a weight copy transposed once per layer
+            // (~10 us): both operands k-contiguous is what the DMA staging needs (gemm_f32.hpp: DmaStage)
+            const bool nt = gemm_dma_ok((int)SB, (int)G, in_l, skf);
+            if (nt) launch_transpose(wx_l, w.wxT, in_l, (int)G, st);   // (in, G) -> (G, in): B(k=i, n=g) = wxT[g*in + i]
+            GemmArgs g{xin, nt ? (const float*)w.wxT : wx_l, skf > 1 ? w.wpart : lw.xw, (int)SB, (int)G, in_l, in_l, 1,
+                       nt ? 1 : (long)G, nt ? (long)in_l : 1, (long)G, 0, skf, (long)(SB * G)};
             launch_gemm(g, st);
             if (skf > 1)
                 hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((SB * G + 255) / 256)), dim3(256), 0, st,
@@ -971,13 +976,16 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
             if (prc) return prc;
             persist_prof_report("fwd", l, S, st);
         }
+        const int sk_rec = gemm_splitk(B, (int)G, H);
+        const bool nt_rec = !persist && S > 0 && gemm_dma_ok(B, (int)G, H, sk_rec);
+        if (nt_rec) launch_transpose(wh_l, w.whT, H, (int)G, st);      // (H, G) -> (G, H): B(k=h, n=g) = whT[g*H + h]
         for (int s = 0; s < S && !persist; ++s) {
             const float* h_prev = s == 0 ? h0 + (size_t)l * BH : lw.hseq + (size_t)(s - 1) * BH;
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
             float* hw_s = lw.hw + (size_t)s * B * G;
-            const int sk = gemm_splitk(B, (int)G, H);
-            GemmArgs g{h_prev, wh_l, sk > 1 ? w.hw_part : hw_s, B, (int)G, H, H, 1, (long)G, 1, (long)G, 0, sk,
-                       (long)((size_t)B * G)};
+            const int sk = sk_rec;
+            GemmArgs g{h_prev, nt_rec ? (const float*)w.whT : wh_l, sk > 1 ? w.hw_part : hw_s, B, (int)G, H, H, 1,
+                       nt_rec ? 1 : (long)G, nt_rec ? (long)H : 1, (long)G, 0, sk, (long)((size_t)B * G)};
             launch_gemm(g, st);
             launch_cell_fwd(H, B, st, (const float*)(lw.xw + (size_t)s * B * G),
                             (const float*)(sk > 1 ? w.hw_part : hw_s), sk, (long)((size_t)B * G), hw_s,
@@ -1077,7 +1085,8 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         if (dxin) {
             const int skd = gemm_splitk((int)SB, in_l, (int)G);
             // NN against a transposed copy only where it was measured to win (C4: -2 %; B <= 1024: +2..5 %)
-            if (g_lstm_nn_bwd && (double)SB * in_l >= (double)(1u << 28)) {
+            // (with LDS-DMA staging the NT form -- the weights as they lie -- is the fast one: no transposed copy)
+            if (g_lstm_nn_bwd && (double)SB * in_l >= (double)(1u << 28) && !gemm_dma_ok((int)SB, in_l, (int)G, skd)) {
                 launch_transpose(wx_l, w.wxT, in_l, (int)G, st);   // (in, G) -> (G, in): B(k=g, n=i) = wxT[g*in + i]
                 GemmArgs g{p_dxw, w.wxT, skd > 1 ? w.wpart : dxin, (int)SB, in_l, (int)G, (long)G, 1, (long)in_l, 1,
                            (long)in_l, 0, skd, (long)(SB * in_l)};
@@ -1129,9 +1138,12 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         const float* dh_carry = dhn ? dhn + (size_t)l * BH : nullptr;
         const float* dc_carry = dcn ? dcn + (size_t)l * BH : nullptr;
         int dh_parts = 1;                                   // how many split-K partials dh_carry consists of
-        const bool nn_dh = g_lstm_nn_bwd != 0 && (long)B * H >= (1L << 22);   // large batches only (measured)
+        bool nn_dh = g_lstm_nn_bwd != 0 && (long)B * H >= (1L << 22);   // large batches only (measured)
         // NN form: 128x128x16 tiles with their own split-K (one round of ~1024 workgroups), like the forward product
-        const int sk_dh = (nn_dh && g_lstm_dh_big) ? gemm_splitk_big(B, H, (int)G) : gemm_splitk(B, H, (int)G);
+        int sk_dh = (nn_dh && g_lstm_dh_big) ? gemm_splitk_big(B, H, (int)G) : gemm_splitk(B, H, (int)G);
+        const bool dh_big = nn_dh && g_lstm_dh_big;
+        // ... unless that product takes the LDS-DMA kernel as NT against Wh as it lies (no transposed copy)
+        if (nn_dh && gemm_dma_ok(B, H, (int)G, sk_dh)) nn_dh = false;
         if (persist) {   // one kernel walks the whole sequence of this layer backwards (lstm_persist.hpp)
             PersistBwd a{d_out, dh_carry, dc_carry, lw.gates, lw.c, c0 + (size_t)l * BH, lw.xw, lw.hw, lw.stats, gamma_l,
                          wh_l, w.dgate, w.dxw, w.dhw, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, (u64*)w.xchg,
@@ -1159,7 +1171,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             else launch_cell_bwd(B, st, ca);
             // dh_prev (B,H) = dHW_s (B,G) @ Wh^T, as an NN product against the transposed copy
             GemmArgs g{w.dhw + (size_t)s * B * G, nn_dh ? (const float*)w.whT : wh_l, w.dh, B, H, (int)G, (long)G, 1,
-                       nn_dh ? (long)H : 1, nn_dh ? 1 : (long)G, (long)H, 0, sk_dh, (long)BH, (nn_dh && g_lstm_dh_big) ? 1 : 0};
+                       nn_dh ? (long)H : 1, nn_dh ? 1 : (long)G, (long)H, 0, sk_dh, (long)BH, dh_big ? 1 : 0};
             launch_gemm(g, st);
             dh_carry = w.dh;
             dh_parts = sk_dh;

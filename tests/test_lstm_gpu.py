@@ -407,6 +407,7 @@ def test_gemm_256_tile_is_bit_identical_to_128_tile():
     bt = b.t().contiguous()
     at_ = a.t().contiguous()
     try:
+        U.tune_set(25, 0)        # register staging for NT too (its LDS-DMA form has another k order: next test)
         outs = {}
         for key in (1, 0):
             U.tune_set(16, key)
@@ -418,6 +419,38 @@ def test_gemm_256_tile_is_bit_identical_to_128_tile():
         assert ((outs[1][0].double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
     finally:
         U.tune_set(16, 1)
+        U.tune_set(25, 1)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 16), (4096, 4096, 48), (2048, 8192, 1024), (8192, 8192, 272), (256, 65536, 64)])
+def test_gemm_lds_dma_staging(M, N, K):
+    """Tune key 25: NT products (both operands contiguous along k) on the 256x256x16 tile stage their tiles by LDS-DMA
+    (global_load_lds_dwordx4; gemm_f32.hpp: DmaStage): rows land raw, XOR-swizzled through the choice of the global chunk a
+    lane asks for, and MFMA step s multiplies k = s and k = 8 + s of the k-tile.  Against the register-staged kernel
+    (another k order: equal to fp32 rounding, NOT bit for bit -- which also shows that the other kernel ran) and against
+    fp64, on shapes with one k-tile, an odd number of k-tiles, many k-tiles, several rounds of workgroups."""
+    import hpc_torch_utils_network as U
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    bt = torch.randn(N, K, device=DEV, generator=g)
+    try:
+        U.tune_set(25, 1)
+        dma = U.gemm_f32(a, bt.t())
+        again = U.gemm_f32(a, bt.t())
+        U.tune_set(25, 0)
+        reg = U.gemm_f32(a, bt.t())
+    finally:
+        U.tune_set(25, 1)
+    assert torch.equal(dma, again)
+    ref = a.double() @ bt.double().t()
+    scale = ref.abs().max().item()
+    assert (dma.double() - ref).abs().max().item() < 1e-5 * scale
+    assert (dma - reg).abs().max().item() < 4e-6 * scale
+    if K >= 48:
+        assert not torch.equal(dma, reg)
+    out = torch.full((M, N), 3.0, device=DEV)                 # accumulate form
+    U.gemm_f32(a, bt.t(), out, True)
+    assert (out - 3.0 - dma).abs().max().item() < 4e-6 * scale
 
 
 _STARVED = r"""

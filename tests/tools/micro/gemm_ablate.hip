@@ -4,6 +4,7 @@
 //   ABL 1  MFMAs + LDS operand reads only          -> ceiling of the inner loop as written
 //   ABL 2  + global prefetch into registers         -> cost of the HBM/L2 stream beside the MFMAs
 //   ABL 3  + LDS store + barrier, no global loads   -> cost of the staging / synchronisation structure
+//   ABL 4  staging by LDS-DMA pieces (global_load_lds_dwordx4) + barrier: no staging registers, no ds_write (round 3)
 //   ABL 0  everything
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I di-hpc_amd/csrc -I include tests/tools/micro/gemm_ablate.hip
 //               -o tests/tools/micro/gemm_ablate.bin
@@ -107,6 +108,9 @@ int main() {
         run<256, 256, 16, 2, 2, 0, 0, 16>("256x256x16 16 waves, no xcd order", A, B, C, M, N, K, 0);
         run<256, 256, 16, 2, 2, 1, 0, 16>("256x256x16 16 waves ABL1", A, B, C, M, N, K, 1);
         run<256, 256, 16, 2, 2, 3, 0, 16>("256x256x16 16 waves ABL3", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 4, 0, 16>("256x256x16 16 waves ABL4 LDS-DMA NN", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 4, 2, 16>("256x256x16 16 waves ABL4 LDS-DMA NT", A, B, C, M, N, K, 1);
+        run<128, 128, 16, 2, 2, 4>("128x128x16 ABL4 LDS-DMA NN", A, B, C, M, N, K, 1);
         run<256, 256, 16, 2, 2, 0, 2, 16>("256x256x16 16 waves NT", A, B, C, M, N, K, 1);
         run<256, 256, 16, 2, 2, 0, 1, 16>("256x256x16 16 waves TN", A, B, C, M, N, K, 1);
         run<256, 256, 32, 2, 2, 0, 0, 16>("256x256x32 16 waves full NN", A, B, C, M, N, K, 1);
