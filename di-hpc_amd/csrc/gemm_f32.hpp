@@ -161,6 +161,7 @@ struct TileStage {
     // ABL 4 (tests/tools/micro/gemm_ablate.hip only, WRONG results): the loads of load_fast as LDS-DMA pieces
     // (global_load_lds_dwordx4: 64 lanes x 16 bytes land contiguously at an M0 base, no VGPRs, no ds_write) -- what the
     // staging would cost if the tile layout were the DMA's.  The LDS positions are arbitrary inside the tile.
+    template <int SZ = 16>   // SZ = 4: the same bytes as 4-byte pieces (any layout / transposition possible, 4x the instructions)
     __device__ __forceinline__ void dma_fast(long sx, long sk, float* lds_tile) {
         if (!active()) return;
         const int lt = (int)threadIdx.x - T0;
@@ -174,8 +175,16 @@ struct TileStage {
             for (int t = 0; t < 4; ++t) {
                 const float* src = MODE == kContigMN ? p + (long)(2 * t) * sk + i * 4 * (NT / NSET)
                                                      : p + (long)(i * 4 * (NT / KQ) + t) * sx;
-                float* dst = lds_tile + (((i * 4 + t) * (NT / 64) + wv) * 256) % (X * BK);
-                __builtin_amdgcn_global_load_lds((gl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+                if constexpr (SZ == 16) {
+                    float* dst = lds_tile + (((i * 4 + t) * (NT / 64) + wv) * 256) % (X * BK);
+                    __builtin_amdgcn_global_load_lds((gl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float* dst = lds_tile + ((((i * 4 + t) * 4 + e) * (NT / 64) + wv) * 64) % (X * BK);
+                        __builtin_amdgcn_global_load_lds((gl_ptr)(src + e), (lds_ptr)dst, 4, 0, 0);
+                    }
+                }
             }
         }
     }
@@ -278,14 +287,17 @@ template <int BM, int BN, int BK, int NW = 4> struct GemmOcc {
 // registers and spilled in the NT variants.)
 // ABL != 0: ablation builds for tests/tools/micro/gemm_ablate.hip only (WRONG results): 1 = MFMAs + LDS operand reads
 // only; 2 = + global prefetch (waited for where the LDS store would be); 3 = + LDS store + barrier, no global loads;
-// 4 = staging by LDS-DMA (global_load_lds_dwordx4) + barrier instead of register prefetch + ds_write.
+// 4 = staging by LDS-DMA (global_load_lds_dwordx4) + barrier instead of register prefetch + ds_write; 5 = the same bytes
+// as 4-byte LDS-DMA pieces (what an m/n-contiguous operand would need).
 // Where the time goes (tests/tools/micro/gemm_ablate.hip, profiles/r02_gemm_ablate.txt; 4096^3 NN, full-entropy data,
 // shader clock measured in-run at 2.41 GHz): MFMAs + the b128 operand reads alone 150 TFLOP/s (95 % of the matrix
 // rate; 136 with the first version's b32 reads); + LDS store and barrier 141; + the global prefetch 129 -- the same
 // with one or TWO k-tiles of prefetch in flight (a second register set, tried and removed), with 128x128 or 256x128
 // tiles, with full or half cache lines per load (TN / NT / NN all within 127-130): what the stream costs is not its
 // latency but the ISSUE of the vector-memory instructions beside the MFMAs (~65 cycles of matrix pipe per
-// global_load_dwordx4 of a wave; MI355X_MICROARCH.md quotes ~60 for an LDS-DMA piece).
+// global_load_dwordx4 of a wave; MI355X_MICROARCH.md quotes ~60 for an LDS-DMA piece -- measured in round 3 (ABL 4): a
+// dwordx4 LDS-DMA piece costs nothing measurable, the kernel then runs at the rate of "LDS store + barrier, no global
+// loads"; hence DmaStage below for the products whose operands are both k-contiguous).
 // NW: waves per workgroup (4, or 16 for the 256x256 tile: half the vector-memory instructions per MFMA).
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool INTERIOR, int ABL = 0, int NW = 4>
 __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gemm_f32_kernel(const GemmArgs g) {
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
     float* const Cz = g.C + (long)blockIdx.z * g.c_split;
     constexpr bool DMA = AMODE == kDmaK;
     static_assert((AMODE == kDmaK) == (BMODE == kDmaK), "LDS-DMA staging: both operands or none (k convention)");
-    static_assert(!DMA || (INTERIOR && BK == 16 && ABL == 0), "LDS-DMA staging: interior tiles, 64-byte rows");
+    static_assert(!DMA || (INTERIOR && (BK == 16 || BK == 32) && ABL == 0), "LDS-DMA staging: interior tiles, 64- or 128-byte rows");
     DmaStage<BM, BK, NTH> da;
     DmaStage<BN, BK, NTH> db;
     if constexpr (DMA) {
@@ -419,16 +431,16 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
                 sa.advance(g.a_sk);
                 sb.advance(g.b_sk);
             }
-            if constexpr (ABL == 4) {
+            if constexpr (ABL == 4 || ABL == 5) {
                 if (kt + 1 < ktiles) {
-                    sa.dma_fast(g.a_sm, g.a_sk, As + (buf ^ 1) * BK * BM);
-                    sb.dma_fast(g.b_sn, g.b_sk, Bs + (buf ^ 1) * BK * BN);
+                    sa.template dma_fast<ABL == 4 ? 16 : 4>(g.a_sm, g.a_sk, As + (buf ^ 1) * BK * BM);
+                    sb.template dma_fast<ABL == 4 ? 16 : 4>(g.b_sn, g.b_sk, Bs + (buf ^ 1) * BK * BN);
                     sa.advance(g.a_sk);
                     sb.advance(g.b_sk);
                 }
             }
             mfma_tile(buf);
-            if constexpr (ABL == 4) {
+            if constexpr (ABL == 4 || ABL == 5) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }

@@ -249,7 +249,10 @@ def suite_gemm():
         c = torch.empty(M, N, device=dev)
         t = timed(lambda: U.gemm_f32(a, b, out=c), n=3)
         report("gemm_f32_nn", f"M={M} N={N} K={K}", t, None, flops_f=2.0 * M * N * K)
-        del a, b, c
+        bt = torch.randn(N, K, device=dev)          # NT: both operands contiguous along k -> LDS-DMA staging (tune key 25)
+        t = timed(lambda: U.gemm_f32(a, bt.t(), out=c), n=3)
+        report("gemm_f32_nt", f"M={M} N={N} K={K}", t, None, flops_f=2.0 * M * N * K)
+        del a, b, bt, c
 
 
 def suite_c5(B=4096, M=256, N=64, H=64, W=64, quick=False):

@@ -5,6 +5,7 @@
 //   ABL 2  + global prefetch into registers         -> cost of the HBM/L2 stream beside the MFMAs
 //   ABL 3  + LDS store + barrier, no global loads   -> cost of the staging / synchronisation structure
 //   ABL 4  staging by LDS-DMA pieces (global_load_lds_dwordx4) + barrier: no staging registers, no ds_write (round 3)
+//   ABL 5  the same with 4-byte pieces (global_load_lds_dword): what an m/n-contiguous operand would need
 //   ABL 0  everything
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I di-hpc_amd/csrc -I include tests/tools/micro/gemm_ablate.hip
 //               -o tests/tools/micro/gemm_ablate.bin
@@ -32,15 +33,16 @@ __global__ void clock_probe(long long* out, int ms) {
 
 // LAYOUT 0: NN (A k-contiguous, B n-contiguous)  1: TN (both contiguous along m/n: full 128-byte lines per load)
 //        2: NT (both k-contiguous: 16 floats = HALF a line per row and k-tile at BK = 16)
-template <int BM, int BN, int BK, int WM, int WN, int ABL, int LAYOUT = 0, int NW = 4>
+template <int BM, int BN, int BK, int WM, int WN, int ABL, int LAYOUT = 0, int NW = 4, bool DMA = false>
 static double run(const char* tag, const float* A, const float* B, float* C, int M, int N, int K, int xcd) {
     GemmArgs g{A, B, C, M, N, K, (long)K, 1, (long)N, 1, (long)N, 0};
     if (LAYOUT == 1) { g.a_sm = 1; g.a_sk = M; }
     if (LAYOUT == 2) { g.b_sk = 1; g.b_sn = K; }
     g.xcd_swizzle = xcd;
     const dim3 grid(N / BN, M / BM, 1);
-    auto k = gemm_f32_kernel<BM, BN, BK, WM, WN, (LAYOUT == 1 ? kContigMN : kContigK), (LAYOUT == 2 ? kContigK : kContigMN),
-                             true, ABL, NW>;
+    static_assert(!DMA || LAYOUT == 2, "the LDS-DMA kernel is the NT form");
+    auto k = gemm_f32_kernel<BM, BN, BK, WM, WN, (DMA ? kDmaK : LAYOUT == 1 ? kContigMN : kContigK),
+                             (DMA ? kDmaK : LAYOUT == 2 ? kContigK : kContigMN), true, ABL, NW>;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -111,7 +113,13 @@ int main() {
         run<256, 256, 16, 2, 2, 4, 0, 16>("256x256x16 16 waves ABL4 LDS-DMA NN", A, B, C, M, N, K, 1);
         run<256, 256, 16, 2, 2, 4, 2, 16>("256x256x16 16 waves ABL4 LDS-DMA NT", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 4>("128x128x16 ABL4 LDS-DMA NN", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 5, 1, 16>("256x256x16 16 waves ABL5 4-byte DMA TN", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 5, 0, 16>("256x256x16 16 waves ABL5 4-byte DMA NN", A, B, C, M, N, K, 1);
         run<256, 256, 16, 2, 2, 0, 2, 16>("256x256x16 16 waves NT", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 0, 2, 16, true>("256x256x16 16 waves NT LDS-DMA (shipped)", A, B, C, M, N, K, 1);
+        run<256, 256, 32, 2, 2, 0, 2, 16, true>("256x256x32 16 waves NT LDS-DMA", A, B, C, M, N, K, 1);
+        run<128, 128, 16, 2, 2, 0, 2, 4, true>("128x128x16 NT LDS-DMA", A, B, C, M, N, K, 1);
+        run<128, 128, 32, 2, 2, 0, 2, 4, true>("128x128x32 NT LDS-DMA", A, B, C, M, N, K, 1);
         run<256, 256, 16, 2, 2, 0, 1, 16>("256x256x16 16 waves TN", A, B, C, M, N, K, 1);
         run<256, 256, 32, 2, 2, 0, 0, 16>("256x256x32 16 waves full NN", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 0, 1>("128x128x16 full TN (full lines)", A, B, C, M, N, K, 1);
