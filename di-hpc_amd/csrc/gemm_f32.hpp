@@ -278,7 +278,7 @@ template <int BM, int BN, int BK, int NW = 4> struct GemmOcc {
     static constexpr int lds = 2 * BK * (BM + BN) * 4;
     // (256x128 tiles hold 128 accumulator registers per lane: two waves per SIMD; a 16-wave workgroup IS the CU's
     //  four waves per SIMD: one workgroup per CU)
-    static constexpr int value = NW == 16 ? 1 : BM * BN >= 256 * 128 ? 2 : lds <= 36 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : 2;
+    static constexpr int value = NW == 16 ? 1 : NW == 8 ? 4 : BM * BN >= 256 * 128 ? 2 : lds <= 36 * 1024 ? 4 : lds <= 53 * 1024 ? 3 : 2;   // NW == 8: two 8-wave workgroups per CU
 };
 
 // INTERIOR: every tile of the launch lies entirely inside A, B and its K slice (M % BM == N % BN == K % BK == 0, no
@@ -499,10 +499,21 @@ inline bool gemm_tile256_ok(int M, int N, int K, int splitk) {
     const long wgs = (long)(M / 256) * (N / 256) * sk;
     return g_gemm_tile256 && M > 0 && N > 0 && M % 256 == 0 && N % 256 == 0 && K % 16 == 0 && (wgs % 256 == 0 || wgs >= 4096);
 }
-inline bool gemm_dma_ok(int M, int N, int K, int splitk) {
-    extern int g_gemm_dma;   // tuning knob (hpc_rll_tune_set key 25)
-    return g_gemm_dma && gemm_tile256_ok(M, N, K, splitk) && (splitk <= 1 || (K / 16) % splitk == 0);
+// LDS-DMA tiles for NT products (tune key 25): 1 = 256x128x16 with 8 waves, TWO workgroups per CU -- while one of them
+// sits at its k-tile barrier the other keeps the matrix pipe fed (142.7 TFLOP/s at 4096^3 against 140.0 for the 16-wave
+// 256x256 tile, whose workgroup IS the CU; profiles/r03_gemm_ablate_dma.txt) -- when the workgroups come in whole rounds
+// of two per CU; 2 = 256x256x16 with 16 waves under the conditions of gemm_tile256_ok; 0 = neither.
+inline int gemm_dma_tile(int M, int N, int K, int splitk) {
+    extern int g_gemm_dma;   // 0 off, 1 both tiles, 2 the 256x256 tile only
+    if (!g_gemm_dma || M <= 0 || N <= 0 || K % 16 != 0) return 0;
+    const int sk = splitk > 1 ? splitk : 1;
+    if (g_gemm_dma == 1 && M % 256 == 0 && N % 128 == 0) {
+        const long wgs = (long)(M / 256) * (N / 128) * sk;
+        if (wgs % 512 == 0 || wgs >= 8192) return 1;
+    }
+    return gemm_tile256_ok(M, N, K, splitk) ? 2 : 0;
 }
+inline bool gemm_dma_ok(int M, int N, int K, int splitk) { return gemm_dma_tile(M, N, K, splitk) != 0; }
 
 // Staging mode an operand admits.  x = the operand's non-k axis (m for A, n for B).
 inline int gemm_mode(const float* p, long sx, long sk, int XD, int KD) {
@@ -601,6 +612,25 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     const int bk = g_gemm_bk ? g_gemm_bk
                              : (((am == kContigK && bm == kContigMN) || (g.big && t.bm == 128 && t.bn == 128)) ? 16 : 32);
     extern int g_gemm_tile256;   // tuning knob (hpc_rll_tune_set key 16)
+    if (am == kContigK && bm == kContigK) {   // NT: LDS-DMA staged tiles (DmaStage)
+        const int dt = gemm_dma_tile(g.M, g.N, g.K, g.splitk);
+        const int sk = g.splitk > 1 ? g.splitk : 1;
+        GemmArgs h = g;
+        extern int g_gemm_exp;
+        h.prio = g_gemm_exp & 1;
+        if (dt == 1) {
+            const dim3 grid(g.N / 128, g.M / 256, sk);
+            h.xcd_swizzle = (((long)grid.x * grid.y) % 8 == 0 && grid.y >= 8) ? 1 : 0;
+            hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 16, 2, 2, kDmaK, kDmaK, true, 0, 8>), grid, dim3(512), 0, st, h);
+            return;
+        }
+        if (dt == 2) {
+            const dim3 grid(g.N / 256, g.M / 256, sk);
+            h.xcd_swizzle = 0;
+            hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 16, 2, 2, kDmaK, kDmaK, true, 0, 16>), grid, dim3(1024), 0, st, h);
+            return;
+        }
+    }
     {
         // 256x256x16 tiles, 16 waves (one workgroup = a CU's four waves per SIMD): half the vector-memory instructions per
         // MFMA of the 128x128 tile -- the cost the ablation isolates (profiles/r02_gemm_ablate.txt: 4096^3 128.9 ->
@@ -615,11 +645,6 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
             h.xcd_swizzle = 0;   // measured neutral for this tile (136.5 vs 136.7)
             extern int g_gemm_exp;   // tune key 23 (experiments): bit 0 s_setprio around the MFMA clusters, bit 1 BK = 32
             h.prio = g_gemm_exp & 1;
-            extern int g_gemm_dma;   // tune key 25: LDS-DMA staging for NT products (both operands k-contiguous)
-            if (g_gemm_dma && am == kContigK && bm == kContigK && (sk == 1 || (g.K / 16) % sk == 0)) {
-                hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 16, 2, 2, kDmaK, kDmaK, true, 0, 16>), grid, dim3(1024), 0, st, h);
-                return;
-            }
 #define HPC_RLL_GEMM256(AM, BMD)                                                                                          \
             if (am == AM && bm == BMD) {                                                                                  \
                 if ((g_gemm_exp & 2) && g.K % 32 == 0)                                                                    \

@@ -139,10 +139,11 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * key 24: samples per wave of the large-batch C51 / QR-DQN forwards (a wave loads the per-sample scalars of that many
  * consecutive samples coalesced, then walks them): 0 (default) = by batch size, 1 = never (the wave- / group-per-sample
  * kernels), or 8 / 16 / 32 / 64.
- * key 25: 1 (default) = fp32 GEMM products with BOTH operands contiguous along k ("NT") that take the 256x256x16 tile
- * stage their tiles by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write); the LSTM then presents its
- * large products in that form (forward against weight copies transposed once per layer).  Each output is still one exact
- * fp32 fma chain, in another k order than the register-staged kernels.  0 = register staging everywhere (round 2).
+ * key 25: 1 (default) = fp32 GEMM products with BOTH operands contiguous along k ("NT") whose workgroups fill the chip in
+ * whole rounds stage their tiles by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), on 256x128x16
+ * tiles with 8 waves (two workgroups per CU) or 256x256x16 with 16; the LSTM then presents its large products in that form
+ * (forward against weight copies transposed once per layer).  Each output is still one exact fp32 fma chain, in another
+ * k order than the register-staged kernels.  2 = the 256x256 tile only; 0 = register staging everywhere (round 2).
  */
 int hpc_rll_tune_set(int key, int value);
 

@@ -424,7 +424,7 @@ def test_gemm_256_tile_is_bit_identical_to_128_tile():
 
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 16), (4096, 4096, 48), (2048, 8192, 1024), (8192, 8192, 272), (256, 65536, 64)])
 def test_gemm_lds_dma_staging(M, N, K):
-    """Tune key 25: NT products (both operands contiguous along k) on the 256x256x16 tile stage their tiles by LDS-DMA
+    """Tune key 25: NT products (both operands contiguous along k) on 256x128x16 / 256x256x16 tiles stage their tiles by LDS-DMA
     (global_load_lds_dwordx4; gemm_f32.hpp: DmaStage): rows land raw, XOR-swizzled through the choice of the global chunk a
     lane asks for, and MFMA step s multiplies k = s and k = 8 + s of the k-tile.  Against the register-staged kernel
     (another k order: equal to fp32 rounding, NOT bit for bit -- which also shows that the other kernel ran) and against
@@ -434,14 +434,17 @@ def test_gemm_lds_dma_staging(M, N, K):
     a = torch.randn(M, K, device=DEV, generator=g)
     bt = torch.randn(N, K, device=DEV, generator=g)
     try:
-        U.tune_set(25, 1)
+        U.tune_set(25, 1)                                     # 256x128x16 tiles, 8 waves, two workgroups per CU
         dma = U.gemm_f32(a, bt.t())
         again = U.gemm_f32(a, bt.t())
+        U.tune_set(25, 2)                                     # 256x256x16 tiles, 16 waves
+        dma256 = U.gemm_f32(a, bt.t())
         U.tune_set(25, 0)
         reg = U.gemm_f32(a, bt.t())
     finally:
         U.tune_set(25, 1)
     assert torch.equal(dma, again)
+    assert torch.equal(dma, dma256)                           # same k convention in both DMA tiles
     ref = a.double() @ bt.double().t()
     scale = ref.abs().max().item()
     assert (dma.double() - ref).abs().max().item() < 1e-5 * scale

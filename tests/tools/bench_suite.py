@@ -341,6 +341,10 @@ if __name__ == "__main__":
     import faulthandler
     faulthandler.enable()
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    for _kv in os.environ.get("HPC_RLL_TUNE", "").split(","):      # e.g. HPC_RLL_TUNE=25:0,16:1 (A/B runs of this tool)
+        if ":" in _kv:
+            import hpc_rl_utils as _U
+            _U.tune_set(int(_kv.split(":")[0]), int(_kv.split(":")[1]))
     # steady-state power / clock state: bench.py runs these suites after seconds of GAE work, where the VALU-heavy
     # categorical kernels read ~10 % slower than on a freshly leased GPU (335 -> 365 us per 2.15 GB head; not placement:
     # tests/tools/r03_cat_placement_probe.py shows eight input allocations within 1 % of each other).  Pre-roll with the
