@@ -101,7 +101,9 @@ def test_lstm_golden(golden):
                                        (3, 2048, 32, 256, 1), (2, 512, 48, 1024, 2), (2, 520, 16, 1028, 1),
                                        # B >= 4096, 768 <= H <= 1024: backward cells walk 8 rows per workgroup and keep
                                        # the bias / gamma / beta column sums across steps and layers
-                                       (3, 4096, 16, 768, 2), (2, 4100, 8, 1024, 1)])   # (4100: rows do not divide over the 512 workgroups)
+                                       (3, 4096, 16, 768, 2), (2, 4100, 8, 1024, 1),    # (4100: rows do not divide over the 512 workgroups)
+                                       # x-branch products on LDS-DMA tiles (NT against Wx^T), recurrent ones on the register path
+                                       (8, 2048, 128, 256, 2)])
 def test_lstm_oracle(S, B, I, H, L):
     rng = np.random.default_rng(S + H)
     gain = 1.0 / np.sqrt(H)
