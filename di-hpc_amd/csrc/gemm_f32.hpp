@@ -489,6 +489,97 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
         }
 }
 
+// ---- TN products (A and B both contiguous along m / n, rows along k: the LSTM's weight gradients, K = S*B) by LDS-DMA.
+// A 16-byte piece of such an operand is four consecutive m at ONE k, so the tile can only land k-MAJOR in LDS: [BK][BM].
+// A 32x32x2 MFMA wants, per lane (i = lane & 31, h = lane >> 5), A[m_i][k_h] -- with a k-major tile the 32 lanes of a half
+// read 32 consecutive floats, which is one ds_read_b32 per MFMA step and block: the instruction rate round 1 stopped at
+// (136 TFLOP/s for the bare inner loop).  The way out is to let one 16-byte read serve FOUR m-blocks: block j of the wave
+// owns the rows m = 4 i + j (interleaved, not contiguous), so lane i's float4 at [k][4 i .. 4 i + 3] is exactly its operand
+// for blocks 0..3 at that k; B likewise with a float2 and two n-blocks (n = 2 i + j).  A wave is then 4 x 2 blocks =
+// 128 (m) x 64 (n), 128 accumulator registers, and step t of a k-tile needs ONE ds_read_b128 + ONE ds_read_b64 for
+// 8 MFMAs (the NT kernel: one b128 per 4).  k is consumed in memory order, two per MFMA (k = 2t from the lower half wave,
+// 2t + 1 from the upper): the same order as the register-staged kernels, so results are bit-identical to theirs.
+// Workgroup = 8 waves (2 along m x 4 along n) = a 256 x 256 tile, one per CU (2 waves per SIMD at ~150 registers); a
+// wave-piece of the DMA is one whole k-row of a tile (64 lanes x 16 B = 256 floats), global reads of 1 KiB.
+// Interior launches only (M % 256 == N % 256 == K % 16 == 0, 16-byte aligned rows), split-K slices as in gemm_f32_kernel.
+__global__ __launch_bounds__(512, 2) void gemm_f32_tn_dma_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 16, NW = 8;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
+    float* const As = lds;                 // [buf][BK][BM]
+    float* const Bs = lds + 2 * BK * BM;   // [buf][BK][BN]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;                    // 2 x 4 waves
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int all_tiles = g.K / BK;
+    const int per = (all_tiles + g.splitk - 1) / g.splitk;
+    const int kbeg = (int)blockIdx.z * per * BK;
+    const int KE = min(g.K, kbeg + per * BK);
+    const int ktiles = KE > kbeg ? (KE - kbeg) / BK : 0;
+    float* const Cz = g.C + (long)blockIdx.z * g.c_split;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // DMA: wave w brings k-rows w and w + 8 of both tiles; lane L the 16 bytes at m0 + 4 L of that row
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gl_ptr;
+    const float* pa = g.A + (long)(kbeg + wave) * g.a_sk + m0 + 4 * lane;
+    const float* pb = g.B + (long)(kbeg + wave) * g.b_sk + n0 + 4 * lane;
+    const long a8 = 8 * g.a_sk, b8 = 8 * g.b_sk, a16 = 16 * g.a_sk, b16 = 16 * g.b_sk;
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        float* at = As + buf * BK * BM + wave * BM;
+        float* bt = Bs + buf * BK * BN + wave * BN;
+        __builtin_amdgcn_global_load_lds((gl_ptr)pa, (lds_ptr)at, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gl_ptr)(pa + a8), (lds_ptr)(at + 8 * BM), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gl_ptr)pb, (lds_ptr)bt, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gl_ptr)(pb + b8), (lds_ptr)(bt + 8 * BN), 16, 0, 0);
+        pa += a16;
+        pb += b16;
+    };
+    if (ktiles > 0) issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int h = lane >> 5, i32 = lane & 31;
+    const int a_off = h * BM + wm * 128 + 4 * i32;             // + 2 t BM: row k = 2 t + h
+    const int b_off = h * BN + wn * 64 + 2 * i32;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ktiles) issue(buf ^ 1);
+        const float* __restrict__ as = As + buf * BK * BM + a_off;
+        const float* __restrict__ bs = Bs + buf * BK * BN + b_off;
+#pragma unroll
+        for (int t = 0; t < BK / 2; ++t) {
+            const gf4 a = *reinterpret_cast<const gf4*>(as + 2 * t * BM);
+            const gf2 b = *reinterpret_cast<const gf2*>(bs + 2 * t * BN);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // epilogue: block (i, j) of the wave holds rows m = 4 * row32 + i, columns n = 2 * col32 + j (interleaved); the 32x32
+    // C layout: col32 = lane & 31, row32 = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  The two n-blocks of a row pair up into
+    // one 8-byte store: 32 lanes x 8 B = 256 contiguous bytes per row.
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row32 = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + wm * 128 + 4 * row32 + i;
+            float* p = Cz + (long)m * g.ldc + n0 + wn * 64 + 2 * i32;
+            gf2 o = {acc[i][0][r], acc[i][1][r]};
+            if (g.accumulate) { o[0] += p[0]; o[1] += p[1]; }
+            *reinterpret_cast<gf2*>(p) = o;
+        }
+}
+
 inline bool gemm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Would launch_gemm take the 256x256x16 tile for this problem (and, with both operands k-contiguous, its LDS-DMA form)?
@@ -612,6 +703,17 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     const int bk = g_gemm_bk ? g_gemm_bk
                              : (((am == kContigK && bm == kContigMN) || (g.big && t.bm == 128 && t.bn == 128)) ? 16 : 32);
     extern int g_gemm_tile256;   // tuning knob (hpc_rll_tune_set key 16)
+    {   // TN: LDS-DMA with k-major tiles (gemm_f32_tn_dma_kernel), one 8-wave workgroup per CU
+        extern int g_gemm_dma;
+        const int sk = g.splitk > 1 ? g.splitk : 1;
+        const long wgs = (long)(g.M / 256) * (g.N / 256) * sk;
+        if (g_gemm_dma == 1 && am == kContigMN && bm == kContigMN && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 16 == 0 &&
+            (g.ldc % 2) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 7) == 0 && (g.c_split % 2) == 0 &&
+            (wgs % 256 == 0 || wgs >= 4096)) {
+            hipLaunchKernelGGL(gemm_f32_tn_dma_kernel, dim3(g.N / 256, g.M / 256, sk), dim3(512), 0, st, g);
+            return;
+        }
+    }
     if (am == kContigK && bm == kContigK) {   // NT: LDS-DMA staged tiles (DmaStage)
         const int dt = gemm_dma_tile(g.M, g.N, g.K, g.splitk);
         const int sk = g.splitk > 1 ? g.splitk : 1;

@@ -424,6 +424,31 @@ def test_gemm_256_tile_is_bit_identical_to_128_tile():
         U.tune_set(25, 1)
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 16), (4096, 4096, 80), (1024, 16384, 4096), (256, 65536, 48)])
+def test_gemm_lds_dma_staging_tn(M, N, K):
+    """TN products (A and B rows along k: the LSTM's weight gradients) through gemm_f32_tn_dma_kernel: k-major LDS tiles by
+    LDS-DMA, interleaved m / n blocks so that one ds_read_b128 + one ds_read_b64 feed 8 MFMAs.  k is consumed in memory
+    order, two per MFMA, like the register-staged kernels: BIT-IDENTICAL to them (tune key 25 = 0), plus fp64 and the
+    accumulate form."""
+    import hpc_torch_utils_network as U
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    at_ = torch.randn(K, M, device=DEV, generator=g)
+    b = torch.randn(K, N, device=DEV, generator=g)
+    try:
+        U.tune_set(25, 1)
+        dma = U.gemm_f32(at_.t(), b)
+        U.tune_set(25, 0)
+        reg = U.gemm_f32(at_.t(), b)
+    finally:
+        U.tune_set(25, 1)
+    assert torch.equal(dma, reg)
+    ref = at_.double().t() @ b.double()
+    assert (dma.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+    out = torch.full((M, N), -2.0, device=DEV)
+    U.gemm_f32(at_.t(), b, out, True)
+    assert torch.equal(out, dma - 2.0) or (out - (dma - 2.0)).abs().max().item() < 4e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 16), (4096, 4096, 48), (2048, 8192, 1024), (8192, 8192, 272), (256, 65536, 64)])
 def test_gemm_lds_dma_staging(M, N, K):
     """Tune key 25: NT products (both operands contiguous along k) on 256x128x16 / 256x256x16 tiles stage their tiles by LDS-DMA
