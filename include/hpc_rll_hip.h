@@ -143,7 +143,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * whole rounds stage their tiles by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), on 256x128x16
  * tiles with 8 waves (two workgroups per CU) or 256x256x16 with 16; the LSTM then presents its large products in that form
  * (forward against weight copies transposed once per layer).  Each output is still one exact fp32 fma chain, in another
- * k order than the register-staged kernels.  2 = the 256x256 tile only; 0 = register staging everywhere (round 2).
+ * k order than the register-staged kernels.  TN products (both operands with their rows along k: the weight gradients)
+ * take a DMA kernel with k-major tiles whose results are bit-identical to the register-staged kernel.  2 = NT on the 256x256
+ * tile only, TN on registers; 0 = register staging everywhere (round 2).
  */
 int hpc_rll_tune_set(int key, int value);
 
