@@ -288,7 +288,9 @@ template <int BM, int BN, int BK, int NW = 4> struct GemmOcc {
 // ABL != 0: ablation builds for tests/tools/micro/gemm_ablate.hip only (WRONG results): 1 = MFMAs + LDS operand reads
 // only; 2 = + global prefetch (waited for where the LDS store would be); 3 = + LDS store + barrier, no global loads;
 // 4 = staging by LDS-DMA (global_load_lds_dwordx4) + barrier instead of register prefetch + ds_write; 5 = the same bytes
-// as 4-byte LDS-DMA pieces (what an m/n-contiguous operand would need).
+// as 4-byte LDS-DMA pieces (what an m/n-contiguous operand would need); 6 (with kDmaK operands; CORRECT results) = the
+// LDS-DMA loop with three buffers and the barrier in the middle of a tile: 256x256 / 16 waves 140.0 -> 142.5 TFLOP/s, but
+// the 8-wave tile loses its second workgroup per CU to the third buffer (143.2 -> 136.9), so the shipped loop has two.
 // Where the time goes (tests/tools/micro/gemm_ablate.hip, profiles/r02_gemm_ablate.txt; 4096^3 NN, full-entropy data,
 // shader clock measured in-run at 2.41 GHz): MFMAs + the b128 operand reads alone 150 TFLOP/s (95 % of the matrix
 // rate; 136 with the first version's b32 reads); + LDS store and barrier 141; + the global prefetch 129 -- the same
@@ -304,9 +306,11 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
     constexpr int WAVES_M = BM / (32 * WM);
     constexpr int NTH = NW * 64;
     static_assert(WAVES_M * (BN / (32 * WN)) == NW, "waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
-    float* const As = lds;                 // [buf][BK*BM]
-    float* const Bs = lds + 2 * BK * BM;   // [buf][BK*BN]
+    constexpr bool PIPE3 = (AMODE == kDmaK) && ABL == 6;   // three LDS buffers, barrier in the middle of a tile (see the DMA loop)
+    constexpr int NBUF = PIPE3 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * BK * BM + NBUF * BK * BN];
+    float* const As = lds;                    // [buf][BK*BM]
+    float* const Bs = lds + NBUF * BK * BM;   // [buf][BK*BN]
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -354,7 +358,8 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
     float* const Cz = g.C + (long)blockIdx.z * g.c_split;
     constexpr bool DMA = AMODE == kDmaK;
     static_assert((AMODE == kDmaK) == (BMODE == kDmaK), "LDS-DMA staging: both operands or none (k convention)");
-    static_assert(!DMA || (INTERIOR && (BK == 16 || BK == 32) && ABL == 0), "LDS-DMA staging: interior tiles, 64- or 128-byte rows");
+    static_assert(!DMA || (INTERIOR && (BK == 16 || BK == 32) && (ABL == 0 || ABL == 6)), "LDS-DMA staging: interior tiles, 64- or 128-byte rows");
+    static_assert(!PIPE3 || BK == 16, "pipelined DMA loop: two operand quarters per tile");
     DmaStage<BM, BK, NTH> da;
     DmaStage<BN, BK, NTH> db;
     if constexpr (DMA) {
@@ -406,7 +411,51 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
             if (NW == 16 && g.prio) __builtin_amdgcn_s_setprio(0);
         }
     };
-    if constexpr (DMA) {
+    if constexpr (PIPE3) {
+        // Three LDS buffers, ONE barrier per k-tile placed between the two operand quarters of a tile: when a wave reaches
+        // it, the operands of the second quarter are already in registers (no refill bubble behind the barrier), and the
+        // first quarter of the NEXT tile -- visible to everyone as of this barrier -- is fetched while the second quarter's
+        // MFMAs run, so the matrix pipe never waits for ds_read at a tile boundary.  After the barrier every wave has left
+        // tile kt-1, whose buffer takes the request for tile kt+2.
+        gf4 a0[WM], b0[WN], a1[WM], b1[WN];
+        auto fetch = [&](int buf, int q, gf4 (&a)[WM], gf4 (&b)[WN]) __attribute__((always_inline)) {
+            const float* __restrict__ as = As + buf * BK * BM;
+            const float* __restrict__ bs = Bs + buf * BK * BN;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const gf4*>(as + a_off[q] + i * 32 * BK);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const gf4*>(bs + b_off[q] + j * 32 * BK);
+        };
+        auto mfma4 = [&](const gf4 (&a)[WM], const gf4 (&b)[WN]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+        };
+        if (ktiles > 1) {
+            da.issue(As + 1 * BK * BM);
+            db.issue(Bs + 1 * BK * BN);
+        }
+        if (ktiles > 0) fetch(0, 0, a0, b0);
+        int cur = 0;
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
+            fetch(cur, 1, a1, b1);
+            mfma4(a0, b0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of tile kt+1
+            __syncthreads();                                   // everyone's; and every wave is past tile kt-1
+            if (kt + 2 < ktiles) {
+                da.issue(As + nn * BK * BM);
+                db.issue(Bs + nn * BK * BN);
+            }
+            if (kt + 1 < ktiles) fetch(nxt, 0, a0, b0);
+            mfma4(a1, b1);
+            cur = nxt;
+        }
+    } else if constexpr (DMA) {
         // next k-tile requested straight into the other LDS buffer (every wave has passed the barrier that ended the last
         // reads of that buffer), MFMAs of this one, then: my pieces have landed (vmcnt) + everyone's (barrier)
         for (int kt = 0; kt < ktiles; ++kt) {

@@ -145,6 +145,8 @@ int main() {
         run<256, 128, 16, 2, 2, 0, 0, 8>("256x128x16 8 waves NN registers (2 per CU)", A, B, C, M, N, K, 1);
         run<128, 256, 16, 2, 2, 0, 1, 8>("128x256x16 8 waves TN registers (2 per CU)", A, B, C, M, N, K, 1);
         run<256, 128, 16, 2, 2, 0, 2, 8, true>("256x128x16 8 waves NT LDS-DMA (2 per CU)", A, B, C, M, N, K, 1);
+        run<256, 128, 16, 2, 2, 6, 2, 8, true>("256x128x16 8 waves NT LDS-DMA 3 buffers mid barrier", A, B, C, M, N, K, 1);
+        run<256, 256, 16, 2, 2, 6, 2, 16, true>("256x256x16 16 waves NT LDS-DMA 3 buffers mid barrier", A, B, C, M, N, K, 1);
         run<128, 256, 16, 2, 2, 0, 2, 8, true>("128x256x16 8 waves NT LDS-DMA (2 per CU)", A, B, C, M, N, K, 1);
         run<256, 128, 32, 2, 2, 0, 2, 8, true>("256x128x32 8 waves NT LDS-DMA (2 per CU)", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 0, 2, 4, true>("128x128x16 NT LDS-DMA", A, B, C, M, N, K, 1);
