@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.join(ROOT, "di-hpc_amd"))
 import torch  # noqa: E402
 import hpc_torch_utils_network as U  # noqa: E402
 dev = torch.device("cuda:0")
-shapes = [("NN rec", 4096, 4096, 1024, "nn"), ("NT dh", 4096, 1024, 4096, "nt"), ("TN dW", 1024, 4096, 65536, "tn")]
+shapes = [("NN rec", 4096, 4096, 1024, "nn"), ("NT dh", 4096, 1024, 4096, "nt"), ("TN dW", 1024, 4096, 65536, "tn"),
+          # round 3: shapes that take the LDS-DMA kernels without split-K (the LSTM's recurrent product as it now runs, and a
+          # TN product of 256 workgroups)
+          ("NT rec (LDS-DMA 256x128)", 4096, 4096, 1024, "nt"), ("TN 4096^3 (LDS-DMA k-major)", 4096, 4096, 4096, "tn")]
 for name, M, N, K, lay in shapes:
     a = torch.randn(M, K, device=dev)
     b = torch.randn(K, N, device=dev)

@@ -15,11 +15,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 db = os.path.join(ROOT, "gpurun_out", "prof_" + tag, "gemm_pmc", "gemm_pmc_results.db")
 con = sqlite3.connect(db)
 rows = con.execute("select dispatch_id, kernel_name, grid_size, workgroup_size, counter_name, value, duration from "
-                   "counters_collection where kernel_name like '%gemm_f32_kernel%'").fetchall()
+                   "counters_collection where kernel_name like '%gemm_f32_%kernel%'").fetchall()
 disp = collections.OrderedDict()
 for did, k, grid, wg, c, v, dur in rows:
     disp.setdefault(did, {"kernel": k, "grid": grid, "wg": wg, "dur_ns": float(dur)})[c] = disp.get(did, {}).get(c, 0.0) + float(v)
-shapes = [("NN rec 4096x4096x1024", 4096, 4096, 1024), ("NT dh 4096x1024x4096", 4096, 1024, 4096), ("TN dW 1024x4096x65536", 1024, 4096, 65536)]
+shapes = [("NN rec 4096x4096x1024", 4096, 4096, 1024), ("NT dh 4096x1024x4096", 4096, 1024, 4096), ("TN dW 1024x4096x65536", 1024, 4096, 65536),
+          ("NT rec 4096x4096x1024 (LDS-DMA 256x128x16, 8 waves)", 4096, 4096, 1024), ("TN 4096x4096x4096 (LDS-DMA k-major tiles)", 4096, 4096, 4096)]
 lines = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY",
          "# tests/tools/gemm_pmc_probe.py (3 launches per shape; the LAST launch of each shape is listed), MI355X, counters only",
          "# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); expected = 2*M*N*K/4096 MFMAs * 64 cycles",
