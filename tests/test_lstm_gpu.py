@@ -174,6 +174,44 @@ def _record_errors(name, worst):
             f.write(json.dumps({"case": name, "err": {k: {"hip": a, "torch_fp32": b} for k, (a, b) in worst.items()}}) + "\n")
 
 
+@pytest.mark.parametrize("S,B,I,H,L", [(16, 1024, 1024, 256, 2), (8, 2048, 512, 512, 1), (3, 4096, 1024, 1024, 1)])
+def test_lstm_lds_dma_products_against_register_products(S, B, I, H, L):
+    """Tune key 25: where the products of a layer fill the chip in whole rounds the LSTM runs them as LDS-DMA staged NT / TN
+    GEMMs (forward against weight copies transposed per layer, dx / dh against the weights as they lie, dWx / dWh on
+    k-major tiles).  Same module, same inputs, key 25 = 1 against key 25 = 0 (register staging everywhere, round 2's
+    forms): outputs and every gradient agree to fp32 rounding of another k order (the TN kernel itself is bit-identical)."""
+    import hpc_rl_utils as U
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(S * 131 + H)
+    m = LSTM(S, B, I, H, L).to(DEV)
+    with torch.no_grad():
+        m.ln_gamma.add_(0.1 * torch.randn_like(m.ln_gamma))
+        m.ln_beta.add_(0.1 * torch.randn_like(m.ln_beta))
+        m.bias.add_(0.1 * torch.randn_like(m.bias))
+    x0 = torch.randn(S, B, I, device=DEV)
+    h0 = torch.randn(L, B, H, device=DEV)
+    c0 = torch.randn(L, B, H, device=DEV)
+    gy = torch.randn(S, B, H, device=DEV)
+    res = {}
+    try:
+        for key in (1, 0):
+            U.tune_set(25, key)
+            for p in m.parameters():
+                p.grad = None
+            x, h, c = x0.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+            y, (hn, cn) = m(x, (h, c))
+            ((y * gy).sum() + hn.sum() - cn.sum()).backward()
+            res[key] = dict(y=y.detach().clone(), hn=hn.detach().clone(), cn=cn.detach().clone(), x=x.grad, h0=h.grad, c0=c.grad,
+                            **{n: p.grad.clone() for n, p in m.named_parameters()})
+    finally:
+        U.tune_set(25, 1)
+    for k in res[1]:
+        a, b = res[1][k], res[0][k]
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) < 2e-5 * scale, (k, float((a - b).abs().max()), scale)
+    assert not torch.equal(res[1]["y"], res[0]["y"])          # another k order: the DMA kernels did run
+
+
 def test_lstm_reference_usage_pattern():
     """tests/test_lstm.py:45-46: prev_state=None, loss = output.mean(), backward to input and parameters."""
     from hpc_rll.torch_utils.network.rnn import LSTM
