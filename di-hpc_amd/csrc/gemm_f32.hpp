@@ -629,6 +629,94 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_tn_dma_kernel(const GemmArgs 
         }
 }
 
+// ---- NN products (A contiguous along k, B along n) by LDS-DMA: the A tile as in the NT kernels (raw rows, DmaStage), the
+// B tile k-major as in gemm_f32_tn_dma_kernel.  The k convention of the raw A rows (lane half h holds k = 8h .. 8h+7, MFMA
+// step s multiplies k = s and k = 8 + s) is met on the B side by reading ROW 8h + s of the k-major tile; n-blocks are
+// interleaved by four (n = 4 i + j), so one ds_read_b128 of B feeds the four n-blocks of a step and one ds_read_b128 of A
+// feeds four steps of an m-block: a wave of 2 x 4 blocks = 64 (m) x 128 (n) issues 6 reads per 32 MFMAs.  Workgroup = 8
+// waves (4 along m x 2 along n) = 256 x 256, one per CU.  Same k order as the NT DMA kernels: bit-identical to them on the
+// same operands.
+__global__ __launch_bounds__(512, 2) void gemm_f32_nn_dma_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 16, NTH = 512;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
+    float* const As = lds;                 // [buf][BM rows][BK]  (swizzled chunks, lds_pos)
+    float* const Bs = lds + 2 * BK * BM;   // [buf][BK][BN]       (k-major)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 3, wn = wave >> 2;                    // 4 x 2 waves
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int all_tiles = g.K / BK;
+    const int per = (all_tiles + g.splitk - 1) / g.splitk;
+    const int kbeg = (int)blockIdx.z * per * BK;
+    const int KE = min(g.K, kbeg + per * BK);
+    const int ktiles = KE > kbeg ? (KE - kbeg) / BK : 0;
+    float* const Cz = g.C + (long)blockIdx.z * g.c_split;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gl_ptr;
+    DmaStage<BM, BK, NTH> da;
+    da.init(g.A, g.a_sm, m0, kbeg);
+    const float* pb = g.B + (long)(kbeg + wave) * g.b_sk + n0 + 4 * lane;     // wave w: k-rows w and w + 8
+    const long b8 = 8 * g.b_sk, b16 = 16 * g.b_sk;
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        da.issue(As + buf * BK * BM);
+        float* bt = Bs + buf * BK * BN + wave * BN;
+        __builtin_amdgcn_global_load_lds((gl_ptr)pb, (lds_ptr)bt, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gl_ptr)(pb + b8), (lds_ptr)(bt + 8 * BN), 16, 0, 0);
+        pb += b16;
+    };
+    if (ktiles > 0) issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int h = lane >> 5, i32 = lane & 31;
+    int a_off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) a_off[q] = lds_pos<BK>(wm * 64 + i32, 8 * h + 4 * q);   // block i: + 32 rows = + 32 * BK floats
+    const int b_off = (8 * h) * BN + wn * 128 + 4 * i32;                                 // + s * BN: row 8 h + s
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ktiles) issue(buf ^ 1);
+        const float* __restrict__ as = As + buf * BK * BM;
+        const float* __restrict__ bs = Bs + buf * BK * BN + b_off;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            gf4 a[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const gf4*>(as + a_off[q] + i * 32 * BK);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const gf4 b = *reinterpret_cast<const gf4*>(bs + (4 * q + t) * BN);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // epilogue: block (i, j): rows m = 32 i + row32 (plain), columns n = 4 col32 + j (interleaved): the four n-blocks of a
+    // row are one 16-byte store, 32 lanes x 16 B = 512 contiguous bytes per row
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row32 = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + wm * 64 + i * 32 + row32;
+            float* p = Cz + (long)m * g.ldc + n0 + wn * 128 + 4 * i32;
+            gf4 o = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            if (g.accumulate) o += *reinterpret_cast<const gf4*>(p);
+            *reinterpret_cast<gf4*>(p) = o;
+        }
+}
+
 inline bool gemm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Would launch_gemm take the 256x256x16 tile for this problem (and, with both operands k-contiguous, its LDS-DMA form)?
@@ -654,6 +742,13 @@ inline int gemm_dma_tile(int M, int N, int K, int splitk) {
     return gemm_tile256_ok(M, N, K, splitk) ? 2 : 0;
 }
 inline bool gemm_dma_ok(int M, int N, int K, int splitk) { return gemm_dma_tile(M, N, K, splitk) != 0; }
+// ... and would an NN product (A along k, B along n, 16-byte aligned C rows) take gemm_f32_nn_dma_kernel?
+inline bool gemm_nn_dma_ok(int M, int N, int K, int splitk) {
+    extern int g_gemm_dma;
+    const int sk = splitk > 1 ? splitk : 1;
+    const long wgs = (long)(M / 256) * (N / 256) * sk;
+    return g_gemm_dma == 1 && M > 0 && N > 0 && M % 256 == 0 && N % 256 == 0 && K % 16 == 0 && (wgs % 256 == 0 || wgs >= 4096);
+}
 
 // Staging mode an operand admits.  x = the operand's non-k axis (m for A, n for B).
 inline int gemm_mode(const float* p, long sx, long sk, int XD, int KD) {
@@ -760,6 +855,16 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
             (g.ldc % 2) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 7) == 0 && (g.c_split % 2) == 0 &&
             (wgs % 256 == 0 || wgs >= 4096)) {
             hipLaunchKernelGGL(gemm_f32_tn_dma_kernel, dim3(g.N / 256, g.M / 256, sk), dim3(512), 0, st, g);
+            return;
+        }
+    }
+    {   // NN: LDS-DMA, A as raw rows + B k-major (gemm_f32_nn_dma_kernel), one 8-wave workgroup per CU
+        extern int g_gemm_dma;
+        const int sk = g.splitk > 1 ? g.splitk : 1;
+        const long wgs = (long)(g.M / 256) * (g.N / 256) * sk;
+        if (g_gemm_dma == 1 && am == kContigK && bm == kContigMN && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 16 == 0 &&
+            (g.ldc % 4) == 0 && gemm_al16(g.C) && (g.c_split % 4) == 0 && (wgs % 256 == 0 || wgs >= 4096)) {
+            hipLaunchKernelGGL(gemm_f32_nn_dma_kernel, dim3(g.N / 256, g.M / 256, sk), dim3(512), 0, st, g);
             return;
         }
     }

@@ -956,7 +956,8 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
             const int skf = gemm_splitk((int)SB, (int)G, in_l);
             // Products whose tiles take the LDS-DMA kernel run as NT against a weight copy transposed once per layer
             // (~10 us): both operands k-contiguous is what the DMA staging needs (gemm_f32.hpp: DmaStage)
-            const bool nt = gemm_dma_ok((int)SB, (int)G, in_l, skf);
+            // (not when the product takes the NN DMA kernel with Wx as it lies: 141.3 against 140.1 TFLOP/s on the C4 shape)
+            const bool nt = !gemm_nn_dma_ok((int)SB, (int)G, in_l, skf) && gemm_dma_ok((int)SB, (int)G, in_l, skf);
             if (nt) launch_transpose(wx_l, w.wxT, in_l, (int)G, st);   // (in, G) -> (G, in): B(k=i, n=g) = wxT[g*in + i]
             GemmArgs g{xin, nt ? (const float*)w.wxT : wx_l, skf > 1 ? w.wpart : lw.xw, (int)SB, (int)G, in_l, in_l, 1,
                        nt ? 1 : (long)G, nt ? (long)in_l : 1, (long)G, 0, skf, (long)(SB * G)};
@@ -977,7 +978,7 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
             persist_prof_report("fwd", l, S, st);
         }
         const int sk_rec = gemm_splitk(B, (int)G, H);
-        const bool nt_rec = !persist && S > 0 && gemm_dma_ok(B, (int)G, H, sk_rec);
+        const bool nt_rec = !persist && S > 0 && !gemm_nn_dma_ok(B, (int)G, H, sk_rec) && gemm_dma_ok(B, (int)G, H, sk_rec);
         if (nt_rec) launch_transpose(wh_l, w.whT, H, (int)G, st);      // (H, G) -> (G, H): B(k=h, n=g) = whT[g*H + h]
         for (int s = 0; s < S && !persist; ++s) {
             const float* h_prev = s == 0 ? h0 + (size_t)l * BH : lw.hseq + (size_t)(s - 1) * BH;
@@ -1086,7 +1087,9 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
             const int skd = gemm_splitk((int)SB, in_l, (int)G);
             // NN against a transposed copy only where it was measured to win (C4: -2 %; B <= 1024: +2..5 %)
             // (with LDS-DMA staging the NT form -- the weights as they lie -- is the fast one: no transposed copy)
-            if (g_lstm_nn_bwd && (double)SB * in_l >= (double)(1u << 28) && !gemm_dma_ok((int)SB, in_l, (int)G, skd)) {
+            // (... unless the NN form itself takes the NN DMA kernel, which is the faster of the two: then NN it stays)
+            if (g_lstm_nn_bwd && (double)SB * in_l >= (double)(1u << 28) &&
+                (gemm_nn_dma_ok((int)SB, in_l, (int)G, skd) || !gemm_dma_ok((int)SB, in_l, (int)G, skd))) {
                 launch_transpose(wx_l, w.wxT, in_l, (int)G, st);   // (in, G) -> (G, in): B(k=g, n=i) = wxT[g*in + i]
                 GemmArgs g{p_dxw, w.wxT, skd > 1 ? w.wpart : dxin, (int)SB, in_l, (int)G, (long)G, 1, (long)in_l, 1,
                            (long)in_l, 0, skd, (long)(SB * in_l)};
@@ -1143,7 +1146,7 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         int sk_dh = (nn_dh && g_lstm_dh_big) ? gemm_splitk_big(B, H, (int)G) : gemm_splitk(B, H, (int)G);
         const bool dh_big = nn_dh && g_lstm_dh_big;
         // ... unless that product takes the LDS-DMA kernel as NT against Wh as it lies (no transposed copy)
-        if (nn_dh && gemm_dma_ok(B, H, (int)G, sk_dh)) nn_dh = false;
+        if (nn_dh && !gemm_nn_dma_ok(B, H, (int)G, sk_dh) && gemm_dma_ok(B, H, (int)G, sk_dh)) nn_dh = false;
         if (persist) {   // one kernel walks the whole sequence of this layer backwards (lstm_persist.hpp)
             PersistBwd a{d_out, dh_carry, dc_carry, lw.gates, lw.c, c0 + (size_t)l * BH, lw.xw, lw.hw, lw.stats, gamma_l,
                          wh_l, w.dgate, w.dxw, w.dhw, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, (u64*)w.xchg,

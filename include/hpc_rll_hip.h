@@ -144,8 +144,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * tiles with 8 waves (two workgroups per CU) or 256x256x16 with 16; the LSTM then presents its large products in that form
  * (forward against weight copies transposed once per layer).  Each output is still one exact fp32 fma chain, in another
  * k order than the register-staged kernels.  TN products (both operands with their rows along k: the weight gradients)
- * take a DMA kernel with k-major tiles whose results are bit-identical to the register-staged kernel.  2 = NT on the 256x256
- * tile only, TN on registers; 0 = register staging everywhere (round 2).
+ * take a DMA kernel with k-major tiles whose results are bit-identical to the register-staged kernel; NN products (A along
+ * k, B along n) one that combines both tile forms (bit-identical to the NT DMA kernels).  2 = NT on the 256x256 tile only,
+ * TN / NN on registers; 0 = register staging everywhere (round 2).
  */
 int hpc_rll_tune_set(int key, int value);
 

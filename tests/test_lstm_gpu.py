@@ -462,6 +462,34 @@ def test_gemm_256_tile_is_bit_identical_to_128_tile():
         U.tune_set(25, 1)
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 16), (4096, 4096, 112), (2048, 8192, 1024), (65536, 256, 32)])
+def test_gemm_lds_dma_staging_nn(M, N, K):
+    """NN products through gemm_f32_nn_dma_kernel (A raw rows by DmaStage, B k-major, n-blocks interleaved by four): the
+    k order of the NT DMA kernels, so BIT-IDENTICAL to them on the same operands; against the register-staged kernel to
+    fp32 rounding; fp64; accumulate form."""
+    import hpc_torch_utils_network as U
+    g = torch.Generator(device=DEV).manual_seed(M + K + 1)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    b = torch.randn(K, N, device=DEV, generator=g)
+    bt = b.t().contiguous()
+    try:
+        U.tune_set(25, 1)
+        nn = U.gemm_f32(a, b)
+        nt = U.gemm_f32(a, bt.t())
+        U.tune_set(25, 0)
+        reg = U.gemm_f32(a, b)
+    finally:
+        U.tune_set(25, 1)
+    assert torch.equal(nn, nt)
+    ref = a.double() @ b.double()
+    scale = ref.abs().max().item()
+    assert (nn.double() - ref).abs().max().item() < 1e-5 * scale
+    assert (nn - reg).abs().max().item() < 4e-6 * scale
+    out = torch.full((M, N), 0.5, device=DEV)
+    U.gemm_f32(a, b, out, True)
+    assert (out - 0.5 - nn).abs().max().item() < 4e-6 * scale
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 16), (4096, 4096, 80), (1024, 16384, 4096), (256, 65536, 48)])
 def test_gemm_lds_dma_staging_tn(M, N, K):
     """TN products (A and B rows along k: the LSTM's weight gradients) through gemm_f32_tn_dma_kernel: k-major LDS tiles by
