@@ -636,11 +636,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_tn_dma_kernel(const GemmArgs 
 // feeds four steps of an m-block: a wave of 2 x 4 blocks = 64 (m) x 128 (n) issues 6 reads per 32 MFMAs.  Workgroup = 8
 // waves (4 along m x 2 along n) = 256 x 256, one per CU.  Same k order as the NT DMA kernels: bit-identical to them on the
 // same operands.
+template <bool PIPE>   // PIPE: three LDS buffers, the k-tile barrier between the two halves of a tile (see the loop): measured
+                       // 142.9 -> 144.0 TFLOP/s at 4096^3, 141.5 -> 141.9 on the C4 x-branch shape -- shipped: false
 __global__ __launch_bounds__(512, 2) void gemm_f32_nn_dma_kernel(const GemmArgs g) {
-    constexpr int BM = 256, BN = 256, BK = 16, NTH = 512;
-    __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
-    float* const As = lds;                 // [buf][BM rows][BK]  (swizzled chunks, lds_pos)
-    float* const Bs = lds + 2 * BK * BM;   // [buf][BK][BN]       (k-major)
+    constexpr int BM = 256, BN = 256, BK = 16, NTH = 512, NBUF = PIPE ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * BK * BM + NBUF * BK * BN];
+    float* const As = lds;                    // [buf][BM rows][BK]  (swizzled chunks, lds_pos)
+    float* const Bs = lds + NBUF * BK * BM;   // [buf][BK][BN]       (k-major)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 3, wn = wave >> 2;                    // 4 x 2 waves
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -680,27 +682,68 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_nn_dma_kernel(const GemmArgs 
 #pragma unroll
     for (int q = 0; q < 2; ++q) a_off[q] = lds_pos<BK>(wm * 64 + i32, 8 * h + 4 * q);   // block i: + 32 rows = + 32 * BK floats
     const int b_off = (8 * h) * BN + wn * 128 + 4 * i32;                                 // + s * BN: row 8 h + s
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ktiles) issue(buf ^ 1);
-        const float* __restrict__ as = As + buf * BK * BM;
-        const float* __restrict__ bs = Bs + buf * BK * BN + b_off;
+    auto half = [&](const float* as, const float* bs, int q, const gf4 (&a)[2], gf4 b0) __attribute__((always_inline)) {
+        // steps 4 q .. 4 q + 3 of a tile: A operands and the first B operand already in registers
+        gf4 b = b0;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            gf4 a[2];
+        for (int t = 0; t < 4; ++t) {
+            gf4 bnx = b;
+            if (t < 3) bnx = *reinterpret_cast<const gf4*>(bs + (4 * q + t + 1) * BN);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const gf4*>(as + a_off[q] + i * 32 * BK);
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const gf4 b = *reinterpret_cast<const gf4*>(bs + (4 * q + t) * BN);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j], acc[i][j], 0, 0, 0);
+            b = bnx;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+    if constexpr (PIPE) {
+        // one barrier per k-tile, BETWEEN the two halves of a tile: a wave reaches it with the second half's first operands
+        // in registers, and fetches the next tile's first operands -- visible as of this barrier -- under the second half's
+        // MFMAs: no operand refill bubble behind a barrier.  After it every wave has left tile kt-1, whose buffer takes the
+        // request for tile kt+2 (three buffers).
+        if (ktiles > 1) issue(1);
+        gf4 a0[2], a1[2], b0, b1;
+        if (ktiles > 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a0[i] = *reinterpret_cast<const gf4*>(As + a_off[0] + i * 32 * BK);
+            b0 = *reinterpret_cast<const gf4*>(Bs + b_off);
+        }
+        int cur = 0;
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
+            const float* as = As + cur * BK * BM;
+            const float* bs = Bs + cur * BK * BN + b_off;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a1[i] = *reinterpret_cast<const gf4*>(as + a_off[1] + i * 32 * BK);
+            b1 = *reinterpret_cast<const gf4*>(bs + 4 * BN);
+            half(as, bs, 0, a0, b0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 2 < ktiles) issue(nn);
+            if (kt + 1 < ktiles) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a0[i] = *reinterpret_cast<const gf4*>(As + nxt * BK * BM + a_off[0] + i * 32 * BK);
+                b0 = *reinterpret_cast<const gf4*>(Bs + nxt * BK * BN + b_off);
+            }
+            half(as, bs, 1, a1, b1);
+            cur = nxt;
+        }
+    } else {
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < ktiles) issue(buf ^ 1);
+            const float* __restrict__ as = As + buf * BK * BM;
+            const float* __restrict__ bs = Bs + buf * BK * BN + b_off;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                gf4 a[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const gf4*>(as + a_off[q] + i * 32 * BK);
+                half(as, bs, q, a, *reinterpret_cast<const gf4*>(bs + 4 * q * BN));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
     // epilogue: block (i, j): rows m = 32 i + row32 (plain), columns n = 4 col32 + j (interleaved): the four n-blocks of a
     // row are one 16-byte store, 32 lanes x 16 B = 512 contiguous bytes per row
@@ -864,7 +907,7 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
         const long wgs = (long)(g.M / 256) * (g.N / 256) * sk;
         if (g_gemm_dma == 1 && am == kContigK && bm == kContigMN && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 16 == 0 &&
             (g.ldc % 4) == 0 && gemm_al16(g.C) && (g.c_split % 4) == 0 && (wgs % 256 == 0 || wgs >= 4096)) {
-            hipLaunchKernelGGL(gemm_f32_nn_dma_kernel, dim3(g.N / 256, g.M / 256, sk), dim3(512), 0, st, g);
+            hipLaunchKernelGGL(gemm_f32_nn_dma_kernel<false>, dim3(g.N / 256, g.M / 256, sk), dim3(512), 0, st, g);
             return;
         }
     }

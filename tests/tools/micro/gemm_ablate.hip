@@ -100,17 +100,18 @@ static void run_tn_dma(const char* tag, const float* A, const float* B, float* C
     fflush(stdout);
 }
 
+template <bool PIPE>
 static void run_nn_dma(const char* tag, const float* A, const float* B, float* C, int M, int N, int K) {
     GemmArgs g{A, B, C, M, N, K, (long)K, 1, (long)N, 1, (long)N, 0};
     const dim3 grid(N / 256, M / 256, 1);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_f32_nn_dma_kernel, grid, dim3(512), 0, 0, g);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_f32_nn_dma_kernel<PIPE>, grid, dim3(512), 0, 0, g);
     double best = 1e30;
     for (int r = 0; r < 5; ++r) {
         hipEventRecord(e0, 0);
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_f32_nn_dma_kernel, grid, dim3(512), 0, 0, g);
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_f32_nn_dma_kernel<PIPE>, grid, dim3(512), 0, 0, g);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -175,7 +176,8 @@ int main() {
         run<128, 128, 32, 2, 2, 0, 2, 4, true>("128x128x32 NT LDS-DMA", A, B, C, M, N, K, 1);
         run<256, 256, 16, 2, 2, 0, 1, 16>("256x256x16 16 waves TN", A, B, C, M, N, K, 1);
         if (M <= 8192) run_tn_dma("256x256x16 8 waves TN LDS-DMA (k-major)", A, B, C, M, N, K);
-        run_nn_dma("256x256x16 8 waves NN LDS-DMA (A rows + B k-major)", A, B, C, M, N, K);
+        run_nn_dma<false>("256x256x16 8 waves NN LDS-DMA (A rows + B k-major)", A, B, C, M, N, K);
+        run_nn_dma<true>("256x256x16 8 waves NN LDS-DMA 3 buffers mid barrier", A, B, C, M, N, K);
         run<256, 256, 32, 2, 2, 0, 0, 16>("256x256x32 16 waves full NN", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 0, 1>("128x128x16 full TN (full lines)", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 0, 2>("128x128x16 full NT (half lines)", A, B, C, M, N, K, 1);
