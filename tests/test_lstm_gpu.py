@@ -462,6 +462,41 @@ def test_gemm_256_tile_is_bit_identical_to_128_tile():
         U.tune_set(25, 1)
 
 
+@pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
+def test_gemm_lds_dma_kernels_with_strided_operands_and_output(layout):
+    """The C ABI takes arbitrary strides: operands that are column slices of wider buffers (row strides > the row length)
+    and an output with ldc > N must still take the LDS-DMA kernels' paths correctly -- compared bit for bit with the same
+    product on dense copies."""
+    import cabi as Nb
+    M, N, K, PAD = 4096, 4096, 96, 64
+    g = torch.Generator(device=DEV).manual_seed(7)
+    P = lambda t: t.data_ptr()  # noqa: E731
+    s = torch.cuda.current_stream().cuda_stream
+    if layout == "tn":
+        abuf, bbuf = torch.randn(K, M + PAD, device=DEV, generator=g), torch.randn(K, N + PAD, device=DEV, generator=g)
+        a_v, b_v = abuf[:, :M], bbuf[:, :N]                          # A(m,k) = abuf[k, m], B(k,n) = bbuf[k, n]
+        sa, sb = (1, M + PAD), (N + PAD, 1)                          # (a_sm, a_sk), (b_sk, b_sn)
+        dense = (a_v.contiguous(), b_v.contiguous(), (1, M), (N, 1))
+    elif layout == "nt":
+        abuf, bbuf = torch.randn(M, K + PAD, device=DEV, generator=g), torch.randn(N, K + PAD, device=DEV, generator=g)
+        a_v, b_v = abuf[:, :K], bbuf[:, :K]                          # B(k,n) = bbuf[n, k]
+        sa, sb = (K + PAD, 1), (1, K + PAD)
+        dense = (a_v.contiguous(), b_v.contiguous(), (K, 1), (1, K))
+    else:
+        abuf, bbuf = torch.randn(M, K + PAD, device=DEV, generator=g), torch.randn(K, N + PAD, device=DEV, generator=g)
+        a_v, b_v = abuf[:, :K], bbuf[:, :N]
+        sa, sb = (K + PAD, 1), (N + PAD, 1)
+        dense = (a_v.contiguous(), b_v.contiguous(), (K, 1), (N, 1))
+    cbuf = torch.zeros(M, N + PAD, device=DEV)
+    assert Nb.lib.hpc_rll_gemm_f32(P(a_v), P(b_v), P(cbuf), M, N, K, sa[0], sa[1], sb[0], sb[1], N + PAD, 0, s) == 0
+    cd = torch.empty(M, N, device=DEV)
+    da, db, dsa, dsb = dense
+    assert Nb.lib.hpc_rll_gemm_f32(P(da), P(db), P(cd), M, N, K, dsa[0], dsa[1], dsb[0], dsb[1], N, 0, s) == 0
+    assert torch.equal(cbuf[:, :N], cd) and not cbuf[:, N:].any()
+    ref = (a_v.double().t() if layout == "tn" else a_v.double()) @ (b_v.double().t() if layout == "nt" else b_v.double())
+    assert (cd.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 16), (4096, 4096, 112), (2048, 8192, 1024), (65536, 256, 32)])
 def test_gemm_lds_dma_staging_nn(M, N, K):
     """NN products through gemm_f32_nn_dma_kernel (A raw rows by DmaStage, B k-major, n-blocks interleaved by four): the
