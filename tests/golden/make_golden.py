@@ -59,6 +59,17 @@ def close(name, a, b, tol=2e-5):
     return err
 
 
+def gclose(name, a, b, tol=2e-6):
+    """Gradients: relative to the tensor's own maximum (they are O(1/(T*B)) for mean-reduced losses, so close()'s
+    max(1,|a|) denominator would accept errors of several percent of the tensor -- VERDICT r03 weak #2)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = float(np.max(np.abs(a))) if a.size else 0.0
+    err = float(np.max(np.abs(a - b))) / scale if scale > 0 else float(np.max(np.abs(b))) if b.size else 0.0
+    assert err <= tol, f"oracle restatement mismatch for {name} (relative to max |ref| = {scale:.3e}): {err}"
+    return err
+
+
 def save(name, **arrs):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrs)
@@ -87,8 +98,8 @@ def gen_gae():
         a64 = R.gae(d64(v), d64(r), g, l)
         close("gae fwd", adv.detach().numpy(), a64.numpy())
         gv, gr = R.gae_backward(d64(ga), g, l)
-        close("gae grad_value", tv.grad.numpy(), gv.numpy())
-        close("gae grad_reward", tr.grad.numpy(), gr.numpy())
+        gclose("gae grad_value", tv.grad.numpy(), gv.numpy(), 1e-5)
+        gclose("gae grad_reward", tr.grad.numpy(), gr.numpy(), 1e-5)
     # big shapes of the reference tests: seeds + summary statistics only
     big = []
     for (T, B, seed) in [(1024, 64, 11), (256, 256, 12)]:
@@ -127,7 +138,7 @@ def gen_td_lambda():
         l64 = R.td_lambda_error(v64, d64(r), None if w is None else d64(w), g, l)
         l64.backward()
         close("tdl loss", loss.item(), l64.item())
-        close("tdl grad", tv.grad.numpy(), v64.grad.numpy(), 2e-6)
+        gclose("tdl grad", tv.grad.numpy(), v64.grad.numpy(), 2e-6)
     save("td_lambda", **out)
 
 
@@ -165,8 +176,8 @@ def gen_vtrace():
         l64 = R.vtrace_error(to64, d64(bo), T_(a), v64, d64(r), None if w is None else d64(w), g, l, rc, cc, pc)
         (coef[0] * l64[0] + coef[1] * l64[1] + coef[2] * l64[2]).backward()
         close("vtrace losses", [x.item() for x in ls], [x.item() for x in l64])
-        close("vtrace gto", tto.grad.numpy(), to64.grad.numpy(), 2e-6)
-        close("vtrace gv", tv.grad.numpy(), v64.grad.numpy(), 2e-6)
+        gclose("vtrace gto", tto.grad.numpy(), to64.grad.numpy(), 2e-6)
+        gclose("vtrace gv", tv.grad.numpy(), v64.grad.numpy(), 2e-6)
     save("vtrace", **out)
 
 
@@ -192,7 +203,7 @@ def gen_upgo():
         l64 = R.upgo_loss(to64, d64(rho), T_(a), d64(r), d64(v))
         l64.backward()
         close("upgo loss", loss.item(), l64.item())
-        close("upgo grad", tto.grad.numpy(), to64.grad.numpy(), 2e-6)
+        gclose("upgo grad", tto.grad.numpy(), to64.grad.numpy(), 2e-6)
     save("upgo", **out)
 
 
@@ -234,8 +245,8 @@ def gen_ppo():
         (coef[0] * l64[0] + coef[1] * l64[1] + coef[2] * l64[2]).backward()
         close("ppo losses", [x.item() for x in ls], [x.item() for x in l64])
         close("ppo info", list(info), list(i64), 1e-5)
-        close("ppo gl", tln.grad.numpy(), ln64.grad.numpy(), 2e-6)
-        close("ppo gv", tvn.grad.numpy(), vn64.grad.numpy(), 2e-6)
+        gclose("ppo gl", tln.grad.numpy(), ln64.grad.numpy(), 2e-6)
+        gclose("ppo gv", tvn.grad.numpy(), vn64.grad.numpy(), 2e-6)
     save("ppo", **out)
 
 
@@ -266,7 +277,7 @@ def gen_qntd():
             l64.backward()
             close("qntd loss " + tag, loss.item(), l64.item(), 5e-5)
             close("qntd per " + tag, per.detach().numpy(), p64.detach().numpy(), 5e-5)
-            close("qntd grad " + tag, tq.grad.numpy(), q64.grad.numpy(), 5e-5)
+            gclose("qntd grad " + tag, tq.grad.numpy(), q64.grad.numpy(), 2e-6)
     save("qntd", **out)
 
 
@@ -301,7 +312,7 @@ def gen_dntd():
         l32.backward()
         close("dntd loss", loss.item(), l32.item(), 1e-4)
         close("dntd per", per.detach().numpy(), p32.detach().numpy(), 1e-4)
-        close("dntd grad", td.grad.numpy(), d32.grad.numpy(), 1e-4)
+        gclose("dntd grad", td.grad.numpy(), d32.grad.numpy(), 5e-6)
     save("dntd", **out)
 
 
@@ -337,7 +348,7 @@ def gen_iqn():
         l64.backward()
         close("iqn loss", loss.item(), l64.item(), 5e-5)
         close("iqn per", per.detach().numpy(), p64.detach().numpy(), 5e-5)
-        close("iqn grad", tq.grad.numpy(), q64.grad.numpy(), 5e-5)
+        gclose("iqn grad", tq.grad.numpy(), q64.grad.numpy(), 2e-6)
     save("iqn", **out)
 
 
@@ -372,7 +383,7 @@ def gen_qrdqn():
         l64.backward()
         close("qrdqn loss", loss.item(), l64.item(), 5e-5)
         close("qrdqn per", per.detach().numpy(), p64.detach().numpy(), 5e-5)
-        close("qrdqn grad", tq.grad.numpy(), q64.grad.numpy(), 5e-5)
+        gclose("qrdqn grad", tq.grad.numpy(), q64.grad.numpy(), 2e-6)
     save("qrdqn", **out)
 
 
@@ -437,7 +448,7 @@ def gen_scatter():
                 assert torch.equal(o2.detach(), o.detach()), "cover must be bit exact"
             else:
                 close("scatter add", o.detach().numpy(), o2.detach().numpy(), 1e-6)
-            close("scatter grad " + st, tx.grad.numpy(), x2.grad.numpy(), 1e-6)
+            gclose("scatter grad " + st, tx.grad.numpy(), x2.grad.numpy(), 1e-6)
     save("scatter", **out)
 
 

@@ -239,9 +239,12 @@ def test_fuzz_lstm():
                             m.ln_gamma.detach().cpu().double(), m.ln_beta.detach().cpu().double())
         (oy.sum() + oh.sum() * 0.5 - oc.sum()).backward()
         assert rel_err(oy.detach().numpy(), y.detach().cpu().numpy()) < 2e-5, (S, B, I, H, L)
-        # relative to the tensor's own maximum (round 3; the bound used to be absolute): measured <= 2.05e-4 over the 12
-        # shapes (profiles/r03_parity_probe.json) -- the S*L LayerNorms over a handful of columns amplify fp32 rounding
-        assert grad_err(ox.grad.numpy(), dx.grad.cpu().numpy()) < 4e-4, (S, B, I, H, L)
+        # relative to the tensor's own maximum.  Shapes with ONE input feature are degenerate: x W_x is rank one, LayerNorm
+        # removes its scale, so dx is analytically ~0 and what is left is rounding noise of the cancellation -- the SAME
+        # fp64 oracle evaluated in fp32 differs from itself by 8.3e-4 on (2,2,1,2,2); every other
+        # shape is held to 3e-5 (fp32-vs-fp64 oracle: <= 3e-5 on all eleven).
+        tol = 3e-5 if I >= 2 else 4e-4   # (I = 1: measured 2.05e-4 on the kernel, r03)
+        assert grad_err(ox.grad.numpy(), dx.grad.cpu().numpy()) < tol, (S, B, I, H, L)
 
 
 @pytest.mark.parametrize("B,N,K", [(7, 4, 1), (300, 4, 1), (5, 256, 64), (3, 8, 2), (9, 2, 2), (4, 1024, 16), (6, 6, 2)])

@@ -242,6 +242,28 @@ def test_ppo_oracle(B, N, dual, uvc):
     assert grad_err(vn64.grad.numpy(), dvn.grad.cpu().numpy()) < GTOL
 
 
+def test_ppo_reference_inputs():
+    """tests/test_ppo.py:10-27 literally: B=N=128, clip 0.2, value clip on, no dual clip, and EVERY float input an independent
+    randn -- logits_old unrelated to logits_new (ratios from e^-5 to e^5, most samples clipped), negative weights, negative
+    and non-binary everything else (SURVEY 4 "input quirks the build must accept")."""
+    from hpc_rll.rl_utils.ppo import PPO
+    B, N = 128, 128
+    rng = np.random.default_rng(77)
+    ln, lo = f32(rng, B, N), f32(rng, B, N)
+    a = rng.integers(0, N, (B,)).astype(np.int64)
+    vn, vo, adv, ret, w = f32(rng, B), f32(rng, B), f32(rng, B), f32(rng, B), f32(rng, B)
+    ln64, vn64 = D(ln, True), D(vn, True)
+    l64, i64 = R.ppo_error(ln64, D(lo), torch.from_numpy(a), vn64, D(vo), D(adv), D(ret), D(w), 0.2, True, None)
+    sum(l64).backward()
+    dln, dvn = G(ln, True), G(vn, True)
+    ls, info = PPO(B, N)(dln, G(lo), G(a), dvn, G(vo), G(adv), G(ret), G(w), 0.2, True, None)
+    sum(ls).backward()
+    assert rel_err([x.item() for x in l64], [x.item() for x in ls]) < TOL
+    assert rel_err(list(i64), list(info)) < 1e-4
+    assert grad_err(ln64.grad.numpy(), dln.grad.cpu().numpy()) < GTOL
+    assert grad_err(vn64.grad.numpy(), dvn.grad.cpu().numpy()) < GTOL
+
+
 # ------------------------------------------------------------------------------------------------ q n-step TD
 def test_qntd_golden(golden):
     from hpc_rll.rl_utils.td import QNStepTD, QNStepTDRescale
@@ -258,12 +280,14 @@ def test_qntd_golden(golden):
             assert grad_err(g[f"c{i}_{tag}_grad_q"], q.grad.cpu().numpy()) < 5e-5
 
 
+@pytest.mark.parametrize("T", [1024, 16])
 @pytest.mark.parametrize("rescale", [False, True])
-def test_qntd_oracle_reference_shape(rescale):
-    """tests/test_qntd.py: T=1024 (nstep), B=64, N=64, done/weight are randn floats (tests/test_qntd.py:21-22)."""
+def test_qntd_oracle_reference_shape(rescale, T):
+    """tests/test_qntd.py:10-22: T=1024 (nstep), B=64, N=64, done / weight are randn floats -- the literal shape and input
+    distributions (VERDICT r03 weak #1); T=16 in addition, where gamma^n still leaves the bootstrap term visible."""
     from hpc_rll.rl_utils.td import QNStepTD, QNStepTDRescale
-    T, B, N = 16, 64, 64     # nstep=1024 makes gamma^n underflow the interesting part away; 16 keeps it meaningful
-    rng = np.random.default_rng(11)
+    B, N = 64, 64
+    rng = np.random.default_rng(11 + T)
     q, nq = f32(rng, B, N), f32(rng, B, N)
     a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
     r, done, w = f32(rng, T, B), f32(rng, B), f32(rng, B)
@@ -294,28 +318,43 @@ def test_dntd_golden(golden):
         assert grad_err(g[f"c{i}_grad_dist"], d.grad.cpu().numpy()) < 1e-4
 
 
-def test_dntd_oracle_reference_shape():
-    """tests/test_dntd.py:10-16: T=B=N=128, n_atom=51, v in [-10,10], abs(randn) inputs (oracle evaluated in fp32:
-    floor/ceil of the projected position is discontinuous)."""
+@pytest.mark.parametrize("T,quirks", [(128, True), (128, False), (4, True), (4, False)])
+def test_dntd_oracle_reference_shape(T, quirks):
+    """tests/test_dntd.py:10-25: T=B=N=128, n_atom=51, v in [-10,10], abs(randn) distributions; `quirks`: done / weight =
+    randn exactly as the reference draws them (negative and non-binary: SURVEY 4 "input quirks the build must accept"),
+    else 0/1 done and positive weights.  floor / ceil of the projected position is discontinuous, so the oracle is
+    evaluated in fp32 AND fp64: a sample on which those two disagree sits on an atom boundary (its n-step return rounds to
+    the other side in another summation order) and is excluded -- at most 3 % of the batch; every other sample, the loss
+    restricted to them and their gradient rows must agree with the fp32 oracle to 1e-4."""
     from hpc_rll.rl_utils.td import DistNStepTD
-    T, B, N, n_atom = 4, 128, 128, 51
-    rng = np.random.default_rng(5)
+    B, N, n_atom = 128, 128, 51
+    rng = np.random.default_rng(5 + T + int(quirks))
     dist = (np.abs(f32(rng, B, N, n_atom)) + 1e-3).astype(np.float32)
     nd = np.abs(f32(rng, B, N, n_atom))
     a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
     r = f32(rng, T, B)
-    done = (rng.random(B) < 0.3).astype(np.float32)
-    w = rng.random(B).astype(np.float32)
+    done = f32(rng, B) if quirks else (rng.random(B) < 0.3).astype(np.float32)
+    w = f32(rng, B) if quirks else rng.random(B).astype(np.float32)
     d32 = torch.from_numpy(dist).requires_grad_(True)
     l32, p32 = R.dist_nstep_td_error(d32, torch.from_numpy(nd), torch.from_numpy(a), torch.from_numpy(na),
                                      torch.from_numpy(r), torch.from_numpy(done), torch.from_numpy(w), 0.95, -10., 10., n_atom)
     l32.backward()
+    _, p64 = R.dist_nstep_td_error(D(dist), D(nd), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(w), 0.95,
+                                   -10., 10., n_atom)
     dd = G(dist, True)
     loss, per = DistNStepTD(T, B, N, n_atom)(dd, G(nd), G(a), G(na), G(r), G(done), G(w), 0.95, -10., 10.)
     loss.backward()
-    assert rel_err(l32.item(), loss.item()) < 1e-4
-    assert rel_err(p32.detach().numpy(), per.cpu().numpy()) < 1e-4
-    assert grad_err(d32.grad.numpy(), dd.grad.cpu().numpy()) < 1e-4
+    p32n, p64n, pgot = p32.detach().numpy().astype(np.float64), p64.detach().numpy(), per.cpu().numpy().astype(np.float64)
+    scale = float(np.abs(p64n).max())
+    edge = np.abs(p32n - p64n) > 1e-5 * scale          # the oracle itself is precision-sensitive on these samples
+    assert edge.mean() <= 0.03, float(edge.mean())
+    ok = ~edge
+    assert float(np.abs(p32n[ok] - pgot[ok]).max()) < 1e-4 * scale
+    if not edge.any():
+        assert rel_err(l32.item(), loss.item()) < 1e-4
+    # the gradient of sample b lives in row (b, action[b]) only and does not depend on the other samples
+    g32, ggot = d32.grad.numpy()[ok], dd.grad.cpu().numpy()[ok]
+    assert grad_err(g32, ggot) < 1e-4
 
 
 def test_c51_run_sum_projection_against_the_gather_kernel_and_the_oracle():
@@ -381,20 +420,28 @@ def test_iqn_golden(golden):
         assert grad_err(g[f"c{i}_grad_q"], q.grad.cpu().numpy()) < 5e-5
 
 
-def test_iqn_oracle_reference_shape():
-    """tests/test_iqn_nstep_td_error.py:10-16: tau=33, tau'=34, T=10, B=64, N=8, kappa=0.9."""
+@pytest.mark.parametrize("quirks", [True, False])
+def test_iqn_oracle_reference_shape(quirks):
+    """tests/test_iqn_nstep_td_error.py:10-29: tau=33, tau'=34, T=10, B=64, N=8, kappa=0.9; `quirks`: done, replay
+    quantiles, weight AND value_gamma = randn, exactly as the reference test draws them (negative, non-binary)."""
     from hpc_rll.rl_utils.td import IQNNStepTDError
     tau, taup, T, B, N, kappa = 33, 34, 10, 64, 8, 0.9
-    rng = np.random.default_rng(6)
+    rng = np.random.default_rng(6 + int(quirks))
     q, nq = f32(rng, tau, B, N), f32(rng, taup, B, N)
     a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
-    r, done = f32(rng, T, B), (rng.random(B) < 0.3).astype(np.float32)
-    rq, w = rng.random((tau, B)).astype(np.float32), rng.random(B).astype(np.float32)
+    r = f32(rng, T, B)
+    if quirks:
+        done, rq, w, vg = f32(rng, B), f32(rng, tau, B), f32(rng, B), f32(rng, B)
+    else:
+        done, rq, w, vg = (rng.random(B) < 0.3).astype(np.float32), rng.random((tau, B)).astype(np.float32), \
+            rng.random(B).astype(np.float32), None
     q64 = D(q, True)
-    l64, p64 = R.iqn_nstep_td_error(q64, D(nq), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(rq), D(w), 0.95, kappa)
+    l64, p64 = R.iqn_nstep_td_error(q64, D(nq), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(rq), D(w), 0.95,
+                                    kappa, None if vg is None else D(vg))
     l64.backward()
     dq = G(q, True)
-    loss, per = IQNNStepTDError(tau, taup, T, B, N)(dq, G(nq), G(a), G(na), G(r), G(done), G(rq), 0.95, kappa, G(w))
+    loss, per = IQNNStepTDError(tau, taup, T, B, N)(dq, G(nq), G(a), G(na), G(r), G(done), G(rq), 0.95, kappa, G(w),
+                                                    None if vg is None else G(vg))
     loss.backward()
     assert rel_err(l64.item(), loss.item()) < 2e-5
     assert rel_err(p64.detach().numpy(), per.cpu().numpy()) < 2e-5
@@ -415,19 +462,27 @@ def test_qrdqn_golden(golden):
         assert grad_err(g[f"c{i}_grad_q"], q.grad.cpu().numpy()) < 5e-5
 
 
-def test_qrdqn_oracle_reference_shape():
-    """tests/test_qrdqn_nstep_td_error.py:10-14: tau=39, T=10, B=89, N=67."""
+@pytest.mark.parametrize("quirks", [True, False])
+def test_qrdqn_oracle_reference_shape(quirks):
+    """tests/test_qrdqn_nstep_td_error.py:10-24: tau=39, T=10, B=89, N=67; `quirks`: done, weight and value_gamma = randn
+    exactly as the reference test draws them."""
     from hpc_rll.rl_utils.td import QRDQNNStepTDError
     tau, T, B, N = 39, 10, 89, 67
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(8 + int(quirks))
     q, nq = f32(rng, B, N, tau), f32(rng, B, N, tau)
     a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
-    r, done, w = f32(rng, T, B), (rng.random(B) < 0.3).astype(np.float32), rng.random(B).astype(np.float32)
+    r = f32(rng, T, B)
+    if quirks:
+        done, w, vg = f32(rng, B), f32(rng, B), f32(rng, B)
+    else:
+        done, w, vg = (rng.random(B) < 0.3).astype(np.float32), rng.random(B).astype(np.float32), None
     q64 = D(q, True)
-    l64, p64 = R.qrdqn_nstep_td_error(q64, D(nq), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), tau, D(w), 0.95)
+    l64, p64 = R.qrdqn_nstep_td_error(q64, D(nq), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), tau, D(w), 0.95,
+                                      None if vg is None else D(vg))
     l64.backward()
     dq = G(q, True)
-    loss, per = QRDQNNStepTDError(tau, T, B, N)(dq, G(nq), G(a), G(na), G(r), G(done), 0.95, G(w))
+    loss, per = QRDQNNStepTDError(tau, T, B, N)(dq, G(nq), G(a), G(na), G(r), G(done), 0.95, G(w),
+                                               None if vg is None else G(vg))
     loss.backward()
     assert rel_err(l64.item(), loss.item()) < 2e-5
     assert rel_err(p64.detach().numpy(), per.cpu().numpy()) < 2e-5

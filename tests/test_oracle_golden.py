@@ -9,8 +9,13 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, rel_err
+from conftest import ROOT, grad_err, rel_err
 from oracle import ref_torch as R
+
+# Gradients of mean-reduced losses are O(1/(T*B)): compared relative to the tensor's own maximum (conftest.grad_err), not with
+# rel_err's max(1,|ref|) denominator.  The fixtures are the reference's fp32 results, the oracle runs in
+# fp64: measured 1e-7 ... 2.7e-7 of the maximum.
+GRAD_TOL = 2e-6
 
 T64 = lambda a: torch.from_numpy(np.asarray(a)).double()  # noqa: E731
 TL = lambda a: torch.from_numpy(np.asarray(a))            # noqa: E731
@@ -26,8 +31,8 @@ def test_gae_restatement(golden):
         adv = R.gae(T64(g[f"c{i}_value"]), T64(g[f"c{i}_reward"]), gam, lam)
         assert rel_err(g[f"c{i}_adv"], adv.numpy()) < 1e-5
         gv, gr = R.gae_backward(T64(g[f"c{i}_grad_adv"]), gam, lam)
-        assert rel_err(g[f"c{i}_grad_value"], gv.numpy()) < 1e-5
-        assert rel_err(g[f"c{i}_grad_reward"], gr.numpy()) < 1e-5
+        assert grad_err(g[f"c{i}_grad_value"], gv.numpy()) < GRAD_TOL
+        assert grad_err(g[f"c{i}_grad_reward"], gr.numpy()) < GRAD_TOL
 
 
 @pytest.fixture(scope="module")
@@ -56,8 +61,8 @@ def test_gae_c_restatement(golden, cref):
         assert rel_err(g[f"c{i}_adv"], adv) < 1e-5
         gv, gr, tab = np.empty((T + 1, B), np.float32), np.empty((T, B), np.float32), np.empty(T, np.float32)
         cref.gae_ref_backward(_fp(ga), _fp(gv), _fp(gr), _fp(tab), T, B, gam, lam)
-        assert rel_err(g[f"c{i}_grad_value"], gv) < 2e-5
-        assert rel_err(g[f"c{i}_grad_reward"], gr) < 2e-5
+        assert grad_err(g[f"c{i}_grad_value"], gv) < 2e-5      # fp32 C scan against the reference's fp32 autograd
+        assert grad_err(g[f"c{i}_grad_reward"], gr) < 2e-5
 
 
 def test_gae_big_shape_statistics(golden, cref):
@@ -89,7 +94,7 @@ def test_td_lambda(golden):
         loss = R.td_lambda_error(v, T64(g[f"c{i}_reward"]), opt(g, f"c{i}_weight"), gam, lam)
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < 1e-5
-        assert rel_err(g[f"c{i}_grad_value"], v.grad.numpy()) < 1e-5
+        assert grad_err(g[f"c{i}_grad_value"], v.grad.numpy()) < GRAD_TOL
 
 
 def test_vtrace(golden):
@@ -102,8 +107,8 @@ def test_vtrace(golden):
                             opt(g, f"c{i}_weight"), gam, lam, rc, cc, pc)
         (co[0] * ls[0] + co[1] * ls[1] + co[2] * ls[2]).backward()
         assert rel_err(g[f"c{i}_losses"], [x.item() for x in ls]) < 1e-5
-        assert rel_err(g[f"c{i}_grad_target_output"], to.grad.numpy()) < 1e-5
-        assert rel_err(g[f"c{i}_grad_value"], v.grad.numpy()) < 1e-5
+        assert grad_err(g[f"c{i}_grad_target_output"], to.grad.numpy()) < GRAD_TOL
+        assert grad_err(g[f"c{i}_grad_value"], v.grad.numpy()) < GRAD_TOL
 
 
 def test_upgo(golden):
@@ -113,7 +118,7 @@ def test_upgo(golden):
         loss = R.upgo_loss(to, T64(g[f"c{i}_rhos"]), TL(g[f"c{i}_action"]), T64(g[f"c{i}_reward"]), T64(g[f"c{i}_value"]))
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < 1e-5
-        assert rel_err(g[f"c{i}_grad_target_output"], to.grad.numpy()) < 1e-5
+        assert grad_err(g[f"c{i}_grad_target_output"], to.grad.numpy()) < GRAD_TOL
 
 
 def test_ppo(golden):
@@ -128,8 +133,8 @@ def test_ppo(golden):
         (co[0] * ls[0] + co[1] * ls[1] + co[2] * ls[2]).backward()
         assert rel_err(g[f"c{i}_losses"], [x.item() for x in ls]) < 1e-5
         assert rel_err(g[f"c{i}_info"], list(info)) < 1e-5
-        assert rel_err(g[f"c{i}_grad_logit_new"], ln.grad.numpy()) < 1e-5
-        assert rel_err(g[f"c{i}_grad_value_new"], vn.grad.numpy()) < 1e-5
+        assert grad_err(g[f"c{i}_grad_logit_new"], ln.grad.numpy()) < GRAD_TOL
+        assert grad_err(g[f"c{i}_grad_value_new"], vn.grad.numpy()) < GRAD_TOL
 
 
 def test_qntd(golden):
@@ -142,7 +147,7 @@ def test_qntd(golden):
             loss.backward()
             assert rel_err(g[f"c{i}_{tag}_loss"], loss.item()) < 5e-5
             assert rel_err(g[f"c{i}_{tag}_td_err"], per.detach().numpy()) < 5e-5
-            assert rel_err(g[f"c{i}_{tag}_grad_q"], q.grad.numpy()) < 5e-5
+            assert grad_err(g[f"c{i}_{tag}_grad_q"], q.grad.numpy()) < GRAD_TOL
 
 
 def test_dntd(golden):
@@ -156,7 +161,7 @@ def test_dntd(golden):
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < 1e-4
         assert rel_err(g[f"c{i}_td_err"], per.detach().numpy()) < 1e-4
-        assert rel_err(g[f"c{i}_grad_dist"], d.grad.numpy()) < 1e-4
+        assert grad_err(g[f"c{i}_grad_dist"], d.grad.numpy()) < 5e-6   # both sides fp32 here (floor / ceil of the projection)
 
 
 def test_iqn(golden):
@@ -169,7 +174,7 @@ def test_iqn(golden):
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < 5e-5
         assert rel_err(g[f"c{i}_td_err"], per.detach().numpy()) < 5e-5
-        assert rel_err(g[f"c{i}_grad_q"], q.grad.numpy()) < 5e-5
+        assert grad_err(g[f"c{i}_grad_q"], q.grad.numpy()) < GRAD_TOL
 
 
 def test_qrdqn(golden):
@@ -182,7 +187,7 @@ def test_qrdqn(golden):
         loss.backward()
         assert rel_err(g[f"c{i}_loss"], loss.item()) < 5e-5
         assert rel_err(g[f"c{i}_td_err"], per.detach().numpy()) < 5e-5
-        assert rel_err(g[f"c{i}_grad_q"], q.grad.numpy()) < 5e-5
+        assert grad_err(g[f"c{i}_grad_q"], q.grad.numpy()) < GRAD_TOL
 
 
 def test_padding_bit_exact(golden):
@@ -211,7 +216,7 @@ def test_scatter(golden):
                 assert np.array_equal(o.detach().numpy(), g[f"c{i}_cover_out"])
             else:
                 assert rel_err(g[f"c{i}_add_out"], o.detach().numpy()) < 1e-6
-            assert rel_err(g[f"c{i}_{st}_grad_x"], x.grad.numpy()) < 1e-6
+            assert grad_err(g[f"c{i}_{st}_grad_x"], x.grad.numpy()) < GRAD_TOL
 
 
 def test_lstm(golden):
@@ -229,12 +234,12 @@ def test_lstm(golden):
         assert rel_err(g[f"c{i}_hn"], hn.detach().numpy()) < 1e-5
         assert rel_err(g[f"c{i}_cn"], cn.detach().numpy()) < 1e-5
         tol = 2e-4  # golden grads are fp32 autograd through S*L LayerNorms
-        assert rel_err(g[f"c{i}_grad_x"], x.grad.numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_h0"], h0.grad.numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_c0"], c0.grad.numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_bias"], bias.grad.numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_ln_gamma"], gam.grad.numpy()) < tol
-        assert rel_err(g[f"c{i}_grad_ln_beta"], beta.grad.numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_x"], x.grad.numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_h0"], h0.grad.numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_c0"], c0.grad.numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_bias"], bias.grad.numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_ln_gamma"], gam.grad.numpy()) < tol
+        assert grad_err(g[f"c{i}_grad_ln_beta"], beta.grad.numpy()) < tol
         for l in range(L):
-            assert rel_err(g[f"c{i}_grad_wx{l}"], wx[l].grad.numpy()) < tol
-            assert rel_err(g[f"c{i}_grad_wh{l}"], wh[l].grad.numpy()) < tol
+            assert grad_err(g[f"c{i}_grad_wx{l}"], wx[l].grad.numpy()) < tol
+            assert grad_err(g[f"c{i}_grad_wh{l}"], wh[l].grad.numpy()) < tol
