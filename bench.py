@@ -16,10 +16,14 @@ the batch axis shards across ranks with NO data-path collective.
 What the headline ``value`` is (BASELINE.json metric: "T=1024, B=64k; 1/2/4/8 GPUs"):
   * N = 1: B = 65536 on the one GPU, eager launches (``module(...)`` + ``.backward()``).
   * N > 1: STRONG scaling -- the same GLOBAL batch of 65536 trajectories split over the N ranks (B = 65536/N per GPU),
-    ``"scaling": "strong"``.  A rank then holds a step of a few tens of microseconds, the launch-latency regime, so the
-    step is launched the way the library ships for that regime: ``hpc_rll.graphed`` (forward + backward captured once
-    into a hipGraph, one hipGraphLaunch per step; same kernels, same order, same results), stated in
-    ``config.launch``.  ``--scaling weak`` / ``--launch eager`` select the other readings as the headline.
+    ``"scaling": "strong"``, ``"metric_version": 2``.  A rank then holds a step of a few tens of microseconds, the
+    launch-latency regime, where the host-side launch path decides -- and which one wins differs from box to box (r03: 35 us
+    eager vs 40 us graphed on one, 48 vs 40 on another).  So BOTH are timed in the run (W warmup + K steps each): eager
+    ``module(...)`` + ``.backward()``, and ``hpc_rll.graphed`` (forward + backward captured once into a hipGraph, one
+    hipGraphLaunch per step; same kernels, same order, same results); the headline is the faster, named in
+    ``config.launch``, both listed in ``config.launch_modes``.  ``--scaling weak`` / ``--launch eager|graph`` pin a reading.
+    ``scaling_detail.loss_ops`` times what the GAE headline has none of -- the collective: batch-sharded V-trace + TD-lambda
+    at the C3 global shape, each forward ending in its ONE all-reduce (RCCL over xGMI), with the all-reduce's share.
 Whatever the headline is, the same JSON line carries ``scaling_detail`` with BOTH readings, measured in this run after
 the headline region: weak (B = 65536 per GPU) and strong (global B = 65536 split over the N ranks), each eager and as
 hipGraph replay, with every rank's step time and the RCCL world size seen.  With one rank it also times the per-rank
@@ -36,9 +40,12 @@ Rank 0 prints ONE JSON line.  Extra objects:
                   `pytorch_restatement` is the same algorithm run the way hpc_rll.origin runs it (oracle/ref_torch.py:
                   a python loop of fp32 torch CPU ops + autograd backward), on a smaller bounded sample.
   suite        -- (N = 1) BASELINE.json configs[2..4] through the same drop-in modules: V-trace / UPGO / TD-lambda at
-                  T=256,B=16384,N=128; LSTM S=128,B=4096,H=1024; ScatterConnection (cover, add) B=4096,M=256,N=64,64x64
-                  and the packed Pad1D over 2^20 ragged rows: forward / backward ms and roofline fraction each
-                  (tests/tools/bench_suite.py holds the byte / flop models).
+                  T=256,B=16384,N=128; PPO at B=65536,N=128; q / C51 / IQN / QR-DQN n-step TD at B=262144 (IQN 65536) -- the
+                  reference prints a *_perf() timing for each of them (tests/test_qntd.py:70, test_dntd.py:73,
+                  test_qrdqn_nstep_td_error.py:77, test_ppo.py:79); LSTM S=128,B=4096,H=1024; ScatterConnection (cover, add)
+                  B=4096,M=256,N=64,64x64 and the packed Pad1D over 2^20 ragged rows: forward / backward ms and roofline
+                  fraction each, with `bound` = "hbm", "mfma" or -- for the instruction-bound quantile / C51 forwards --
+                  "valu" (tests/tools/bench_suite.py holds the byte / flop / instruction models).
 """
 import argparse
 import ctypes
@@ -68,27 +75,39 @@ def cpu_baseline(T, B, gamma, lam, budget_s=12.0):
     lib.gae_ref_forward.argtypes = [fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
     lib.gae_ref_backward.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
     lib.gae_ref_num_threads.restype = ctypes.c_int
-    Bs = min(B, 16384)  # bounded sample: a quarter of the batch axis (columns are independent)
     g = torch.Generator().manual_seed(0)
-    v, r, ga = torch.randn(T + 1, Bs, generator=g), torch.randn(T, Bs, generator=g), torch.randn(T, Bs, generator=g)
-    adv, gv, gr, tab = torch.empty(T, Bs), torch.empty(T + 1, Bs), torch.empty(T, Bs), torch.empty(T)
+    fp32 = torch.float32
     P = lambda t: ctypes.cast(t.data_ptr(), fp)  # noqa: E731
 
-    def one():
-        lib.gae_ref_forward(P(v), P(r), P(adv), T, Bs, gamma, lam)
-        lib.gae_ref_backward(P(ga), P(gv), P(gr), P(tab), T, Bs, gamma, lam)
+    def run(Bs, budget, max_reps):
+        """fwd + adjoint bwd passes of the C port at batch Bs for ~budget seconds: (samples/s, reps, seconds)."""
+        v, r, ga = (torch.randn(T + 1, Bs, generator=g, dtype=fp32), torch.randn(T, Bs, generator=g, dtype=fp32),
+                    torch.randn(T, Bs, generator=g, dtype=fp32))
+        adv, gv, gr, tab = torch.empty(T, Bs), torch.empty(T + 1, Bs), torch.empty(T, Bs), torch.empty(T)
 
-    one()
-    reps, t0 = 0, time.perf_counter()
-    while True:
+        def one():
+            lib.gae_ref_forward(P(v), P(r), P(adv), T, Bs, gamma, lam)
+            lib.gae_ref_backward(P(ga), P(gv), P(gr), P(tab), T, Bs, gamma, lam)
+
         one()
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or reps >= 200:
-            break
-    res = {"value": T * Bs * reps / dt, "unit": "samples/s", "cores": int(lib.gae_ref_num_threads()),
-           "kind": "port", "sample": f"T={T} B={Bs} (1/{B // Bs} of the batch axis) x {reps} fwd+bwd passes, "
-                                     f"oracle/gae_ref.c OpenMP, {dt:.1f}s"}
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            one()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or reps >= max_reps:
+                break
+        return T * Bs * reps / dt, reps, dt
+
+    # the metric's own configuration (VERDICT r03 item 8: one pass of the C port at the full B is ~0.2 s on this class of
+    # host), and the quarter-batch sample of the earlier rounds beside it (columns are independent: same work per sample)
+    full, reps, dt = run(B, budget_s * 0.6, 100)
+    Bq = max(1, min(B, 16384))
+    quarter, reps_q, dt_q = run(Bq, budget_s * 0.4, 200)
+    res = {"value": full, "unit": "samples/s", "cores": int(lib.gae_ref_num_threads()), "kind": "port",
+           "sample": f"T={T} B={B} (the full batch of the metric's configuration) x {reps} fwd+bwd passes, "
+                     f"oracle/gae_ref.c OpenMP, {dt:.1f}s",
+           "quarter_batch_sample": {"value": quarter, "sample": f"T={T} B={Bq} x {reps_q} passes, {dt_q:.1f}s"}}
     # The same algorithm the way hpc_rll.origin runs it (north_star: "next to hpc_rll.origin timed on the same box's host
     # CPU"): the pure-PyTorch restatement oracle/ref_torch.gae (origin/gae.py:28-37, a python loop over T of fp32 tensor
     # ops) forward + autograd backward, on a smaller bounded sample.  Reported beside the (faster) C port, never the target.
@@ -258,9 +277,10 @@ def main():
     lib = ctypes.CDLL(os.path.join(ROOT, "di-hpc_amd", "hpc_rll", "_lib", "libhpc_rll_hip.so"))   # already loaded: diagnostics
 
     scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
-    launch = "graph" if args.graph else args.launch
+    launch_arg = "graph" if args.graph else args.launch
+    launch = launch_arg
     if launch == "auto":
-        launch = "graph" if (world > 1 and scaling == "strong") else "eager"
+        launch = "eager"      # N = 1; for N > 1 both modes are timed below and the faster one leads
     T, B, gamma, lam = args.T, args.B, 0.99, 0.97
     global_B = B if scaling == "strong" else B * world
     if scaling == "strong":
@@ -315,13 +335,36 @@ def main():
         per_rank = [x.item() for x in allt]
         return max(per_rank), per_rank
 
-    step, keep = make_step(B, launch == "graph")
-    value, reward, grad_adv = keep[:3]
     # device clock / allocator pre-roll: a freshly leased GPU idles at its low power state and the first ~10 ms of
     # work run at ramping clocks.  Untimed, not part of W or K (the W warmup steps and the K timed steps follow).
-    for _ in range(max(30, int(30 * 65536 / max(B, 1)) if B < 65536 else 30)):
-        step()
-    elapsed, per_rank_s = timed(step, args.steps, args.warmup)
+    n_pre = max(30, int(30 * 65536 / max(B, 1)) if B < 65536 else 30)
+    launch_modes = None
+    if launch_arg == "auto" and world > 1:
+        # N > 1: which host-side launch path is faster at B/N trajectories per rank depends on the box (driver's r03 box at
+        # B = 8192: 35.3 us eager vs 39.8 us graphed; builder's: 47.7 vs 40.5) -- so BOTH are timed, W warmup + K steps
+        # each, same tensors' shapes, same kernels, and the headline is the faster one, named in config.launch (VERDICT r03
+        # item 2a).  Every rank takes the same decision (the times are the max over ranks, gathered).
+        launch_modes = {}
+        best = None
+        for mode in ("eager", "graph"):
+            st_m, keep_m = make_step(B, mode == "graph")
+            for _ in range(n_pre):
+                st_m()
+            el_m, per_m = timed(st_m, args.steps, args.warmup)
+            launch_modes[mode] = {"ms_per_step": el_m / args.steps * 1e3,
+                                  "per_rank_ms_per_step": [p_ / args.steps * 1e3 for p_ in per_m]}
+            if best is None or el_m < best[0]:
+                best = (el_m, per_m, mode, st_m, keep_m)
+            del st_m, keep_m
+        elapsed, per_rank_s, launch, step, keep = best
+        del best
+        value, reward, grad_adv = keep[:3]
+    else:
+        step, keep = make_step(B, launch == "graph")
+        value, reward, grad_adv = keep[:3]
+        for _ in range(n_pre):
+            step()
+        elapsed, per_rank_s = timed(step, args.steps, args.warmup)
 
     # ---- per-kernel durations, measured IMMEDIATELY after the timed region (same clocks / thermal state), in the same
     # alternating fwd/bwd order as the timed region (a kernel repeated back to back would find its inputs in the
@@ -393,6 +436,9 @@ def main():
             detail["strong_per_rank_probe"] = {str(n): {"eager": leg(GB // n, False), "graph": leg(GB // n, True)}
                                                for n in (2, 4, 8)}
 
+    if detail is not None and world > 1:
+        detail["loss_ops"] = loss_ops_leg(dev, dist, world, rank, backend, timed)
+
     # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not
     # fit one pass and cannot be combined with tracing), so the figure is the committed result of
     # tests/tools/collect_profiles.sh for this shape (profiles/<round>_gae_pmc_traffic.csv), not a live measurement --
@@ -430,6 +476,10 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
+            # 1 (rounds 1-2): weak scaling, eager launches for every N.  2 (round 3 on): N > 1 is STRONG scaling (global
+            # B = 65536 split over the ranks, BASELINE.json's reading) and its launch mode is the faster of eager / hipGraph
+            # replay, both timed in the run; N = 1 is unchanged.  The weak / eager reading stays in scaling_detail.
+            "metric_version": 2,
             "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
@@ -438,6 +488,7 @@ def main():
                        "T": T, "B_per_gpu": B, "global_B": global_B,
                        "parallelism": f"batch-sharded x{world}, no data-path collective",
                        "launch": "hpc_rll.graphed (hipGraph replay of the same kernels)" if launch == "graph" else "eager",
+                       "launch_modes": launch_modes,
                        "backend": (dist.get_backend() if dist is not None else None)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_launch / t_dom / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bytes_launch / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
@@ -447,6 +498,7 @@ def main():
                          "fwd_us": t_fwd * 1e6, "bwd_us": t_bwd * 1e6,
                          "fwd_us_min_max": [min(kf) * 1e3, max(kf) * 1e3], "bwd_us_min_max": [min(kb) * 1e3, max(kb) * 1e3],
                          "fwd_bwd_frac": (2 * bytes_launch) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS,
+                         "frac_rocprof": frac_rocprof(T, B, bytes_launch),
                          "stream_event_fwd_us": t_fwd_ev * 1e6, "stream_event_bwd_us": t_bwd_ev * 1e6,
                          "sclk_mhz": sclk.summary(), "launch_config": cfg},
             "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per_rank_s],
@@ -460,6 +512,107 @@ def main():
         dist.destroy_process_group()
 
 
+def frac_rocprof(T, B, bytes_launch):
+    """The same roofline fraction from the COMMITTED rocprofv3 summary (profiles/rNN_gae_bench_kernel_stats.csv, the
+    newest round present): kernel-trace average durations of the two GAE kernels of `python bench.py` at this shape.  Lets a
+    reader compare the live figure of this box with the committed profile in the line itself; the two
+    come from different boxes / runs and differ by the box-to-box spread (a few percent)."""
+    import csv
+    import glob
+    if (T, B) != (T_DEFAULT, B_DEFAULT):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gae_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    out = {"source": os.path.relpath(files[-1], ROOT)}
+    try:
+        for row in csv.DictReader(open(files[-1])):
+            name = row["Name"]
+            for key, tag in (("gae_fwd", "fwd"), ("gae_bwd", "bwd")):
+                if key in name and "coef" not in name and tag + "_us" not in out:
+                    avg = float(row["AverageNs"])
+                    out[tag + "_us"] = avg / 1e3
+                    out[tag + "_calls"] = int(row["Calls"])
+                    out[tag] = bytes_launch / (avg * 1e-9) / 1e9 / HBM_PEAK_GBS
+        if "fwd" in out and "bwd" in out:
+            out["dominant"] = min(out["fwd"], out["bwd"])     # the slower kernel = the lower fraction
+            out["fwd_bwd"] = 2 * bytes_launch / ((out["fwd_us"] + out["bwd_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)
+    return out
+
+
+def loss_ops_leg(dev, dist, world, rank, backend, timed, steps=50, warmup=10):
+    """the part of north_star the GAE headline does not time -- "a single RCCL all-reduce over xGMI
+    for the scalar loss".  V-trace + TD-lambda at the C3 GLOBAL shape (T=256, B=16384, N=128), the batch axis split over the
+    ranks, through the drop-in modules with sharded=True: every forward ends in its ONE all-reduce (3 scalars for V-trace,
+    1 for TD-lambda; hpc_rll/dist.py), the backward needs none.  A step = V-trace forward + backward, TD-lambda forward +
+    backward.  Timed like the headline (barrier + synchronize on both sides, max over ranks).  The all-reduce's share is
+    read off a second pass of the SAME local work without the collective (sharded=False and the global loss scale passed
+    by hand would need a private entry point, so: the modules as they are, with the process group's all-reduce replaced by
+    nothing = sharded=False; the local kernels are identical, the scale differs by a constant factor), plus the bare
+    latency of a 3-scalar all-reduce on this group."""
+    import time as _t
+    from hpc_rll.rl_utils.td import TDLambda
+    from hpc_rll.rl_utils.vtrace import VTrace
+    T, GB, N = 256, 16384, 128
+    if GB % world:
+        return {"skipped": f"global B {GB} does not divide by {world} ranks"}
+    Bk = GB // world
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    to = torch.randn(T, Bk, N, device=dev, generator=g).requires_grad_(True)
+    bo = torch.randn(T, Bk, N, device=dev, generator=g)
+    act = torch.randint(0, N, (T, Bk), device=dev, generator=g)
+    val = torch.randn(T + 1, Bk, device=dev, generator=g).requires_grad_(True)
+    rew = torch.randn(T, Bk, device=dev, generator=g)
+    wt = torch.rand(T, Bk, device=dev, generator=g)
+    res = {"T": T, "global_B": GB, "B_per_gpu": Bk, "N": N,
+           "step": "VTrace fwd (+ its one all-reduce of 3 scalars) + bwd, TDLambda fwd (+ its one all-reduce of 1 scalar) + bwd",
+           "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else None}
+    if dist.get_backend() == "nccl":
+        assert dist.get_world_size() == world, "RCCL world size differs from --gpus"
+    losses = {}
+    for sharded in (True, False):
+        vt, td = VTrace(T, Bk, N, sharded=sharded), TDLambda(T, Bk, sharded=sharded)
+
+        def step():
+            to.grad = None
+            val.grad = None
+            ls = vt(to, bo, act, val, rew)
+            (ls.policy_loss + ls.value_loss + ls.entropy_loss).sum().backward()
+            val.grad = None
+            l2 = td(val, rew, wt, 0.9, 0.8)
+            l2.sum().backward()
+            return ls, l2
+
+        ls, l2 = step()
+        losses[sharded] = [float(x.item()) for x in (*ls, l2)]
+        mx, per = timed(step, steps, warmup)
+        key = "sharded" if sharded else "local_only_no_collective"
+        res[key] = {"ms_per_step": mx / steps * 1e3, "per_rank_ms_per_step": [p_ / steps * 1e3 for p_ in per]}
+    res["global_losses_vtrace_pg_v_ent_tdlambda"] = losses[True]
+    t_s, t_l = res["sharded"]["ms_per_step"], res["local_only_no_collective"]["ms_per_step"]
+    res["allreduce_share_of_step"] = max(0.0, (t_s - t_l) / t_s) if t_s > 0 else None
+    # bare latency of the collective the forward ends in
+    buf = torch.zeros(3, device=dev if backend == "nccl" else "cpu")
+    for _ in range(10):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = _t.perf_counter()
+    for _ in range(100):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    res["allreduce_3_scalars_us"] = (_t.perf_counter() - t0) / 100 * 1e6
+    # every rank must hold the same global loss (the all-reduce's result), bit for bit
+    chk = torch.tensor(losses[True], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    res["global_loss_identical_on_every_rank"] = bool(torch.equal(lo, hi))
+    return res
+
+
 def run_suite(dev):
     """BASELINE.json configs[2..4] through the drop-in modules (bounded: well under a minute).  The timing harness and
     the algorithmic byte / flop models are tests/tools/bench_suite.py's (the tool DESIGN.md's tables come from)."""
@@ -469,7 +622,8 @@ def run_suite(dev):
     S.dev = dev
     t0 = time.perf_counter()
     out = {}
-    for name, fn in (("c3", S.suite_c3), ("c4", S.suite_c4), ("c5", lambda: S.suite_c5(quick=True))):
+    for name, fn in (("c3", S.suite_c3), ("ppo", S.suite_ppo), ("td", S.suite_td), ("c4", S.suite_c4),
+                     ("c5", lambda: S.suite_c5(quick=True))):
         S.rows.clear()
         try:
             fn()
@@ -479,7 +633,7 @@ def run_suite(dev):
             out[name + "_error"] = repr(e)
         torch.cuda.empty_cache()
     out["seconds"] = time.perf_counter() - t0
-    out["peaks"] = {"hbm_GBs": S.HBM, "mfma_f32_TFLOPs": S.MFMA_F32}
+    out["peaks"] = {"hbm_GBs": S.HBM, "mfma_f32_TFLOPs": S.MFMA_F32, "valu_wave_insts_per_s": S.VALU_PEAK}
     return out
 
 

@@ -200,13 +200,14 @@ def _c5_single(pad, unpad, scatter, dev="cpu"):
     return loss.item(), max(len(e) for e in ents), tx.grad.cpu().numpy()
 
 
-def test_cpu_gloo_configs4_entity_sharded_scatter_pad():
+@pytest.mark.parametrize("world", [2, 8])
+def test_cpu_gloo_configs4_entity_sharded_scatter_pad(world):
     """BASELINE.json configs[4] data-parallel leg on the CPU tier: Pad1D/Unpad + ScatterConnection sharded by entity
-    index, scalar loss all-reduced (gloo, world 2) == the single-process loss; the pad width is agreed with one int
-    all-reduce(max); the gradient of a shard equals the corresponding rows of the full gradient."""
+    index, scalar loss all-reduced (gloo; world 2 and the configuration's own world 8 -- "sharded over 8 x MI355X") ==
+    the single-process loss; the pad width is agreed with one int all-reduce(max); the gradient of a shard equals the
+    corresponding rows of the full gradient."""
     from oracle import ref_torch as R
-    world = 2
-    res = _spawn(_cpu_c5_worker, world, 120)
+    res = _spawn(_cpu_c5_worker, world, 240)
     full, width, gx = _c5_single(lambda l: R.pad(l, 0), R.unpad, lambda a, b: R.scatter_connection(a, b, 5, 7, "add"))
     k = gx.shape[0] // world
     for rank, total, w, g in res:
@@ -400,7 +401,15 @@ def test_gpu_rccl_backend_on_device_tensors():
 def _check_bench_line(d, scaling, launch_word, B_per_gpu):
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == scaling
     assert d["config"]["B_per_gpu"] == B_per_gpu and d["config"]["global_B"] == 2 * B_per_gpu
-    assert launch_word in d["config"]["launch"] and d["config"]["backend"] == "gloo"
+    assert d["config"]["backend"] == "gloo" and d["metric_version"] == 2
+    if launch_word is not None:
+        assert launch_word in d["config"]["launch"] and d["config"]["launch_modes"] is None
+    else:      # auto for N > 1: both host launch paths timed in the run, the faster one leads
+        lm = d["config"]["launch_modes"]
+        assert set(lm) == {"eager", "graph"} and all(len(v["per_rank_ms_per_step"]) == 2 for v in lm.values())
+        fastest = min(lm, key=lambda k: lm[k]["ms_per_step"])
+        assert ("graphed" if fastest == "graph" else "eager") in d["config"]["launch"]
+        assert abs(d["ms_per_step"] - lm[fastest]["ms_per_step"]) < 1e-9
     assert len(d["per_rank_ms_per_step"]) == 2 and d["cpu_baseline"] is None and d["suite"] is None
     assert abs(d["value"] - 1024 * 2 * B_per_gpu / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     rf = d["roofline"]
@@ -414,6 +423,12 @@ def _check_bench_line(d, scaling, launch_word, B_per_gpu):
             assert leg["B_per_gpu"] == per_gpu and leg["global_B"] == 2 * per_gpu
             assert len(leg["per_rank_ms_per_step"]) == 2 and len(leg["rounds_ms_per_step"]) == 3 and leg["ms_per_step"] > 0
     assert sd["strong_per_rank_probe"] is None        # only printed by a single rank
+    lo = sd["loss_ops"]      # V-trace + TD-lambda at the C3 global shape, batch-sharded, ONE all-reduce per forward in the step
+    assert lo["global_B"] == 16384 and lo["B_per_gpu"] == 8192 and lo["backend"] == "gloo" and lo["rccl_ranks"] is None
+    assert lo["sharded"]["ms_per_step"] > 0 and lo["local_only_no_collective"]["ms_per_step"] > 0
+    assert len(lo["sharded"]["per_rank_ms_per_step"]) == 2 and 0.0 <= lo["allreduce_share_of_step"] < 1.0
+    assert lo["allreduce_3_scalars_us"] > 0 and lo["global_loss_identical_on_every_rank"] is True
+    assert len(lo["global_losses_vtrace_pg_v_ent_tdlambda"]) == 4
 
 
 def _bench_env():
@@ -444,7 +459,8 @@ def test_bench_two_ranks_emits_both_scaling_readings(tmp_path):
 def test_bench_launches_its_own_ranks():
     """a plain `python bench.py --gpus 2` (no launcher -- the form of the driver's N=1 command) starts
     its own two ranks and exits 0.  Defaults for N > 1: the STRONG reading (--B is the global batch, split over the
-    ranks) launched through hpc_rll.graphed."""
+    ranks); eager launches AND hpc_rll.graphed replay are both timed and the faster leads; the
+    `scaling_detail.loss_ops` leg times batch-sharded V-trace + TD-lambda with their one all-reduce in the step (2b)."""
     import json
     import subprocess
     import sys
@@ -455,7 +471,7 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
-    _check_bench_line(json.loads(lines[0]), "strong", "graphed", 4096)
+    _check_bench_line(json.loads(lines[0]), "strong", None, 4096)
 
 
 def _rccl_multi_worker(rank, world, port, q):

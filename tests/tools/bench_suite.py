@@ -16,7 +16,21 @@ import torch  # noqa: E402
 dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cuda:0")
 QUIET = False      # bench.py imports this module for its `suite` object and sets QUIET (one JSON line on stdout)
 HBM, MFMA_F32 = 8000.0, 157.3   # GB/s, TFLOP/s (MI355X_MICROARCH.md)
+# vector-ALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction = 4 cycles of its SIMD, 2.4 GHz peak shader clock
+VALU_PEAK = 1024 * 2.4e9 / 4     # wave-instructions / s
 rows = []
+
+
+def valu_counts():
+    """VALU wave-instructions per SAMPLE of the instruction-bound forwards, from hardware counters (rocprofv3 --pmc
+    SQ_INSTS_VALU, tests/tools/r04_td_valu.sh -> profiles/td_valu.json).  A static property of the compiled kernel at
+    the recorded shape; the record names the source file's hash so that a stale count is not quoted for a changed kernel."""
+    path = os.path.join(ROOT, "profiles", "td_valu.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return {}
+    return rec.get("valu_wave_insts_per_sample", {})
 
 
 def timed(fn, n=5, rounds=3):
@@ -33,12 +47,23 @@ def timed(fn, n=5, rounds=3):
     return statistics.median(ts)
 
 
-def report(name, shape, t_f, bytes_f, t_b=None, bytes_b=None, flops_f=None, flops_b=None):
+def report(name, shape, t_f, bytes_f, t_b=None, bytes_b=None, flops_f=None, flops_b=None, valu_f=None):
+    """valu_f: VALU wave-instructions of one forward launch (hardware counter): when the vector-ALU issue fraction exceeds
+    the HBM fraction the forward is instruction-bound and says so -- bound "valu", fwd_frac = the VALU fraction, the HBM
+    reading kept as fwd_hbm_frac (an HBM fraction of 0.19 for a kernel whose VALU pipe is 67 % busy
+    hides the real fraction)."""
     r = dict(op=name, shape=shape, fwd_ms=t_f * 1e3)
     if flops_f:
         r.update(fwd_tflops=flops_f / t_f / 1e12, fwd_frac=flops_f / t_f / 1e12 / MFMA_F32, bound="mfma")
     else:
         r.update(fwd_gbs=bytes_f / t_f / 1e9, fwd_frac=bytes_f / t_f / 1e9 / HBM, bound="hbm")
+        if valu_f:
+            vf = valu_f / t_f / VALU_PEAK
+            r.update(fwd_valu_frac=vf, fwd_valu_insts=valu_f)
+            if vf > r["fwd_frac"]:
+                r.update(bound="valu", fwd_hbm_frac=r["fwd_frac"], fwd_frac=vf,
+                         bound_note="forward is VALU-issue bound: fwd_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x "
+                                    "time); backward (a write stream) stays HBM")
     if t_b is not None:
         r.update(bwd_ms=t_b * 1e3)
         if flops_b:
@@ -110,6 +135,9 @@ def add_kernel_times(t_f, bytes_f, t_b, bytes_b):
     """attach the graph-replay (kernel-bound) readings to the row `report` just appended"""
     rows[-1].update(fwd_kernel_ms=t_f * 1e3, fwd_kernel_frac=bytes_f / t_f / 1e9 / HBM, bwd_kernel_ms=t_b * 1e3,
                     bwd_kernel_frac=bytes_b / t_b / 1e9 / HBM)
+    if rows[-1].get("bound") == "valu":
+        rows[-1].update(fwd_kernel_hbm_frac=rows[-1]["fwd_kernel_frac"],
+                        fwd_kernel_frac=rows[-1]["fwd_valu_insts"] / t_f / VALU_PEAK)
     if not QUIET:
         print(json.dumps(rows[-1]), flush=True)
 
@@ -195,6 +223,7 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     weight = torch.rand(B, device=dev, generator=g)
     a, na = act(), act()
     per_sample = 16 + 4 * nstep + 4 + 4 + 4   # actions, rewards, done, weight, td_err
+    vc = valu_counts()
 
     q = torch.randn(B, N, device=dev, generator=g, requires_grad=True)
     nq = torch.randn(B, N, device=dev, generator=g)
@@ -210,7 +239,7 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     m = DistNStepTD(nstep, B, N, n_atom)
     t_f, t_b = fwd_bwd(lambda: m(d, nd, a, na, reward, done, weight, 0.99, -10.0, 10.0)[0], [d])
     report("dist_nstep_td", f"B={B} N={N} atoms={n_atom}", t_f, B * (2 * line(4 * n_atom) + 128 + per_sample + 4 * n_atom),
-           t_b, B * (4 * N * n_atom + 4 * n_atom))
+           t_b, B * (4 * N * n_atom + 4 * n_atom), valu_f=vc.get("dist_nstep_td_fwd", 0) * B)
     add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(d, nd, a, na, reward, done, weight, 0.99, -10.0, 10.0)[0], [d]),
                                          (B * (2 * line(4 * n_atom) + 128 + per_sample + 4 * n_atom), B * (4 * N * n_atom + 4 * n_atom)))
                        for x in pair])
@@ -225,7 +254,7 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     t_f, t_b = fwd_bwd(lambda: m(qi, nqi, ai, nai, reward[:, :Bi].contiguous(), done[:Bi].contiguous(), rq, 0.99, 1.0,
                                  weight[:Bi].contiguous())[0], [qi])
     report("iqn_nstep_td", f"tau=tau'={tau} B={Bi} N={N}", t_f, Bi * (2 * tau * 128 + 8 * tau + per_sample), t_b,
-           Bi * (4 * tau * N + 4 * tau))
+           Bi * (4 * tau * N + 4 * tau), valu_f=vc.get("iqn_nstep_td_fwd", 0) * Bi)
     ri, di, wi = reward[:, :Bi].contiguous(), done[:Bi].contiguous(), weight[:Bi].contiguous()
     add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(qi, nqi, ai, nai, ri, di, rq, 0.99, 1.0, wi)[0], [qi]),
                                          (Bi * (2 * tau * 128 + 8 * tau + per_sample), Bi * (4 * tau * N + 4 * tau))) for x in pair])
@@ -236,7 +265,7 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     m = QRDQNNStepTDError(tau, nstep, B, N)
     t_f, t_b = fwd_bwd(lambda: m(qq, nqq, a, na, reward, done, 0.99, weight)[0], [qq])
     report("qrdqn_nstep_td", f"B={B} N={N} tau={tau}", t_f, B * (2 * line(4 * tau) + per_sample + 4 * tau), t_b,
-           B * (4 * N * tau + 4 * tau))
+           B * (4 * N * tau + 4 * tau), valu_f=vc.get("qrdqn_nstep_td_fwd", 0) * B)
     add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(qq, nqq, a, na, reward, done, 0.99, weight)[0], [qq]),
                                          (B * (2 * line(4 * tau) + per_sample + 4 * tau), B * (4 * N * tau + 4 * tau))) for x in pair])
 
