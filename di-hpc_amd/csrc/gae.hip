@@ -24,7 +24,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <initializer_list>
+#include <new>
 #include <type_traits>
 
 #include "hpc_rll_hip.h"
@@ -760,7 +762,8 @@ struct KTime {
     int cap = 0, n = 0;
     hipEvent_t* ev = nullptr;
     int* kind = nullptr;
-    int last_cfg[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};   // per direction: v, lc, nw, flags, half, pipelined
+    std::atomic<int> last_cfg[2][6] = {};   // per direction: v, lc, nw, flags, half, pipelined (relaxed atomics: GAE launches
+                                            // may come from several host threads; a diagnostic, no ordering implied)
 };
 KTime g_kt;
 
@@ -906,7 +909,7 @@ inline void for_each_cfg(F&& f) {
     do {                                                                                           \
         bool hit = false;                                                                          \
         {                                                                                          \
-            int* lc_ = g_kt.last_cfg[KIND];                                                        \
+            std::atomic<int>* lc_ = g_kt.last_cfg[KIND];                                           \
             lc_[0] = cfg.v; lc_[1] = cfg.lc; lc_[2] = cfg.nw; lc_[3] = cfg.flags; lc_[4] = cfg.half; lc_[5] = cfg.pf; \
         }                                                                                          \
         if (cfg.half) {                                                                            \
@@ -1028,7 +1031,7 @@ extern "C" int hpc_rll_gae_forward_ex(const float* value, const float* reward, f
         return check_launch();
     }
     if (cfg.pf) {
-        int* lc_ = g_kt.last_cfg[0];
+        std::atomic<int>* lc_ = g_kt.last_cfg[0];
         lc_[0] = cfg.v; lc_[1] = cfg.lc; lc_[2] = cfg.nw; lc_[3] = cfg.flags; lc_[4] = 0; lc_[5] = 1;
         if (!dispatch_fwd_pf(cfg, B, st, value, reward, adv, coef, T, B, gamma)) return HPC_RLL_EUNSUPPORTED;
         return check_launch();
@@ -1058,7 +1061,7 @@ extern "C" int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value,
     const Cfg cfg = choose_cfg(false, T, B, max_vec(B, {grad_adv, grad_value, grad_reward}), vec, lc, nw, flags);
     hipStream_t st = (hipStream_t)stream;
     if (cfg.pf && grad_value && grad_reward) {
-        int* lc_ = g_kt.last_cfg[1];
+        std::atomic<int>* lc_ = g_kt.last_cfg[1];
         lc_[0] = cfg.v; lc_[1] = cfg.lc; lc_[2] = cfg.nw; lc_[3] = cfg.flags; lc_[4] = 0; lc_[5] = 1;
         if (!dispatch_bwd_pf(cfg, B, st, grad_adv, grad_value, grad_reward, coef, T, B, gamma)) return HPC_RLL_EUNSUPPORTED;
         return check_launch();
@@ -1075,11 +1078,19 @@ extern "C" int hpc_rll_gae_backward(const float* grad_adv, float* grad_value, fl
 // ---- diagnostics: per-launch kernel durations of the GAE kernels (see KTime above) ----------------------------------
 extern "C" int hpc_rll_ktime_begin(int capacity) {
     if (capacity <= 0 || g_kt.on) return HPC_RLL_EINVAL;
-    g_kt.ev = new hipEvent_t[2 * (size_t)capacity];
-    g_kt.kind = new int[capacity];
-    for (int i = 0; i < 2 * capacity; ++i) {
-        const hipError_t e = hipEventCreate(&g_kt.ev[i]);
-        if (e != hipSuccess) return (int)e;
+    g_kt.ev = new (std::nothrow) hipEvent_t[2 * (size_t)capacity];
+    g_kt.kind = new (std::nothrow) int[capacity];
+    hipError_t e = (g_kt.ev && g_kt.kind) ? hipSuccess : hipErrorOutOfMemory;
+    int made = 0;
+    for (; e == hipSuccess && made < 2 * capacity; ++made) e = hipEventCreate(&g_kt.ev[made]);
+    if (e != hipSuccess) {   // nothing half-initialised is left behind: the events made so far, both arrays
+        for (int i = 0; i + 1 < made; ++i) (void)hipEventDestroy(g_kt.ev[i]);   // (the failed slot itself was never created)
+        delete[] g_kt.ev;
+        delete[] g_kt.kind;
+        g_kt.ev = nullptr;
+        g_kt.kind = nullptr;
+        g_kt.cap = g_kt.n = 0;
+        return (int)e;
     }
     g_kt.cap = capacity;
     g_kt.n = 0;

@@ -885,10 +885,13 @@ extern "C" int64_t hpc_rll_lstm_workspace_y_offset(int S, int B, int I, int H, i
     return (int64_t)(carve(fake, S, B, I, H, L, dropout_p > 0.f).layer[L - 1].hseq - fake);
 }
 
-extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float* c0, const float* wx,
+namespace hpc_rll { namespace {
+// y_hseq: y doubles as the last layer's h sequence (the caller hands the SAME y to the backward, which reads it there):
+// the cells write y directly, the workspace's own slot for it stays unused, no (S,B,H) copy.
+int lstm_forward_impl(const float* x, const float* h0, const float* c0, const float* wx,
                                     const float* wh, const float* bias, const float* ln_gamma, const float* ln_beta,
                                     float* y, float* hn, float* cn, float* ws, int S, int B, int I, int H, int L,
-                                    float dropout_p, uint64_t seed, void* stream) {
+                                    float dropout_p, uint64_t seed, bool y_hseq, void* stream) {
     if (S < 0 || B < 0 || I <= 0 || H <= 0 || L <= 0 || L > 16) return HPC_RLL_EINVAL;
     if (H > 2048) return HPC_RLL_EUNSUPPORTED;
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return HPC_RLL_EINVAL;
@@ -898,7 +901,7 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
     if (S > 0 && (!x || !y || !ws)) return HPC_RLL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t SB = (size_t)S * B, G = 4 * (size_t)H, BH = (size_t)B * H;
-    const Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
+    Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
     if (S > 0 && cell_recompute_gates(B, H)) {   // the backward recomputes the gates: it needs bias and beta (not in its list)
         int rc = copy_async(w.pstash, bias, (size_t)L * G, st);
         if (!rc) rc = copy_async(w.pstash + (size_t)L * G, ln_beta, (size_t)L * 2 * G, st);
@@ -906,7 +909,11 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
     }
     size_t wx_off = 0;
     WaveCfg wc{};
-    if (S > 0 && wave_fwd_ok(S, B, H, L, &wc, st)) {   // all layers in one launch, as a wavefront (lstm_wave.hpp)
+    const bool wave = S > 0 && wave_fwd_ok(S, B, H, L, &wc, st);
+    // (the layer wavefront addresses every layer's buffers with one stride: it keeps its h sequences in the workspace and
+    // y is filled by the copy at the end -- a few KB at B <= 4)
+    if (y_hseq && !wave && S > 0) w.layer[L - 1].hseq = y;
+    if (wave) {   // all layers in one launch, as a wavefront (lstm_wave.hpp)
         const LayerWs& l0 = w.layer[0];
         {
             const int skf = gemm_splitk((int)SB, (int)G, I);
@@ -1018,9 +1025,10 @@ extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float
     return last_error();
 }
 
-extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const float* dcn, const float* x,
+// y_ext != null: the last layer's h sequence lives in y (see lstm_forward_impl), not in the workspace
+int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, const float* x,
                                      const float* h0, const float* c0, const float* wx, const float* wh,
-                                     const float* ln_gamma, float* ws, float* dx, float* dh0, float* dc0, float* dwx,
+                                     const float* ln_gamma, const float* y_ext, float* ws, float* dx, float* dh0, float* dc0, float* dwx,
                                      float* dwh, float* dbias, float* dln_gamma, float* dln_beta, int S, int B, int I,
                                      int H, int L, float dropout_p, uint64_t seed, void* stream) {
     if (S <= 0 || B <= 0 || I <= 0 || H <= 0 || L <= 0 || L > 16) return HPC_RLL_EINVAL;
@@ -1032,7 +1040,8 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         return HPC_RLL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t SB = (size_t)S * B, G = 4 * (size_t)H, BH = (size_t)B * H;
-    const Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
+    Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
+    if (y_ext) w.layer[L - 1].hseq = const_cast<float*>(y_ext);   // read only on this side
     size_t wx_offs[16];
     {
         size_t o = 0;
@@ -1205,6 +1214,43 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
         if (rc) return rc;
     }
     return HPC_RLL_OK;
+}
+} }  // namespace hpc_rll::(anonymous)
+
+extern "C" int hpc_rll_lstm_forward(const float* x, const float* h0, const float* c0, const float* wx,
+                                    const float* wh, const float* bias, const float* ln_gamma, const float* ln_beta,
+                                    float* y, float* hn, float* cn, float* ws, int S, int B, int I, int H, int L,
+                                    float dropout_p, uint64_t seed, void* stream) {
+    return lstm_forward_impl(x, h0, c0, wx, wh, bias, ln_gamma, ln_beta, y, hn, cn, ws, S, B, I, H, L, dropout_p, seed, false,
+                             stream);
+}
+extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const float* dcn, const float* x,
+                                     const float* h0, const float* c0, const float* wx, const float* wh,
+                                     const float* ln_gamma, float* ws, float* dx, float* dh0, float* dc0, float* dwx,
+                                     float* dwh, float* dbias, float* dln_gamma, float* dln_beta, int S, int B, int I,
+                                     int H, int L, float dropout_p, uint64_t seed, void* stream) {
+    return lstm_backward_impl(dy, dhn, dcn, x, h0, c0, wx, wh, ln_gamma, nullptr, ws, dx, dh0, dc0, dwx, dwh, dbias, dln_gamma,
+                              dln_beta, S, B, I, H, L, dropout_p, seed, stream);
+}
+// The pair a framework binding uses (ABI 4): y is the caller's own (S,B,H) tensor AND the last layer's saved h sequence.
+// The forward's cells write it directly (no copy, nothing of the workspace is handed out), the backward gets the same y
+// back.  A holder of y pins S*B*H floats, not the workspace; modifying y between the two calls invalidates the backward
+// (the binding's job to detect: torch's saved-tensor version counter does).
+extern "C" int hpc_rll_lstm_forward_y(const float* x, const float* h0, const float* c0, const float* wx,
+                                      const float* wh, const float* bias, const float* ln_gamma, const float* ln_beta,
+                                      float* y, float* hn, float* cn, float* ws, int S, int B, int I, int H, int L,
+                                      float dropout_p, uint64_t seed, void* stream) {
+    return lstm_forward_impl(x, h0, c0, wx, wh, bias, ln_gamma, ln_beta, y, hn, cn, ws, S, B, I, H, L, dropout_p, seed, true,
+                             stream);
+}
+extern "C" int hpc_rll_lstm_backward_y(const float* dy, const float* dhn, const float* dcn, const float* x,
+                                       const float* h0, const float* c0, const float* wx, const float* wh,
+                                       const float* ln_gamma, const float* y, float* ws, float* dx, float* dh0, float* dc0,
+                                       float* dwx, float* dwh, float* dbias, float* dln_gamma, float* dln_beta, int S, int B,
+                                       int I, int H, int L, float dropout_p, uint64_t seed, void* stream) {
+    if (!y) return HPC_RLL_EINVAL;
+    return lstm_backward_impl(dy, dhn, dcn, x, h0, c0, wx, wh, ln_gamma, y, ws, dx, dh0, dc0, dwx, dwh, dbias, dln_gamma,
+                              dln_beta, S, B, I, H, L, dropout_p, seed, stream);
 }
 
 extern "C" int hpc_rll_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_sm,

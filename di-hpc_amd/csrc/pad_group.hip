@@ -118,7 +118,10 @@ __global__ __launch_bounds__(1024) void split_plan_kernel(const int32_t* __restr
     int64_t* goff = plan + 3 + 2 * G;
     if (mode == 1) {
         // ---- sample policy (padding.cu:8-43): group-1 random cuts in [1, n-2], consecutive duplicates re-drawn,
-        // sorted; a cut whose bucket has the same width as the previous bucket is dropped.  splitmix64 stream.
+        // sorted; a cut whose bucket has the same width as the previous bucket is skipped exactly as the reference skips it
+        // (its rows join the next accepted bucket; after the last cut, the previous one); a repeated cut position is
+        // dropped (the reference would emit an empty bucket of width -1).  Same rule and same splitmix64 stream as the host's
+        // hpc_rll_sample_split_group: identical boundaries for identical (lengths, group, seed).
         if (t == 0) {
             int64_t cut[64];
             int nc = 0;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(1024) void split_plan_kernel(const int32_t* __restr
                 if (idx <= last_idx) continue;
                 while (E[r + 1] <= idx) ++r;                        // run holding sorted element idx = the bucket's maximum
                 const int64_t w = val[r];
-                if (ng > 0 && gmax[ng - 1] == w) { last_idx = idx; continue; }
+                if (ng > 0 && gmax[ng - 1] == w) continue;   // the reference's skip: last_idx stays (padding.cu:34-35)
                 gmax[ng] = w;
                 pos[ng] = last_idx + 1;
                 ++ng;

@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void pad1d_packed_kernel(const float* __restri
         const long lo4 = lo - (long)(((base >> 2) + (unsigned long)lo) & 3UL);
         // a length beyond max_len (the caller's precondition, unchecked) must not overrun the tile: such a workgroup
         // reads its rows straight from memory
-        const bool fits = hi - lo4 <= (long)RB * L + 8 && hi >= lo;
+        // (the staging loop writes WHOLE 16-byte chunks, so the bound is on the span rounded up to a chunk: when RB * L is
+        // no multiple of 4 the last chunk would otherwise reach up to 3 floats past the tile, into s_off -- ADVICE r03)
+        const bool fits = ((hi - lo4 + 3) & ~3L) <= (((long)RB * L + 8) & ~3L) && hi >= lo;
         if (fits)
             for (long p = lo4 + (long)threadIdx.x * 4; p < hi; p += 1024)
                 *reinterpret_cast<vfloat4*>(tile + (p - lo4)) = *reinterpret_cast<const vfloat4*>(flat + p);
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void unpad1d_packed_kernel(const float* __rest
         const long lo = s_off[0];
         const long hi = s_off[nr] < total ? s_off[nr] : total;
         const long lo4 = lo - (long)(((base >> 2) + (unsigned long)lo) & 3UL);
-        const bool fits = s_off[nr] - lo4 <= (long)RB * L + 8 && s_off[nr] >= lo;   // see pad1d_packed_kernel
+        const bool fits = ((s_off[nr] - lo4 + 3) & ~3L) <= (((long)RB * L + 8) & ~3L) && s_off[nr] >= lo;   // see pad1d_packed_kernel
         const unsigned long obase = (unsigned long)r0 * L, oend = obase + (unsigned long)nr * L;
         for (unsigned long o = (obase & ~3UL) + (unsigned long)threadIdx.x * 4; o < oend; o += 1024) {
             const unsigned long first = o < obase ? obase : o;
@@ -975,11 +977,11 @@ extern "C" int hpc_rll_sample_split_group(const int32_t* sizes, int n, int dim, 
         int32_t shape[3] = {-1, -1, -1};
         for (int t = last_idx + 1; t <= idx; ++t)
             for (int d = 0; d < dim; ++d) shape[d] = std::max(shape[d], sizes[(size_t)t * dim + d]);
-        if (ng > 0 && std::memcmp(shape, group_shapes + (ng - 1) * dim, sizeof(int32_t) * dim) == 0) {
-            // same padded shape as the previous group: merge into it (the reference skips the cut)
-            last_idx = idx;
-            continue;
-        }
+        // same padded shape as the previous group: the reference skips the cut WITHOUT moving last_idx (padding.cu:34-35),
+        // so these rows join the NEXT accepted group -- or, after the final cut, the previous one (its end is N).  Mirrored
+        // exactly.  What is not reproduced: a repeated cut position (idx <= last_idx) makes the reference emit an
+        // EMPTY group of shape -1 (its loop over last_idx+1 .. idx is empty), which GroupPad then cannot allocate; dropped.
+        if (ng > 0 && std::memcmp(shape, group_shapes + (ng - 1) * dim, sizeof(int32_t) * dim) == 0) continue;
         for (int d = 0; d < dim; ++d) group_shapes[ng * dim + d] = shape[d];
         positions[ng] = last_idx + 1;
         ++ng;

@@ -66,13 +66,15 @@ bool lstm_recover_from_timeout(const char* what) {
     return true;
 }
 
+// y_hseq: y is also the last layer's saved h sequence (hpc_rll_lstm_forward_y / _backward_y): written by the cells, no copy
 void lstm_forward_launch(const LstmDims& d, const Tensor& x, const Tensor& h0, const Tensor& c0, const Tensor& wx,
                          const Tensor& wh, const Tensor& bias, const Tensor& gamma, const Tensor& beta, const Tensor& y,
-                         const Tensor& hn, const Tensor& cn, const Tensor& ws, double dropout, uint64_t seed) {
+                         const Tensor& hn, const Tensor& cn, const Tensor& ws, double dropout, uint64_t seed,
+                         bool y_hseq = false) {
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const int rc = hpc_rll_lstm_forward(fptr(x), fptr(h0), fptr(c0), fptr(wx), fptr(wh), fptr(bias), fptr(gamma),
-                                            fptr(beta), fmut(y), fmut(hn), fmut(cn), fmut(ws), (int)d.S, (int)d.B, (int)d.I,
-                                            (int)d.H, (int)d.L, (float)dropout, seed, stream_of(d.dev));
+        const int rc = (y_hseq ? hpc_rll_lstm_forward_y : hpc_rll_lstm_forward)(
+            fptr(x), fptr(h0), fptr(c0), fptr(wx), fptr(wh), fptr(bias), fptr(gamma), fptr(beta), fmut(y), fmut(hn), fmut(cn),
+            fmut(ws), (int)d.S, (int)d.B, (int)d.I, (int)d.H, (int)d.L, (float)dropout, seed, stream_of(d.dev));
         if (rc == HPC_RLL_ETIMEOUT && attempt == 0 && lstm_recover_from_timeout("this forward")) continue;
         check(rc, "hpc_rll_lstm_forward");
         return;
@@ -83,13 +85,23 @@ struct LstmGrads { Tensor dx, dh0, dc0, dwx, dwh, dbias, dgamma, dbeta; };
 
 void lstm_backward_launch(const LstmDims& d, const Tensor& dy, const Tensor& dhn, const Tensor& dcn, const Tensor& x,
                           const Tensor& h0, const Tensor& c0, const Tensor& wx, const Tensor& wh, const Tensor& gamma,
-                          const Tensor& ws, const LstmGrads& g, double dropout, uint64_t seed, int64_t fwd_epoch = -1) {
+                          const Tensor& ws, const LstmGrads& g, double dropout, uint64_t seed, int64_t fwd_epoch = -1,
+                          const Tensor& y_hseq = Tensor()) {
     // a timeout seen now may be this graph's own forward: its saved activations cannot be trusted
     const bool recovered = lstm_recover_from_timeout("nothing");
     TORCH_CHECK(!(d.B <= kPersistMaxB && (recovered || (fwd_epoch >= 0 && fwd_epoch != g_persist_epoch.load()))),
                 "hpc_rll LSTM backward: the forward pass of this graph ran on a persistent small-batch kernel around the time "
                 "one of them timed out; its saved activations may be invalid.  Run the forward pass again (it now uses the "
                 "step kernels).");
+    if (y_hseq.defined()) {
+        req(y_hseq, "y", d.dev, {d.S, d.B, d.H});
+        check(hpc_rll_lstm_backward_y(fptr(dy), fptr(dhn), fptr(dcn), fptr(x), fptr(h0), fptr(c0), fptr(wx), fptr(wh),
+                                      fptr(gamma), fptr(y_hseq), fmut(ws), fmut(g.dx), fmut(g.dh0), fmut(g.dc0), fmut(g.dwx),
+                                      fmut(g.dwh), fmut(g.dbias), fmut(g.dgamma), fmut(g.dbeta), (int)d.S, (int)d.B, (int)d.I,
+                                      (int)d.H, (int)d.L, (float)dropout, seed, stream_of(d.dev)),
+              "hpc_rll_lstm_backward_y");
+        return;
+    }
     check(hpc_rll_lstm_backward(fptr(dy), fptr(dhn), fptr(dcn), fptr(x), fptr(h0), fptr(c0), fptr(wx), fptr(wh),
                                 fptr(gamma), fmut(ws), fmut(g.dx), fmut(g.dh0), fmut(g.dc0), fmut(g.dwx), fmut(g.dwh),
                                 fmut(g.dbias), fmut(g.dgamma), fmut(g.dbeta), (int)d.S, (int)d.B, (int)d.I, (int)d.H,
@@ -201,26 +213,22 @@ void LstmBackward(const OptList& in, const OptList& out, double dropout, std::op
 struct LstmFn : public ag::Function<LstmFn> {
     static ag::tensor_list forward(ag::AutogradContext* ctx, const Tensor& x, const Tensor& wx, const Tensor& wh,
                                    const Tensor& bias, const Tensor& gamma, const Tensor& beta, const Tensor& h0,
-                                   const Tensor& c0, double dropout, int64_t seed, bool y_in_ws) {
+                                   const Tensor& c0, double dropout, int64_t seed, bool y_saved) {
         const LstmDims d = lstm_dims(x, h0, wx, wh);
         lstm_check_params(d, c0, bias, gamma, beta);
         c10::DeviceGuard g(d.dev);
         Tensor hn = new_f32({d.L, d.B, d.H}, d.dev), cn = new_f32({d.L, d.B, d.H}, d.dev);
         Tensor ws = new_f32({lstm_ws_floats(d, dropout)}, d.dev);
-        // Training: y is the last layer's h sequence where the cells wrote it -- a view of the workspace, which the graph
-        // keeps alive anyway (no (S,B,H) copy: 0.8 ms at C4; autograd refuses in-place writes to such
-        // an output view on the spot, so the saved workspace cannot be corrupted through y).  Without a graph y is its own tensor, so that it does not
-        // pin the workspace.
-        Tensor y;
-        if (y_in_ws && d.S > 0) {
-            const int64_t off = hpc_rll_lstm_workspace_y_offset((int)d.S, (int)d.B, (int)d.I, (int)d.H, (int)d.L, (float)dropout);
-            TORCH_CHECK(off >= 0, "lstm: workspace_y_offset failed");
-            y = ws.narrow(0, off, d.S * d.B * d.H).view({d.S, d.B, d.H});
-        } else {
-            y = new_f32({d.S, d.B, d.H}, d.dev);
-        }
-        lstm_forward_launch(d, x, h0, c0, wx, wh, bias, gamma, beta, y, hn, cn, ws, dropout, (uint64_t)seed);
-        ctx->save_for_backward({x, h0, c0, wx, wh, gamma, ws});
+        // y is its OWN (S,B,H) tensor in every mode (as a view of the saved workspace it pinned the whole
+        // workspace for any holder of y.detach() and made in-place ops on y raise).  With a graph it is at the same time the
+        // last layer's saved h sequence: the cells write it directly (no copy: 0.8 ms at C4), it is saved for the
+        // backward like any op output that its own derivative needs (exp, sigmoid, ...) -- an in-place update of y is
+        // allowed and caught by the version counter if (and only if) a backward through this node follows.
+        Tensor y = new_f32({d.S, d.B, d.H}, d.dev);
+        const bool y_hseq = y_saved && d.S > 0;
+        lstm_forward_launch(d, x, h0, c0, wx, wh, bias, gamma, beta, y, hn, cn, ws, dropout, (uint64_t)seed, y_hseq);
+        if (y_hseq) ctx->save_for_backward({x, h0, c0, wx, wh, gamma, ws, y});
+        else ctx->save_for_backward({x, h0, c0, wx, wh, gamma, ws});
         ctx->saved_data["dropout"] = dropout;
         ctx->saved_data["seed"] = seed;
         ctx->saved_data["bias_shape"] = bias.sizes().vec();
@@ -245,7 +253,7 @@ struct LstmFn : public ag::Function<LstmFn> {
         gr.dbeta = new_f32(ctx->saved_data["beta_shape"].toIntVector(), d.dev);
         lstm_backward_launch(d, cont(grads[0]), cont(grads[1]), cont(grads[2]), x, h0, c0, wx, wh, gamma, ws, gr,
                              ctx->saved_data["dropout"].toDouble(), (uint64_t)ctx->saved_data["seed"].toInt(),
-                             ctx->saved_data["persist_epoch"].toInt());
+                             ctx->saved_data["persist_epoch"].toInt(), s.size() > 7 ? s[7] : Tensor());
         return {gr.dx, gr.dwx, gr.dwh, gr.dbias, gr.dgamma, gr.dbeta, gr.dh0, gr.dc0, undef(), undef(), undef()};
     }
 };

@@ -64,8 +64,10 @@ class LSTM(nn.Module):
 
     def forward(self, inputs, prev_state):
         """inputs (S,B,input_size); prev_state None or (h0, c0) each (num_layers,B,H) -> (y (S,B,H), [h, c]).
-        When a graph is recorded, y is handed out where the last layer's cells wrote it (a view of the op's saved
-        workspace: no (S,B,H) copy); autograd refuses in-place writes to it -- use out-of-place ops on y."""
+        y is always the caller's own (S,B,H) tensor.  When a graph is recorded it is also the last layer's saved h
+        sequence (written by the cells directly, no (S,B,H) copy): like the output of ``exp`` or ``sigmoid`` it may be
+        modified in place only if no backward through this LSTM call follows (autograd's version counter raises
+        otherwise); holding ``y.detach()`` keeps S*B*H floats alive, not the op's workspace."""
         assert inputs.is_cuda
         if prev_state is None:
             zeros = torch.zeros(self.num_layers, inputs.shape[1], self.hidden_size, dtype=inputs.dtype,

@@ -286,6 +286,11 @@ int hpc_rll_sample_split_group(const int32_t* sizes, int n, int dim, int group, 
  *           and a STABLE radix sort of (length, row) -> order (n,) int64: order[p] = original row of sorted position p
  *           (ascending length, original order among equal lengths = python's sorted()).
  *           ws: hpc_rll_pad1d_group_workspace_int64(n, max_len, group) int64.  No host synchronisation.
+ *           Cost of the plan step: the histogram and the sort stream `lengths` (HBM-bound); the oracle policy
+ *           itself is a DP over the D <= max_len+1 DISTINCT lengths that runs in ONE workgroup, group * D^2 / 1024 steps of
+ *           ~10 ns: microseconds at configs[4] (D <= 96: len ~ U[32,128)), ~2 ms at D = 4096 with group = 8, ~0.25 s at the
+ *           limits D = 16385, group = 63 -- there the host's divide-and-conquer DP (hpc_rll_oracle_split_group on the
+ *           histogram's runs) is the faster route; the prefix scan of the sort is single-workgroup too: n <= 2^28.
  *   forward: all groups in ONE launch.  table = hpc_rll_packed_table rows of the ORIGINAL order; out / mask hold the
  *           groups back to back (group g: (cuts[g+1]-cuts[g]) rows of width[g] at offset[g]); total_out = offset[ng]. */
 int64_t hpc_rll_pad1d_group_workspace_int64(int64_t n, int max_len, int group);
@@ -330,6 +335,20 @@ int hpc_rll_lstm_backward(const float* dy, const float* dhn, const float* dcn, c
                           float* dx, float* dh0, float* dc0, float* dwx, float* dwh, float* dbias, float* dln_gamma,
                           float* dln_beta, int S, int B, int I, int H, int L, float dropout_p, uint64_t seed,
                           void* stream);
+/* ABI 4: the pair a framework binding uses.  y is the caller's own (S,B,H) tensor AND the last layer's saved h sequence
+ * (the reference keeps the same array in both roles: ym[L-1], rnn.py:27-31, read again by LstmBackward lstm.cu:352-370):
+ * the forward's cells write y directly -- no (S,B,H) copy and no view of the workspace handed out, so a holder of y pins
+ * S*B*H floats, not the workspace -- and the SAME y is passed to the backward, which reads the sequence from it.  y must
+ * not be modified in between (the binding's job to detect; torch's saved-tensor version counter does). */
+int hpc_rll_lstm_forward_y(const float* x, const float* h0, const float* c0, const float* wx, const float* wh,
+                           const float* bias, const float* ln_gamma, const float* ln_beta, float* y, float* hn,
+                           float* cn, float* ws, int S, int B, int I, int H, int L, float dropout_p, uint64_t seed,
+                           void* stream);
+int hpc_rll_lstm_backward_y(const float* dy, const float* dhn, const float* dcn, const float* x, const float* h0,
+                            const float* c0, const float* wx, const float* wh, const float* ln_gamma, const float* y,
+                            float* ws, float* dx, float* dh0, float* dc0, float* dwx, float* dwh, float* dbias,
+                            float* dln_gamma, float* dln_beta, int S, int B, int I, int H, int L, float dropout_p,
+                            uint64_t seed, void* stream);
 /* Asynchronous status of the persistent small-batch LSTM kernels (B <= 4).  Their workgroups exchange data through
  * memory and must all be resident at once; that is checked against the runtime's occupancy figure at dispatch and
  * launches of one process are serialised per device, but ANOTHER PROCESS holding compute units for seconds can still

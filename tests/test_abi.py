@@ -117,4 +117,4 @@ def test_c_program_links_and_runs(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and "abi 3 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    assert r.returncode == 0 and "abi 4 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)

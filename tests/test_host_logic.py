@@ -61,6 +61,58 @@ def test_sample_split_is_valid_and_seeded():
     assert U.sample_split_group(xs[:2], 3)[-1] == [0, 2]          # n = 2: the reference divides by zero here
 
 
+def _reference_sample_split(numels, group, seed):
+    """src/rl_utils/padding.cu:8-43 restated in python for sorted 1-D lists, with the library's splitmix64 stream in place of
+    C rand(): group-1 cuts in [1, N-2] (a cut equal to the PREVIOUS draw is re-drawn), sorted, N-1 appended; a cut whose
+    group has the same shape as the previous accepted group is skipped WITHOUT advancing last_idx.  (A repeated cut
+    position -- where the reference emits an empty group of shape -1 -- is dropped, as the library documents.)"""
+    mask = (1 << 64) - 1
+    n = len(numels)
+    cuts = []
+    if n >= 3:
+        last = -1
+        for _ in range(group - 1):
+            now = last
+            if n == 3:
+                now = 1
+            else:
+                while now == last:
+                    seed = (seed + 0x9E3779B97F4A7C15) & mask
+                    z = seed
+                    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+                    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+                    z ^= z >> 31
+                    now = z % (n - 2) + 1
+            cuts.append(now)
+            last = now
+        cuts.sort()
+    cuts.append(n - 1)
+    shapes, idxs, last_idx = [], [], -1
+    for idx in cuts:
+        if idx <= last_idx:
+            continue
+        shape = max(numels[last_idx + 1:idx + 1])
+        if shapes and shape == shapes[-1]:
+            continue
+        shapes.append(shape)
+        idxs.append(last_idx + 1)
+        last_idx = idx
+    idxs.append(n)
+    return shapes, idxs
+
+
+@pytest.mark.parametrize("n,group,seed", [(10, 4, 3), (200, 8, 11), (50, 16, 5), (3, 4, 1), (1000, 63, 7), (40, 6, 123456789)])
+def test_sample_split_mirrors_the_reference_rule(n, group, seed):
+    """same cuts -> same boundaries as the reference's loop, including its equal-shape skip (rows of a skipped
+    cut join the NEXT group).  Lengths from a small range, so that equal-shape neighbours are common."""
+    import hpc_rl_utils as U
+    rng = np.random.default_rng(n + group)
+    nl = sorted(int(v) for v in rng.integers(1, 9, n))
+    res = U.sample_split_group([torch.empty(v) for v in nl], group, seed)
+    shapes, idxs = _reference_sample_split(nl, group, seed)
+    assert res[-1] == idxs and [r[0] for r in res[:-1]] == shapes
+
+
 def test_large_list_is_fast():
     import time
     rng = np.random.default_rng(1)

@@ -229,9 +229,11 @@ def test_lstm_reference_usage_pattern():
 
 @pytest.mark.parametrize("S,B,I,H,L,p", [(12, 3, 40, 48, 3, 0.0), (8, 20, 36, 64, 2, 0.0), (6, 40, 32, 64, 2, 0.25)])
 def test_lstm_training_output_is_written_in_place(S, B, I, H, L, p):
-    """With a graph, y is the last layer's h sequence where the cells wrote it (a view of the workspace,
-    hpc_rll_lstm_workspace_y_offset): no (S,B,H) copy.  Without one, y is its own tensor (it must not pin the workspace).
-    Same bits both ways; an in-place write to y is refused by autograd (use an out-of-place op)."""
+    """With a graph, y is at the same time the last layer's saved h sequence: the cells write it directly (no (S,B,H)
+    copy; hpc_rll_lstm_forward_y / _backward_y).  It is the caller's OWN tensor in every mode: not a view,
+    its storage is exactly S*B*H floats (a rollout buffer holding y.detach() does not pin the workspace), in-place ops on
+    it work like on any op output -- and are caught by the saved-tensor version counter if a backward through the node
+    follows.  Same bits with and without a graph."""
     from hpc_rll.torch_utils.network.rnn import LSTM
     torch.manual_seed(5)
     m = LSTM(S, B, I, H, L, dropout=p).to(DEV)
@@ -241,16 +243,35 @@ def test_lstm_training_output_is_written_in_place(S, B, I, H, L, p):
     with torch.no_grad():
         torch.manual_seed(9)
         y0, (hn0, cn0) = m(x, None)
-    assert y._base is not None and y0._base is None
-    assert y0.untyped_storage().nbytes() == y0.numel() * 4 and y.untyped_storage().nbytes() > y.numel() * 4
+    for t in (y, y0):
+        assert t._base is None and t.untyped_storage().nbytes() == t.numel() * 4
     if p == 0.0:
         assert torch.equal(y, y0) and torch.equal(hn, hn0) and torch.equal(cn, cn0)
     assert torch.equal(y[-1], hn[-1])
+    keep = y.detach()                                        # what an actor's rollout buffer holds
     y.sum().backward()
     assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    gx = x.grad.clone()
+    assert keep.untyped_storage().nbytes() == S * B * H * 4
+    # in-place on the output: allowed (it raised when y was a view of the saved workspace) ...
+    torch.manual_seed(9)
     y2, _ = m(x, None)
-    with pytest.raises(RuntimeError, match="inplace"):      # refused on the spot: y is a view handed out by the node
-        y2.mul_(2.0)
+    y3 = y2 * 1.0
+    y2.detach().mul_(1.0)                                    # a no-op write through a detached alias bumps the version
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        y3.sum().backward()                                  # ... and the node notices that its saved sequence was touched
+    # an untouched graph still gives the same gradient (dropout: same seed)
+    x.grad = None
+    torch.manual_seed(9)
+    y4, _ = m(x, None)
+    y4.relu().sum().backward()
+    assert torch.isfinite(x.grad).all()
+    if p == 0.0:
+        x.grad = None
+        torch.manual_seed(9)
+        y5, _ = m(x, None)
+        y5.sum().backward()
+        assert torch.equal(x.grad, gx)
 
 
 @pytest.mark.parametrize("S,B,I,H,L", [(12, 3, 40, 48, 3), (10, 2, 24, 320, 2), (8, 20, 36, 64, 2)])   # wavefront / per-layer / step kernels
