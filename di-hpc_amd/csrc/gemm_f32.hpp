@@ -32,6 +32,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "wave.hpp"
+
 namespace hpc_rll {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -49,6 +51,8 @@ struct GemmArgs {
     int big = 0;       // 1: a long-K product that brings its own split-K (gemm_splitk_big): 128x128 tiles
     int xcd_swizzle = 0;   // set by launch_gemm_tile
     int prio = 0;          // 1: s_setprio(1) around the MFMA clusters (tune key 23 bit 0; experiment)
+    float* rowpart = nullptr;   // gemm_f32_nn_dma_kernel<., true>: per-row (mean, M2) of every 128-column block of C,
+                                // [N/128][M][2] -- LayerNorm partials out of the product's epilogue (lstm_block.hpp)
 };
 
 enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2, kDmaK = 3 };   // kDmaK: k-contiguous, staged by LDS-DMA (DmaStage)
@@ -636,8 +640,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_tn_dma_kernel(const GemmArgs 
 // feeds four steps of an m-block: a wave of 2 x 4 blocks = 64 (m) x 128 (n) issues 6 reads per 32 MFMAs.  Workgroup = 8
 // waves (4 along m x 2 along n) = 256 x 256, one per CU.  Same k order as the NT DMA kernels: bit-identical to them on the
 // same operands.
-template <bool PIPE>   // PIPE: three LDS buffers, the k-tile barrier between the two halves of a tile (see the loop): measured
+template <bool PIPE, bool ROWSTATS = false>   // PIPE: three LDS buffers, the k-tile barrier between the two halves of a tile (see the loop): measured
                        // 142.9 -> 144.0 TFLOP/s at 4096^3, 141.5 -> 141.9 on the C4 x-branch shape -- shipped: false
+                       // ROWSTATS: also write g.rowpart (single K slice, no accumulate)
 __global__ __launch_bounds__(512, 2) void gemm_f32_nn_dma_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 16, NTH = 512, NBUF = PIPE ? 3 : 2;
     __shared__ __attribute__((aligned(16))) float lds[NBUF * BK * BM + NBUF * BK * BN];
@@ -758,6 +763,27 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_nn_dma_kernel(const GemmArgs 
             if (g.accumulate) o += *reinterpret_cast<const gf4*>(p);
             *reinterpret_cast<gf4*>(p) = o;
         }
+    if constexpr (ROWSTATS) {
+        // a wave holds 64 rows x 128 columns: per row, the 32 lanes of a half wave sum their four columns -- mean, then M2
+        // around that mean (two passes over registers); lane i32 = 16 i + r keeps row (i, r) and writes it
+        float my_m = 0.f, my_d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sm = half_sum_all((acc[i][0][r] + acc[i][1][r]) + (acc[i][2][r] + acc[i][3][r]));
+                const float m = sm * (1.f / 128.f);
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d += (acc[i][j][r] - m) * (acc[i][j][r] - m);
+                d = half_sum_all(d);
+                if (i32 == 16 * i + r) { my_m = m; my_d = d; }
+            }
+        const int rr = i32 & 15;
+        const long m = m0 + wm * 64 + (i32 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        const int cb = blockIdx.x * 2 + wn;
+        *reinterpret_cast<gf2*>(g.rowpart + ((size_t)cb * g.M + m) * 2) = gf2{my_m, my_d};
+    }
 }
 
 inline bool gemm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -876,6 +902,18 @@ inline int gemm_splitk_big(int M, int N, int K) {
     int s = 1;
     while (s < 16 && tiles * s < g_gemm_big_target && ktiles / (s * 2) >= 16) s *= 2;
     return s;
+}
+
+// C = A B through gemm_f32_nn_dma_kernel with the LayerNorm row partials in the epilogue (g.rowpart).  The caller has checked
+// gemm_nn_rowstats_ok.
+inline bool gemm_nn_rowstats_ok(const GemmArgs& g) {
+    extern int g_gemm_dma;
+    return g_gemm_dma == 1 && g.M > 0 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 16 == 0 && g.K > 0 && g.a_sk == 1 &&
+           g.b_sn == 1 && (g.a_sm % 4) == 0 && (g.b_sk % 4) == 0 && (g.ldc % 4) == 0 && gemm_al16(g.A) && gemm_al16(g.B) &&
+           gemm_al16(g.C) && g.splitk <= 1 && !g.accumulate && g.rowpart && (reinterpret_cast<uintptr_t>(g.rowpart) & 7) == 0;
+}
+inline void launch_gemm_nn_rowstats(const GemmArgs& g, hipStream_t st) {
+    hipLaunchKernelGGL((gemm_f32_nn_dma_kernel<false, true>), dim3(g.N / 256, g.M / 256, 1), dim3(512), 0, st, g);
 }
 
 inline void launch_gemm(const GemmArgs& g, hipStream_t st) {

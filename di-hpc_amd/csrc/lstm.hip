@@ -20,6 +20,8 @@
 //     (the reference draws cuRAND numbers seeded from /dev/urandom: parity-unpinned, tests use dropout = 0).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "gemm_f32.hpp"
 #include "hpc_rll_hip.h"
 #include "wave.hpp"
@@ -75,6 +77,47 @@ __device__ __forceinline__ float gate_sigmoid(float a) { return 1.f / (1.f + exp
 // reads anyway (both pre-LayerNorm products, the row statistics, gamma) plus bias / beta, parked in the workspace by the
 // forward.  Shape-only predicate (forward and backward must agree, whatever the tuning knobs say).
 inline bool cell_recompute_gates(int B, int H) { return (long)B * H >= (1L << 19); }
+
+// Layout of the (rows, 4H) pre-activation tensors (xw, hw, dxw, dhw).  Standard: gate g of hidden unit u at column
+// g*H + u (the reference's, lstm_kernel.h:46-60).  GATE-INTERLEAVED (PERM; large batches, lstm_perm_shape): at column
+// 4*u + g, produced by multiplying with column-permuted weight copies -- a matrix-core lane of the NN kernels owns four
+// CONSECUTIVE output columns, so in this layout it owns the four gates of one unit and the cell can run in the product's
+// own epilogue (lstm_block.hpp).  LayerNorm over a row does not care about the column order.  Four consecutive units x
+// four gates are one 16-byte access per gate (standard) or per unit (interleaved: 64 contiguous bytes, a 4x4 transpose in
+// registers).
+inline bool lstm_perm_shape(int B, int H) {
+    return cell_recompute_gates(B, H) && H % 64 == 0 && H >= 768 && H <= 1024 && B % 256 == 0 && B >= 4096;
+}
+template <bool PERM, bool NT>
+__device__ __forceinline__ void load_gq(const float* row, int H, int u0, vfloat4 (&v)[4]) {
+    if (PERM) {
+        vfloat4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = ld<NT>(reinterpret_cast<const vfloat4*>(row + 4 * (u0 + i)));
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[g][i] = t[i][g];
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = ld<NT>(reinterpret_cast<const vfloat4*>(row + g * H + u0));
+    }
+}
+template <bool PERM, bool NT>
+__device__ __forceinline__ void store_gq(float* row, int H, int u0, const vfloat4 (&v)[4]) {
+    if (PERM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vfloat4 t;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t[g] = v[g][i];
+            st<NT>(reinterpret_cast<vfloat4*>(row + 4 * (u0 + i)), t);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st<NT>(reinterpret_cast<vfloat4*>(row + g * H + u0), v[g]);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ forward cell
 // one workgroup per batch row; thread t owns hidden units j = t, t+256, ... (JPT of them) x 4 gates x 2 branches.
@@ -211,7 +254,7 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
 // accesses (the scalar kernel ran at 4.2 TB/s at the C4 shape; a streaming read reaches 7).  Same arithmetic, same
 // summation order inside a thread up to the unit mapping; the block sums are order-insensitive to fp32 rounding only
 // within the usual 1e-7.
-template <int NQ>
+template <int NQ, bool PERM = false>
 __global__ __launch_bounds__(256) void lstm_cell_fwd4_kernel(
     const float* __restrict__ xw, const float* hw, int nsplit, long part_stride, float* hw_out,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -227,10 +270,12 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd4_kernel(
 #pragma unroll
     for (int qq = 0; qq < NQ; ++qq) {
         const int u0 = ((int)threadIdx.x + qq * 256) * 4;
+        if (u0 < H) {
+            load_gq<PERM, true>(xr, H, u0, x[qq]);
+            load_gq<PERM, false>(hr, H, u0, h[qq]);
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            x[qq][g] = (u0 < H) ? __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(xr + g * H + u0)) : zero4;
-            h[qq][g] = (u0 < H) ? *reinterpret_cast<const vfloat4*>(hr + g * H + u0) : zero4;
+            for (int g = 0; g < 4; ++g) x[qq][g] = h[qq][g] = zero4;
         }
     }
     for (int z = 1; z < nsplit; ++z) {   // split-K partials, in slice order
@@ -238,9 +283,11 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd4_kernel(
 #pragma unroll
         for (int qq = 0; qq < NQ; ++qq) {
             const int u0 = ((int)threadIdx.x + qq * 256) * 4;
+            if (u0 < H) load_gq<PERM, false>(hr + (size_t)z * part_stride, H, u0, p[qq]);
+            else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                p[qq][g] = (u0 < H) ? *reinterpret_cast<const vfloat4*>(hr + (size_t)z * part_stride + g * H + u0) : zero4;
+                for (int g = 0; g < 4; ++g) p[qq][g] = zero4;
+            }
         }
 #pragma unroll
         for (int qq = 0; qq < NQ; ++qq)
@@ -251,9 +298,9 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd4_kernel(
 #pragma unroll
     for (int qq = 0; qq < NQ; ++qq) {
         const int u0 = ((int)threadIdx.x + qq * 256) * 4;
+        if (nsplit > 1 && u0 < H) store_gq<PERM, false>(hw_out + (size_t)b * G, H, u0, h[qq]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (nsplit > 1 && u0 < H) *reinterpret_cast<vfloat4*>(hw_out + (size_t)b * G + g * H + u0) = h[qq][g];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 s[0] += x[qq][g][i];
@@ -446,7 +493,7 @@ template <int NQ, bool SAVED /* gates are loaded, not recomputed */> struct Cell
     vfloat4 xv[NQ][4], hv[NQ][4], gv[SAVED ? NQ : 1][SAVED ? 4 : 1], cn[NQ], cp[NQ], dci[NQ], dh[NQ];
     float mx, rx, mh, rh;
 };
-template <int NQ, bool SAVED>
+template <int NQ, bool SAVED, bool PERM = false>
 __device__ __forceinline__ void cell_bwd4_load(const CellBwdArgs& a, int b, CellBwdRow<NQ, SAVED>& r) {
     const int H = a.H, G = 4 * H;
     const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -458,12 +505,11 @@ __device__ __forceinline__ void cell_bwd4_load(const CellBwdArgs& a, int b, Cell
         const int uu = u0 < H ? u0 : 0;   // idle quads re-read quad 0 (no divergent branch around a load), results unused
         const size_t o = (size_t)b * H + uu;
         const size_t og0 = (size_t)b * G + uu;
+        load_gq<PERM, true>(a.xw + (size_t)b * G, H, uu, r.xv[qq]);
+        load_gq<PERM, true>(a.hw + (size_t)b * G, H, uu, r.hv[qq]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            r.xv[qq][g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.xw + og0 + g * H));
-            r.hv[qq][g] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.hw + og0 + g * H));
+        for (int g = 0; g < 4; ++g)
             if (SAVED) r.gv[SAVED ? qq : 0][SAVED ? g : 0] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.gates + og0 + g * H));
-        }
         r.cn[qq] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.c_new + o));
         r.cp[qq] = *reinterpret_cast<const vfloat4*>(a.c_prev + o);
         r.dci[qq] = a.dc_in ? *reinterpret_cast<const vfloat4*>(a.dc_in + o) : zero4;
@@ -473,7 +519,7 @@ __device__ __forceinline__ void cell_bwd4_load(const CellBwdArgs& a, int b, Cell
 // ACC: instead of storing the gate adjoint `da` for a later column-reduction pass over (S*B, 4H), the workgroup adds
 // da, da*xhat_x, da*xhat_h of its row to per-column accumulators in LDS (`acc`, 3 x 4H floats, every column owned by
 // exactly one thread: no synchronisation) -- see lstm_cell_bwd4_rows_kernel.
-template <int NQ, bool SAVED, bool ACC>
+template <int NQ, bool SAVED, bool ACC, bool PERM = false>
 __device__ __forceinline__ void cell_bwd4_compute(const CellBwdArgs& a, int b, const CellBwdRow<NQ, SAVED>& r, float* red,
                                                   float* acc) {
     const int H = a.H, G = 4 * H;
@@ -569,21 +615,20 @@ __device__ __forceinline__ void cell_bwd4_compute(const CellBwdArgs& a, int b, c
     for (int qq = 0; qq < NQ; ++qq) {
         const int u0 = ((int)threadIdx.x + qq * 256) * 4;
         if (u0 >= H) continue;
-        const size_t og0 = (size_t)b * G + u0;
+        vfloat4 ox[4], oh[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const vfloat4 gxv = *reinterpret_cast<const vfloat4*>(a.gamma + g * H + u0);
             const vfloat4 ghv = *reinterpret_cast<const vfloat4*>(a.gamma + G + g * H + u0);
-            vfloat4 ox, oh;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float dyx = da[qq][g][i] * gxv[i], dyh = da[qq][g][i] * ghv[i];
-                ox[i] = rx * (dyx - a0 - (r.xv[qq][g][i] - mx) * rx * a1);
-                oh[i] = rh * (dyh - a2 - (r.hv[qq][g][i] - mh) * rh * a3);
+                ox[g][i] = rx * (dyx - a0 - (r.xv[qq][g][i] - mx) * rx * a1);
+                oh[g][i] = rh * (dyh - a2 - (r.hv[qq][g][i] - mh) * rh * a3);
             }
-            __builtin_nontemporal_store(ox, reinterpret_cast<vfloat4*>(a.dxw + og0 + g * H));
-            *reinterpret_cast<vfloat4*>(a.dhw + og0 + g * H) = oh;   // read next by this step's dh product: keep it cached
         }
+        store_gq<PERM, true>(a.dxw + (size_t)b * G, H, u0, ox);
+        store_gq<PERM, false>(a.dhw + (size_t)b * G, H, u0, oh);   // read next by this step's dh product: keep it cached
     }
 }
 
@@ -607,6 +652,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd4_kernel(const CellBwdArgs a
 // and spills (147.3).  At B = 1024..2048 the row walk loses 2-3 % (too few rows per workgroup to pay for the
 // accumulator round trip), so it starts at 8 rows per workgroup; B = 8192: H = 1024 36.2 -> 35.5 ms (S = 16), H = 512
 // 43.1 -> 43.5 (S = 32, L = 2), so it starts at H = 768.
+template <bool PERM>
 __global__ __launch_bounds__(256) void lstm_cell_bwd4_rows_kernel(const CellBwdArgs a, float* __restrict__ colacc,
                                                                   int acc_init, int B) {
     __shared__ float red[16];
@@ -620,8 +666,8 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd4_rows_kernel(const CellBwdA
     __syncthreads();   // (the owner of a column in the row function is another thread than here unless H % 256 == 0)
     for (int b = r0; b < r1; ++b) {
         CellBwdRow<1, false> r;   // (this path always recomputes the gates: cell_rows_shape)
-        cell_bwd4_load<1, false>(a, b, r);
-        cell_bwd4_compute<1, false, true>(a, b, r, red, acc);
+        cell_bwd4_load<1, false, PERM>(a, b, r);
+        cell_bwd4_compute<1, false, true, PERM>(a, b, r, red, acc);
     }
     __syncthreads();
     for (int i = threadIdx.x * 4; i < 3 * G; i += 1024)
@@ -727,6 +773,33 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
     out[i] = s;
 }
 
+// out[r, 4u + g] = in[r, g*H + u]: the gate-interleaved copy of a (rows, 4H) weight (lstm_perm_shape).  One thread per
+// output quad = the four gates of one unit: four 4-byte gathers, one 16-byte store.
+__global__ __launch_bounds__(256) void perm_cols_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int H) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= rows * H) return;
+    const long r = q / H;
+    const int u = (int)(q - r * H);
+    const float* p = in + r * 4 * H + u;
+    *reinterpret_cast<vfloat4*>(out + r * 4 * H + 4 * u) = vfloat4{p[0], p[H], p[2 * (long)H], p[3 * (long)H]};
+}
+inline void launch_perm_cols(const float* in, float* out, long rows, int H, hipStream_t st) {
+    hipLaunchKernelGGL(perm_cols_kernel, dim3((unsigned)((rows * H + 255) / 256)), dim3(256), 0, st, in, out, rows, H);
+}
+// out[r, g*H + u] = sum_z parts[z*n + r*4H + 4u + g]  (fixed order): the split-K summation of a weight gradient computed in
+// the gate-interleaved layout, written back in the standard one.  One thread per interleaved quad.
+__global__ __launch_bounds__(256) void sum_parts_unperm_kernel(const float* __restrict__ parts, int nparts, long n, long rows,
+                                                               int H, float* __restrict__ out) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= rows * H) return;
+    const long r = q / H;
+    const int u = (int)(q - r * H);
+    vfloat4 s = *reinterpret_cast<const vfloat4*>(parts + r * 4 * H + 4 * u);
+    for (int z = 1; z < nparts; ++z) s += *reinterpret_cast<const vfloat4*>(parts + (size_t)z * n + r * 4 * H + 4 * u);
+    float* o = out + r * 4 * H + u;
+    o[0] = s.x; o[H] = s.y; o[2 * (long)H] = s.z; o[3 * (long)H] = s.w;
+}
+
 template <class... Args>
 inline void launch_cell_fwd_scalar(int H, int B, hipStream_t st, Args... a) {
     const int jpt = (H + 255) / 256;
@@ -739,8 +812,13 @@ inline bool cell_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline void launch_cell_fwd(int H, int B, hipStream_t st, const float* xw, const float* hw, int nsplit, long part_stride,
                             float* hw_out, const float* bias, const float* gamma, const float* beta, const float* c_prev,
-                            float* gates, float* c_out, float* h_out, float* stats) {
+                            float* gates, float* c_out, float* h_out, float* stats, bool perm = false) {
     const int jpt = (H + 255) / 256;
+    if (perm) {   // gate-interleaved pre-activations (lstm_perm_shape: H % 64 == 0, H <= 1024, workspace tensors 16-byte aligned)
+        hipLaunchKernelGGL((lstm_cell_fwd4_kernel<1, true>), dim3(B), dim3(256), 0, st, xw, hw, nsplit, part_stride, hw_out, bias,
+                           gamma, beta, c_prev, gates, c_out, h_out, stats, H);
+        return;
+    }
     if (g_cell_vec4 && jpt >= g_cell_vec4 && (H % 4) == 0 && (part_stride % 4) == 0 && cell_al16(xw) && cell_al16(hw) &&
         cell_al16(hw_out) && cell_al16(bias) && cell_al16(gamma) && cell_al16(beta) && cell_al16(c_prev) &&
         cell_al16(gates) && cell_al16(c_out) && cell_al16(h_out)) {
@@ -785,15 +863,18 @@ constexpr int kCellRowsMaxWgs = 1024;
 inline bool cell_rows_shape(int B, int H) {
     return cell_recompute_gates(B, H) && H % 4 == 0 && H >= 768 && H <= 1024 && g_cell_rows_wgs > 0 && B >= 8 * g_cell_rows_wgs;
 }
-inline void launch_cell_bwd_rows(int B, int nwg, hipStream_t st, const CellBwdArgs& a, float* colacc, int acc_init) {
+inline void launch_cell_bwd_rows(int B, int nwg, hipStream_t st, const CellBwdArgs& a, float* colacc, int acc_init,
+                                 bool perm = false) {
     const size_t lds = (size_t)3 * 4 * a.H * sizeof(float);
-    hipLaunchKernelGGL(lstm_cell_bwd4_rows_kernel, dim3(nwg), dim3(256), lds, st, a, colacc, acc_init, B);
+    if (perm) hipLaunchKernelGGL(lstm_cell_bwd4_rows_kernel<true>, dim3(nwg), dim3(256), lds, st, a, colacc, acc_init, B);
+    else hipLaunchKernelGGL(lstm_cell_bwd4_rows_kernel<false>, dim3(nwg), dim3(256), lds, st, a, colacc, acc_init, B);
 }
 
 }  // namespace
 }  // namespace hpc_rll
 #include "lstm_persist.hpp"
 #include "lstm_wave.hpp"
+#include "lstm_block.hpp"
 namespace hpc_rll {
 namespace {
 
@@ -803,6 +884,7 @@ struct Ws {
     LayerWs layer[16];
     float *pstash;   // bias (L,4H) then ln_beta (L,2,4H), parked by the forward for a gate-recomputing backward
     float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg, *wpart, *dwave, *whT, *wxT;
+    float *whP, *wxP, *blk_part, *blk_flags;   // gate-interleaved weight copies, row-block exchange (lstm_perm_shape only)
     size_t total;
 };
 inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
@@ -835,6 +917,11 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.colpart = take((size_t)(kCellRowsMaxWgs > kColChunks ? kCellRowsMaxWgs : kColChunks) * 3 * G);
     w.whT = take((size_t)H * G);                          // Wh^T of the layer being processed (backward)
     w.wxT = take((size_t)(I > H ? I : H) * G);            // Wx^T of that layer
+    const bool perm = lstm_perm_shape(B, H);
+    w.whP = take(perm ? (size_t)H * G : 0);
+    w.wxP = take(perm ? (size_t)(I > H ? I : H) * G : 0);
+    w.blk_part = take(perm ? block_part_floats(B, H) : 0);
+    w.blk_flags = take(perm ? block_flag_words(B) : 0);
     {   // persistent small-batch paths: {value, tag} exchange words (per-layer kernels / layer wavefront)
         size_t words = xchg_layout(B, H).total_words;
         WaveCfg wc{};
@@ -856,6 +943,9 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
             const int skf = gemm_splitk((int)SB, (int)G, in_l), skd = gemm_splitk((int)SB, in_l, (int)G);
             if (skf > 1 && (size_t)skf * SB * G > need) need = (size_t)skf * SB * G;
             if (skd > 1 && (size_t)skd * SB * in_l > need) need = (size_t)skd * SB * in_l;
+            // gate-interleaved layers compute dWx / dWh into this buffer even without split-K (un-permuted on the way out)
+            if (perm && (size_t)in_l * G > need) need = (size_t)in_l * G;
+            if (perm && (size_t)H * G > need) need = (size_t)H * G;
         }
         w.wpart = take(need);
     }
@@ -886,6 +976,7 @@ extern "C" int64_t hpc_rll_lstm_workspace_y_offset(int S, int B, int I, int H, i
 }
 
 namespace hpc_rll { namespace {
+std::atomic<int> g_lstm_last_path{-1};   // hpc_rll_lstm_last_forward_path (diagnostic)
 // y_hseq: y doubles as the last layer's h sequence (the caller hands the SAME y to the backward, which reads it there):
 // the cells write y directly, the workspace's own slot for it stays unused, no (S,B,H) copy.
 int lstm_forward_impl(const float* x, const float* h0, const float* c0, const float* wx,
@@ -910,6 +1001,7 @@ int lstm_forward_impl(const float* x, const float* h0, const float* c0, const fl
     size_t wx_off = 0;
     WaveCfg wc{};
     const bool wave = S > 0 && wave_fwd_ok(S, B, H, L, &wc, st);
+    g_lstm_last_path.store(wave ? 2 : 0, std::memory_order_relaxed);
     // (the layer wavefront addresses every layer's buffers with one stride: it keeps its h sequences in the workspace and
     // y is filled by the copy at the end -- a few KB at B <= 4)
     if (y_hseq && !wave && S > 0) w.layer[L - 1].hseq = y;
@@ -953,7 +1045,71 @@ int lstm_forward_impl(const float* x, const float* h0, const float* c0, const fl
     const bool persist = S > 0 && persist_cfg(B, H, H, &pc) && persist_fwd_ok(pc, st);
     const XchgLayout xl = xchg_layout(B, H);
     if (persist && hipMemsetAsync(w.xchg, 0, xl.total_words * sizeof(u64), st) != hipSuccess) return last_error();
-    for (int l = 0; l < L; ++l) {
+    // Large batches keep xw / hw in the gate-interleaved layout (shape-only: the backward must agree) and, when the
+    // device can hold a row block's workgroups co-resident, run the recurrence in ONE persistent kernel per layer
+    const bool perm = S > 0 && lstm_perm_shape(B, H);
+    if (perm && !(cell_al16(x) && cell_al16(h0) && cell_al16(c0) && cell_al16(wx) && cell_al16(wh) && cell_al16(bias) &&
+                  cell_al16(ln_gamma) && cell_al16(ln_beta) && cell_al16(y) && cell_al16(hn) && cell_al16(cn) && cell_al16(ws) &&
+                  I % 4 == 0))
+        return HPC_RLL_EALIGN;   // these shapes run 16-byte kernels only
+    const bool block = perm && block_fwd_ok(B, H, st);
+    if (persist) g_lstm_last_path.store(1, std::memory_order_relaxed);
+    if (perm) g_lstm_last_path.store(block ? 4 : 3, std::memory_order_relaxed);
+    for (int l = 0; l < L && perm; ++l) {
+        const int in_l = l == 0 ? I : H;
+        const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
+        const float* wx_l = wx + wx_off;
+        const float* wh_l = wh + (size_t)l * H * G;
+        const LayerWs& lw = w.layer[l];
+        launch_perm_cols(wx_l, w.wxP, in_l, H, st);
+        launch_perm_cols(wh_l, w.whP, H, H, st);
+        {   // x-branch product against the interleaved copy; for the row-block kernel with the LayerNorm partials in its epilogue
+            GemmArgs g{xin, w.wxP, lw.xw, (int)SB, (int)G, in_l, in_l, 1, (long)G, 1, (long)G, 0};
+            g.rowpart = lw.hw;   // (free until the recurrence writes it: 2 * S*B * 4H/128 floats of it are borrowed)
+            if (block && gemm_nn_rowstats_ok(g)) {
+                launch_gemm_nn_rowstats(g, st);
+                hipLaunchKernelGGL(lstm_xstats_kernel, dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)lw.hw, (int)(G / 128), (long)SB, lw.stats);
+            } else {
+                g.rowpart = nullptr;
+                launch_gemm(g, st);
+                if (block)
+                    hipLaunchKernelGGL(lstm_rowstats_kernel, dim3((unsigned)SB), dim3(256), 0, st, (const float*)lw.xw, (int)G,
+                                       lw.stats);
+            }
+        }
+        if (block) {
+            BlockFwd a{lw.xw, w.whP, bias + (size_t)l * G, ln_gamma + (size_t)l * 2 * G, ln_beta + (size_t)l * 2 * G,
+                       h0 + (size_t)l * BH, c0 + (size_t)l * BH, lw.hw, lw.c, lw.hseq, lw.stats, nullptr, nullptr, S, B, H, 0, 0, 0};
+            const int brc = launch_block_fwd(a, w.blk_part, reinterpret_cast<unsigned*>(w.blk_flags), st);
+            if (brc) return brc;
+        }
+        for (int s = 0; s < S && !block; ++s) {
+            const float* h_prev = s == 0 ? h0 + (size_t)l * BH : lw.hseq + (size_t)(s - 1) * BH;
+            const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
+            float* hw_s = lw.hw + (size_t)s * B * G;
+            GemmArgs g{h_prev, w.whP, hw_s, B, (int)G, H, H, 1, (long)G, 1, (long)G, 0};
+            launch_gemm(g, st);
+            launch_cell_fwd(H, B, st, (const float*)(lw.xw + (size_t)s * B * G), (const float*)hw_s, 1, (long)((size_t)B * G),
+                            hw_s, bias + (size_t)l * G, ln_gamma + (size_t)l * 2 * G, ln_beta + (size_t)l * 2 * G, c_prev,
+                            (float*)nullptr, lw.c + (size_t)s * BH, lw.hseq + (size_t)s * BH, lw.stats + (size_t)s * B * 4,
+                            true);
+        }
+        int rc = last_error();
+        if (rc) return rc;
+        if ((rc = copy_async(hn + (size_t)l * BH, lw.hseq + (size_t)(S - 1) * BH, BH, st))) return rc;
+        if ((rc = copy_async(cn + (size_t)l * BH, lw.c + (size_t)(S - 1) * BH, BH, st))) return rc;
+        if (dropout_p > 0.f && l < L - 1) {
+            const long n = (long)(SB * H);
+            long blocks = (n + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)lw.hseq,
+                               lw.xin_next, n, seed + 0x1000003ull * (uint64_t)(l + 1),
+                               (uint32_t)((double)dropout_p * 4294967295.0), 1.f / (1.f - dropout_p));
+        }
+        wx_off += (size_t)in_l * G;
+    }
+    for (int l = 0; l < L && !perm; ++l) {
         const int in_l = l == 0 ? I : H;
         const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
         const float* wx_l = wx + wx_off;
@@ -1055,39 +1211,54 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
     const bool persist = persist_cfg(B, H, 4 * H, &pc) && persist_bwd_ok(pc, st);
     const XchgLayout xl = xchg_layout(B, H);
     if (persist && hipMemsetAsync(w.xchg, 0, xl.total_words * sizeof(u64), st) != hipSuccess) return last_error();
+    // gate-interleaved xw / hw (what the forward wrote at these shapes): dxw / dhw come out interleaved too, the products run
+    // against the interleaved weight copies, the weight gradients are un-permuted by their split-K summation
+    const bool perm = lstm_perm_shape(B, H);
+    if (perm && !(cell_al16(dy) && cell_al16(dhn) && cell_al16(dcn) && cell_al16(x) && cell_al16(h0) && cell_al16(c0) &&
+                  cell_al16(wx) && cell_al16(wh) && cell_al16(ln_gamma) && cell_al16(ws) && cell_al16(dx) && cell_al16(dh0) &&
+                  cell_al16(dc0) && cell_al16(dwx) && cell_al16(dwh) && cell_al16(y_ext) && I % 4 == 0))
+        return HPC_RLL_EALIGN;
     // weight / parameter gradients of layer l from its gate-gradient buffers, and (if `dxin`) d(layer input)
     auto layer_grads = [&](int l, const float* p_dgate, const float* p_dxw, const float* p_dhw, float* dxin,
                            int summed_chunks = 0 /* > 0: colpart already holds that many rows of column sums */) {
         const int in_l = l == 0 ? I : H;
         const LayerWs& lw = w.layer[l];
         const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
-        const float* wx_l = wx + wx_offs[l];
+        const float* wx_l = perm ? (const float*)w.wxP : wx + wx_offs[l];   // (interleaved copy made by the caller below)
         // dWh (H,G) = [h0 ; hseq[0..S-2]]^T @ dHW ; dWx (in,G) = xin^T @ dXW.  K = S*B is long and the output tiles
         // alone may not fill the chip: slices of K go to partial buffers, summed in slice order (deterministic).
+        // (perm: the products come out gate-interleaved; always via the partial buffer, un-permuted by the summation)
         {
             const size_t HG = (size_t)H * G;
             const int skh = S > 1 ? gemm_splitk_big(H, (int)G, (int)((S - 1) * (size_t)B)) : 1;
             float* dwh_l = dwh + (size_t)l * HG;
-            GemmArgs g0{h0 + (size_t)l * BH, p_dhw, skh > 1 ? w.wpart : dwh_l, H, (int)G, B, 1, (long)H, (long)G, 1,
-                        (long)G, 0};
+            float* first = (skh > 1 || perm) ? w.wpart : dwh_l;
+            GemmArgs g0{h0 + (size_t)l * BH, p_dhw, first, H, (int)G, B, 1, (long)H, (long)G, 1, (long)G, 0};
             launch_gemm(g0, st);
             if (S > 1) {
-                GemmArgs g1{lw.hseq, p_dhw + (size_t)B * G, skh > 1 ? w.wpart + HG : dwh_l, H, (int)G,
+                GemmArgs g1{lw.hseq, p_dhw + (size_t)B * G, skh > 1 ? w.wpart + HG : first, H, (int)G,
                             (int)((S - 1) * (size_t)B), 1, (long)H, (long)G, 1, (long)G, skh > 1 ? 0 : 1, skh,
                             (long)HG, 1};
                 launch_gemm(g1, st);
             }
-            if (skh > 1)
+            const int nparts = skh > 1 ? skh + 1 : 1;
+            if (perm)
+                hipLaunchKernelGGL(sum_parts_unperm_kernel, dim3((unsigned)(((size_t)H * H + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, nparts, (long)HG, (long)H, H, dwh_l);
+            else if (skh > 1)
                 hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((HG + 255) / 256)), dim3(256), 0, st,
                                    (const float*)w.wpart, skh + 1, (long)HG, dwh_l);
         }
         {
             const size_t IG = (size_t)in_l * G;
             const int skx = gemm_splitk_big(in_l, (int)G, (int)SB);
-            GemmArgs g{xin, p_dxw, skx > 1 ? w.wpart : dwx + wx_offs[l], in_l, (int)G, (int)SB, 1, (long)in_l, (long)G, 1,
-                       (long)G, 0, skx, (long)IG, 1};
+            GemmArgs g{xin, p_dxw, (skx > 1 || perm) ? w.wpart : dwx + wx_offs[l], in_l, (int)G, (int)SB, 1, (long)in_l,
+                       (long)G, 1, (long)G, 0, skx, (long)IG, 1};
             launch_gemm(g, st);
-            if (skx > 1)
+            if (perm)
+                hipLaunchKernelGGL(sum_parts_unperm_kernel, dim3((unsigned)(((size_t)in_l * H + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)w.wpart, skx > 1 ? skx : 1, (long)IG, (long)in_l, H, dwx + wx_offs[l]);
+            else if (skx > 1)
                 hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((IG + 255) / 256)), dim3(256), 0, st,
                                    (const float*)w.wpart, skx, (long)IG, dwx + wx_offs[l]);
         }
@@ -1145,7 +1316,11 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
     }
     for (int l = L - 1; l >= 0; --l) {
         const LayerWs& lw = w.layer[l];
-        const float* wh_l = wh + (size_t)l * H * G;
+        if (perm) {   // this layer's interleaved weight copies (the forward's were overwritten by the layers above)
+            launch_perm_cols(wh + (size_t)l * H * G, w.whP, H, H, st);
+            launch_perm_cols(wx + wx_offs[l], w.wxP, l == 0 ? I : H, H, st);
+        }
+        const float* wh_l = perm ? (const float*)w.whP : wh + (size_t)l * H * G;
         const float* gamma_l = ln_gamma + (size_t)l * 2 * G;
         const float* dh_carry = dhn ? dhn + (size_t)l * BH : nullptr;
         const float* dc_carry = dcn ? dcn + (size_t)l * BH : nullptr;
@@ -1168,7 +1343,8 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
         if (!persist && nn_dh) launch_transpose(wh_l, w.whT, H, (int)G, st);   // (H, G) -> (G, H): B(k=g, n=h) = whT[g*H + h]
         // large batches: the cell walks several rows per workgroup and keeps the bias / gamma / beta column sums (no
         // dgate buffer, no reduction pass) -- 16-byte accesses, so every base pointer must be 16-byte aligned
-        const int rows_wgs = (!persist && cell_rows_shape(B, H) && cell_al16(d_out) &&
+        const int rows_wgs = perm ? (g_cell_rows_wgs > 0 ? g_cell_rows_wgs : 512)   // (the only cell of this layout)
+                             : (!persist && cell_rows_shape(B, H) && cell_al16(d_out) &&
                               cell_al16(dhn) && cell_al16(dcn) && cell_al16(c0) && cell_al16(ws) && cell_al16(ln_gamma))
                                  ? (B < g_cell_rows_wgs ? B : g_cell_rows_wgs) : 0;
         for (int s = S - 1; s >= 0 && !persist; --s) {
@@ -1179,7 +1355,7 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
                                  lw.stats + (size_t)s * B * 4, gamma_l, w.pstash + (size_t)L * G + (size_t)l * 2 * G,
                                  w.pstash + (size_t)l * G, w.dgate + (size_t)s * B * G, w.dxw + (size_t)s * B * G,
                                  w.dhw + (size_t)s * B * G, w.dc, H};
-            if (rows_wgs) launch_cell_bwd_rows(B, rows_wgs, st, ca, w.colpart, s == S - 1 ? 1 : 0);
+            if (rows_wgs) launch_cell_bwd_rows(B, rows_wgs, st, ca, w.colpart, s == S - 1 ? 1 : 0, perm);
             else launch_cell_bwd(B, st, ca);
             // dh_prev (B,H) = dHW_s (B,G) @ Wh^T, as an NN product against the transposed copy
             GemmArgs g{w.dhw + (size_t)s * B * G, nn_dh ? (const float*)w.whT : wh_l, w.dh, B, H, (int)G, (long)G, 1,
@@ -1232,6 +1408,12 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
     return lstm_backward_impl(dy, dhn, dcn, x, h0, c0, wx, wh, ln_gamma, nullptr, ws, dx, dh0, dc0, dwx, dwh, dbias, dln_gamma,
                               dln_beta, S, B, I, H, L, dropout_p, seed, stream);
 }
+// Which kernels the most recent hpc_rll_lstm_forward* call of this process ran its recurrence on (a diagnostic, like
+// hpc_rll_gae_last_config): 0 = one product + one cell launch per step, 1 = per-layer persistent kernels (B <= 4),
+// 2 = layer wavefront (B <= 4, L >= 2), 3 = step kernels on gate-interleaved pre-activations (large batch), 4 = persistent
+// row-block kernel (large batch, lstm_block.hpp); -1 = no forward yet.
+extern "C" int hpc_rll_lstm_last_forward_path(void) { return g_lstm_last_path.load(std::memory_order_relaxed); }
+
 // The pair a framework binding uses (ABI 4): y is the caller's own (S,B,H) tensor AND the last layer's saved h sequence.
 // The forward's cells write it directly (no copy, nothing of the workspace is handed out), the backward gets the same y
 // back.  A holder of y pins S*B*H floats, not the workspace; modifying y between the two calls invalidates the backward

@@ -658,7 +658,9 @@ inline bool persist_runtime_ready(hipStream_t st) {
     return true;
 }
 // Does the runtime itself say that `blocks` workgroups of kernel `k` (256 threads, `lds` bytes) fit the device at once?
-template <class K> inline bool persist_resident(K k, int blocks, size_t lds) {
+template <class K> inline bool persist_resident_t(K k, int threads, int blocks, size_t lds);
+template <class K> inline bool persist_resident(K k, int blocks, size_t lds) { return persist_resident_t(k, 256, blocks, lds); }
+template <class K> inline bool persist_resident_t(K k, int threads, int blocks, size_t lds) {
     const int dev = persist_device();
     const int cus = persist_cu_count();
     if (dev < 0 || cus <= 0) return false;
@@ -675,7 +677,7 @@ template <class K> inline bool persist_resident(K k, int blocks, size_t lds) {
         return false;
     }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
     std::lock_guard<std::mutex> lk(r.mu);
     r.occupancy[key] = per_cu;
     return (long)per_cu * cus >= blocks;

@@ -90,6 +90,15 @@ __device__ __forceinline__ float group_sum_last(float x) {
     if (GL >= 64) x = dpp_add<0x143, 0xC>(x);   // row_bcast:31 -> row 3 holds the wave total
     return x;
 }
+// Sum over the 32 lanes of a HALF wave (lanes sharing lane >> 5 -- the column index of a 32x32 matrix-core block);
+// every lane of the half gets the total.  Four DPP steps (16-lane row sums in every lane) + one cross-row exchange.
+__device__ __forceinline__ float half_sum_all(float x) {
+    x = dpp_add<0xB1, 0xF>(x);    // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E, 0xF>(x);    // quad_perm [2,3,0,1]
+    x = dpp_add<0x141, 0xF>(x);   // row_half_mirror
+    x = dpp_add<0x140, 0xF>(x);   // row_mirror
+    return x + __shfl_xor(x, 16, 64);
+}
 // reductions restricted to aligned groups of G lanes (G a power of two <= 64)
 template <int G> __device__ __forceinline__ float group_sum(float x) {
 #pragma unroll

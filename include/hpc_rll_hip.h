@@ -147,6 +147,12 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * take a DMA kernel with k-major tiles whose results are bit-identical to the register-staged kernel; NN products (A along
  * k, B along n) one that combines both tile forms (bit-identical to the NT DMA kernels).  2 = NT on the 256x256 tile only,
  * TN / NN on registers; 0 = register staging everywhere (round 2).
+ * key 26: LayerNorm-LSTM at large batch (B >= 4096, B % 256 == 0, 768 <= H <= 1024, H % 64 == 0; gate-interleaved
+ * pre-activations): 1 (default) = the recurrence of a layer's forward runs in ONE persistent kernel whose workgroups
+ * (256 rows x 256 gate columns, one per CU) do the cell in the product's epilogue and synchronise per 256-row block
+ * (lstm_block.hpp); 0 = one product + one cell launch per step (same layout, same saved tensors); set before the forward.
+ * key 27: start skew of that kernel's row blocks in microseconds (0 ... 200, default 0): row block r waits r x this
+ * before its first step, which spreads the HBM-bound epilogues of the row blocks over the step.
  */
 int hpc_rll_tune_set(int key, int value);
 
@@ -349,6 +355,11 @@ int hpc_rll_lstm_backward_y(const float* dy, const float* dhn, const float* dcn,
                             float* ws, float* dx, float* dh0, float* dc0, float* dwx, float* dwh, float* dbias,
                             float* dln_gamma, float* dln_beta, int S, int B, int I, int H, int L, float dropout_p,
                             uint64_t seed, void* stream);
+/* Diagnostic: the kernels the most recent hpc_rll_lstm_forward* call of this process ran its recurrence on.  0 = one product
+ * + one cell launch per step (what src/torch_utils/network/lstm.cu:145-161 does with three launches), 1 = per-layer
+ * persistent kernels (B <= 4), 2 = layer wavefront (B <= 4, L >= 2), 3 = step kernels on gate-interleaved pre-activations
+ * (large batch), 4 = persistent row-block kernel (large batch, tune key 26); -1 = no forward yet. */
+int hpc_rll_lstm_last_forward_path(void);
 /* Asynchronous status of the persistent small-batch LSTM kernels (B <= 4).  Their workgroups exchange data through
  * memory and must all be resident at once; that is checked against the runtime's occupancy figure at dispatch and
  * launches of one process are serialised per device, but ANOTHER PROCESS holding compute units for seconds can still

@@ -102,6 +102,10 @@ def test_lstm_golden(golden):
                                        # B >= 4096, 768 <= H <= 1024: backward cells walk 8 rows per workgroup and keep
                                        # the bias / gamma / beta column sums across steps and layers
                                        (3, 4096, 16, 768, 2), (2, 4100, 8, 1024, 1),    # (4100: rows do not divide over the 512 workgroups)
+                                       # B % 256 == 0 there: gate-interleaved pre-activations + the persistent row-block forward
+                                       # (lstm_block.hpp); 13 column tiles and an x-branch product without the row-statistics
+                                       # epilogue (I % 16 != 0) / 32 row blocks = two launches of 16
+                                       (4, 4096, 100, 832, 1), (3, 8192, 64, 1024, 1),
                                        # x-branch products on LDS-DMA tiles (NT against Wx^T), recurrent ones on the register path
                                        (8, 2048, 128, 256, 2)])
 def test_lstm_oracle(S, B, I, H, L):
@@ -403,6 +407,80 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
         for got in (b, b2):
             assert np.isfinite(got).all(), k
             assert rel_err(o, got) < max(base, 2.0 * rel_err(o, a)), (k, rel_err(o, got), rel_err(o, a))
+
+
+@pytest.mark.parametrize("S,B,I,H,L,p,skew", [(6, 4096, 192, 768, 2, 0.0, 0), (4, 4096, 64, 1024, 1, 0.0, 7), (3, 8192, 48, 960, 1, 0.0, 0),
+                                              (5, 4096, 36, 896, 2, 0.3, 0)])
+def test_lstm_row_block_kernel_matches_step_kernels(S, B, I, H, L, p, skew):
+    """Large batches (B >= 4096, B % 256 == 0, 768 <= H <= 1024, H % 64 == 0) keep xw / hw gate-interleaved and run a layer's
+    recurrence in ONE persistent kernel (csrc/lstm_block.hpp: product + LayerNorm exchange + cell per 256-row block;
+    tune key 26 = 1, default) or as one product + one cell launch per step on the same layout (key 26 = 0).  Same saved
+    tensors, so forward and backward paths can be mixed: forward outputs and every gradient of the two runs agree to
+    rounding (the row statistics are combined from per-tile (mean, M2) partials in one, summed over the row in the other);
+    H = 768 / 896 / 960 give 12 / 14 / 15 column tiles per row block, B = 8192 two launches, I = 36 an x-branch product
+    without the statistics epilogue, p > 0 the inter-layer dropout, skew the start-offset knob (key 27).  The persistent
+    path must also be what actually ran (hpc_rll_lstm_last_forward_path)."""
+    import hpc_torch_utils_network as N
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(S * 7 + H)
+    m = LSTM(S, B, I, H, L, dropout=p).to(DEV)
+    with torch.no_grad():
+        m.ln_gamma.add_(0.1 * torch.randn_like(m.ln_gamma))
+        m.ln_beta.add_(0.1 * torch.randn_like(m.ln_beta))
+        m.bias.add_(0.1 * torch.randn_like(m.bias))
+    x = torch.randn(S, B, I, device=DEV)
+    h0, c0 = torch.randn(L, B, H, device=DEV), torch.randn(L, B, H, device=DEV)
+    gy, gh, gc = torch.randn(S, B, H, device=DEV), torch.randn(L, B, H, device=DEV), torch.randn(L, B, H, device=DEV)
+
+    def run():
+        for q in m.parameters():
+            q.grad = None
+        xs, hs, cs = (t.clone().requires_grad_(True) for t in (x, h0, c0))
+        torch.manual_seed(99)                     # the dropout seed is drawn from torch's generator
+        y, (hn, cn) = m(xs, (hs, cs))
+        ((y * gy).sum() + (hn * gh).sum() + (cn * gc).sum()).backward()
+        torch.cuda.synchronize()
+        assert N.async_error() == 0
+        return [t.detach().clone() for t in (y, hn, cn, xs.grad, hs.grad, cs.grad, m.wx.grad, m.wh.grad, m.bias.grad,
+                                             m.ln_gamma.grad, m.ln_beta.grad)]
+
+    try:
+        N.tune_set(26, 0)
+        step = run()
+        assert N.lstm_last_forward_path() == 3
+        N.tune_set(26, 1)
+        N.tune_set(27, skew)
+        blk = run()
+        assert N.lstm_last_forward_path() == 4     # the persistent kernel is what ran (residency was granted)
+    finally:
+        N.tune_set(26, 1)
+        N.tune_set(27, 0)
+    names = "y hn cn dx dh0 dc0 dwx dwh dbias dgamma dbeta".split()
+    for k, a, b in zip(names, step, blk):
+        assert torch.isfinite(b).all(), k
+        scale = float(a.abs().max())
+        err = float((a - b).abs().max()) / scale
+        assert err < (5e-6 if k in ("y", "hn", "cn") else 5e-5), (k, err, scale)
+    # the oracle on a slice of the batch (rows are independent sequences): y / hn / cn / dx of the first 96 rows
+    n = 96
+    G4 = 4 * H
+    dims = [I] + [H] * L
+    offs = np.cumsum([0] + [d * G4 for d in dims])
+    if p == 0.0:
+        wxf = m.wx.detach().double().cpu()
+        owx = [wxf[offs[l]:offs[l + 1]].reshape(dims[l], G4) for l in range(L)]
+        owh = list(m.wh.detach().double().cpu().reshape(L, H, G4))
+        ox = x[:, :n].double().cpu().requires_grad_(True)
+        oy, ohn, ocn = R.lstm(ox, h0[:, :n].double().cpu(), c0[:, :n].double().cpu(), owx, owh,
+                              m.bias.detach().double().cpu().reshape(L, G4), m.ln_gamma.detach().double().cpu(),
+                              m.ln_beta.detach().double().cpu())
+        ((oy * gy[:, :n].double().cpu()).sum() + (ohn * gh[:, :n].double().cpu()).sum()
+         + (ocn * gc[:, :n].double().cpu()).sum()).backward()
+        for k, ref, got in (("y", oy, blk[0][:, :n]), ("hn", ohn, blk[1][:, :n]), ("cn", ocn, blk[2][:, :n]),
+                            ("dx", ox.grad, blk[3][:, :n])):
+            ref = ref.detach().numpy()
+            e = float(np.abs(ref - got.double().cpu().numpy()).max()) / float(np.abs(ref).max())
+            assert e < (2e-5 if k != "dx" else 2e-4), (k, e)
 
 
 @pytest.mark.parametrize("S,B,I,H,L", [(24, 3, 64, 384, 1), (16, 3, 48, 96, 3), (12, 4, 32, 512, 2)])   # per-layer / wavefront / mixed
