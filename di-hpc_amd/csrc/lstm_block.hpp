@@ -33,8 +33,9 @@
 #include "wave.hpp"
 
 namespace hpc_rll {
-int g_lstm_block = 1;        // hpc_rll_tune_set key 26: 0 = step kernels (same layout), 1 = persistent row-block forward
-int g_lstm_block_skew = 0;   // hpc_rll_tune_set key 27: microseconds between the starts of consecutive row blocks
+int g_lstm_block = 1;        // hpc_rll_tune_set key 26: 0 = step kernels (same layout); bit 0 = persistent row-block forward,
+                             // bit 1 = 128-row blocks (two workgroups per CU), bit 2 = libm gate functions
+int g_lstm_block_skew = 10;  // hpc_rll_tune_set key 27: microseconds between the starts of consecutive row blocks (C4: 69.9 -> 65.9 ms)
 namespace {
 
 // ---- counter barrier over the workgroups of one row block -----------------------------------------------------------
@@ -83,27 +84,59 @@ struct BlockFwd {
     const float *bias, *gamma, *beta;   // standard layouts: (4H), (2, 4H), (2, 4H)
     const float *h0, *c0;               // (B, H)
     float *hw, *c, *hseq, *stats;       // (S,B,4H) interleaved, (S,B,H), (S,B,H), (S,B,4): stats[.,0..1] are inputs
-    float* part;                        // [row blocks of this launch][2][nct][256][2]
+    float* part;                        // [row blocks of this launch][2][2 nct][rows of a block][2]
     unsigned* flags;                    // [row blocks of this launch][2]: arrivals (statistics, h); zero at launch
     int S, B, H, rb0, nct;
     int skew_ticks;                     // wall-clock ticks (100 MHz) between the starts of consecutive row blocks
+    u64* prof;                          // optional (HPC_RLL_LSTM_PROFILE=1): 8 phase accumulators of workgroup gridDim.x / 2
 };
+#define HPC_RLL_BLK_TICK(i)                                   \
+    if (prof_on) {                                            \
+        const u64 now_ = wall_clock64();                      \
+        a.prof[i] += now_ - tprev_;                           \
+        tprev_ = now_;                                        \
+    }
 
 constexpr int kRC = 4;   // rows of a lane whose loads are in flight together in the cell epilogue (register budget)
-constexpr int kBlkLdsFloats = 2 * 16 * 256 + 2 * 16 * 256 + 2 * 256 * 2 + 256 * 4;
-constexpr size_t kBlkLdsBytes = 96 * 1024;   // > half a CU's 160 KB: exactly one workgroup per CU
-static_assert(kBlkLdsFloats * sizeof(float) <= kBlkLdsBytes, "row-block kernel LDS");
 
-__global__ __launch_bounds__(512, 2) void lstm_block_fwd_kernel(const BlockFwd a) {
-    constexpr int BM = 256, BN = 256, BK = 16, NTH = 512;
+// Gate activations of the row-block epilogue.  FAST: hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each) instead of
+// libm's expf / tanhf / IEEE division -- ~55 instead of ~170 vector instructions per hidden unit.  In the step path the cell
+// is a kernel of its own and HBM-bound, the arithmetic is free there (0.3 %); in the product's epilogue it
+// is on the critical path of the CU (measured 25 us of the 60 us epilogue at C4).  Absolute error of a gate <= 2e-7; the
+// backward recomputes the gates with the precise forms from the saved pre-activations (difference <= 2e-7, far inside the
+// 2e-5 / 2e-4 bounds of the parity tests).
+template <bool FAST> __device__ __forceinline__ float blk_sigmoid(float a) {
+    if (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * a));
+    return gate_sigmoid(a);
+}
+template <bool FAST> __device__ __forceinline__ float blk_tanh(float a) {
+    if (FAST) return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177792681f * a));
+    return tanhf(a);
+}
+
+// MW = waves along the rows: 4 -> tile 256 x 256, 8 waves, ONE workgroup per CU; 2 -> tile 128 x 256, 4 waves, TWO
+// workgroups per CU (two independent row blocks: while one sits in its exchange / epilogue the other's product has the
+// matrix pipe).  A row block = 64 * MW batch rows.
+template <int MW> struct BlkCfg {
+    static constexpr int BM = 64 * MW, NW = 2 * MW, NTH = 64 * NW;
+    static constexpr int lds_floats = 2 * 16 * BM + 2 * 16 * 256 + BM * 4;
+    // 1 per CU: more than half of the 160 KB; 2 per CU: 64 KB (a third would not fit; the 256 registers per wave cap it too)
+    static constexpr size_t lds_bytes = MW == 4 ? 96 * 1024 : 64 * 1024;
+    static constexpr int wgs_per_cu = MW == 4 ? 1 : 2;
+    static_assert(lds_floats * sizeof(float) <= lds_bytes, "row-block kernel LDS");
+};
+
+template <int MW, bool FAST>
+__global__ __launch_bounds__(128 * MW, 2) void lstm_block_fwd_kernel(const BlockFwd a) {
+    typedef BlkCfg<MW> C;
+    constexpr int BM = C::BM, BN = 256, BK = 16, NTH = C::NTH, NW = C::NW;
     extern __shared__ __attribute__((aligned(16))) float blk_lds[];
     float* const As = blk_lds;                    // [2][BM rows][BK]  (swizzled chunks, lds_pos)
     float* const Bs = As + 2 * BK * BM;           // [2][BK][BN]       (k-major)
-    float* const pl = Bs + 2 * BK * BN;           // [2 (wn)][256 rows][2]: (mean, M2) of a wave's 128 columns
-    float* const sl = pl + 2 * 256 * 2;           // [256 rows][4]: mean_x, rstd_x, mean_h, rstd_h
+    float* const sl = Bs + 2 * BK * BN;           // [BM rows][4]: mean_x, rstd_x, mean_h, rstd_h
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values live in scalar registers: row
-    const int wm = wave & 3, wn = wave >> 2, h = lane >> 5, i32 = lane & 31;   // addresses = scalar base + per-lane offset
+    const int wm = wave % MW, wn = wave / MW, h = lane >> 5, i32 = lane & 31;   // addresses = scalar base + per-lane offset
     const int rbl = (int)blockIdx.x / a.nct, ct = (int)blockIdx.x % a.nct;
     const int H = a.H, G = 4 * H, nct = a.nct;
     const long row0 = (long)(a.rb0 + rbl) * BM;   // first batch row of the row block
@@ -111,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void lstm_block_fwd_kernel(const BlockFwd a
     const int unit = ct * 64 + wn * 32 + i32;     // the hidden unit whose four gates this lane holds
     unsigned* const flag_p = a.flags + 2 * rbl;
     unsigned* const flag_h = flag_p + 1;
-    float* const part = a.part + (size_t)rbl * 2 * nct * 256 * 2;
+    float* const part = a.part + (size_t)rbl * 2 * 2 * nct * BM * 2;
 
     float gx[4], gh[4], bx[4], bh[4], bb[4];
 #pragma unroll
@@ -138,16 +171,32 @@ __global__ __launch_bounds__(512, 2) void lstm_block_fwd_kernel(const BlockFwd a
 #pragma unroll
     for (int q = 0; q < 2; ++q) a_off[q] = lds_pos<BK>(wm * 64 + i32, 8 * h + 4 * q);
     const int b_off = (8 * h) * BN + wn * 128 + 4 * i32;
-    const long b8 = 8L * G, b16 = 16L * G;
+    const long bstep = (long)NW * G, b16 = 16L * G;
 
+    const bool prof_on = a.prof && blockIdx.x == gridDim.x / 2 && tid == 0;
+    u64 tprev_ = prof_on ? wall_clock64() : 0;
+    f32x16 acc[2][4];
     for (int s = 0; s < a.S; ++s) {
         const size_t srow = (size_t)s * a.B + row0;   // this row block's first row in the (S*B, .) tensors
         const float* hprev = s == 0 ? a.h0 : a.hseq + (size_t)(s - 1) * a.B * H;
         const float* cprev = s == 0 ? a.c0 : a.c + (size_t)(s - 1) * a.B * H;
-        if (s > 0) block_wait(flag_h, (unsigned)(nct * s));   // h_{s-1} of this row block is complete
+        // the previous step's pre-LayerNorm product goes out now (it is only read by the backward): the stores drain under
+        // the wait for h and the first tiles of this step's product
+        if (s > 0) {
+            float* const hw_p = a.hw + (srow - a.B) * G;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int R = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    __builtin_nontemporal_store(vfloat4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]},
+                                                reinterpret_cast<vfloat4*>(hw_p + (size_t)R * G + xoff));
+                }
+            block_wait(flag_h, (unsigned)(nct * s));   // h_{s-1} of this row block is complete
+        }
+        HPC_RLL_BLK_TICK(0)   // hw stores issued, wait for h
 
         // ---- acc = hprev[row block] @ whp[:, tile]   (the loop of gemm_f32_nn_dma_kernel)
-        f32x16 acc[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -156,12 +205,13 @@ __global__ __launch_bounds__(512, 2) void lstm_block_fwd_kernel(const BlockFwd a
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         DmaStage<BM, BK, NTH> da;
         da.init(hprev + row0 * H, H, 0, 0);
-        const float* pb = a.whp + (long)wave * G + n0 + 4 * lane;   // wave w: k-rows w and w + 8
+        const float* pb = a.whp + (long)wave * G + n0 + 4 * lane;   // wave w: k-rows w, w + NW, ...
         auto issue = [&](int buf) __attribute__((always_inline)) {
             da.issue(As + buf * BK * BM);
             float* bt = Bs + buf * BK * BN + wave * BN;
-            __builtin_amdgcn_global_load_lds((gl_ptr)pb, (lds_ptr)bt, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gl_ptr)(pb + b8), (lds_ptr)(bt + 8 * BN), 16, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 16 / NW; ++j)
+                __builtin_amdgcn_global_load_lds((gl_ptr)(pb + j * bstep), (lds_ptr)(bt + j * NW * BN), 16, 0, 0);
             pb += b16;
         };
         issue(0);
@@ -193,9 +243,30 @@ __global__ __launch_bounds__(512, 2) void lstm_block_fwd_kernel(const BlockFwd a
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        HPC_RLL_BLK_TICK(1)   // product
+
+        // ---- the cell's own inputs (x-branch pre-activations, c_{s-1}: both independent of the exchange below) are
+        // requested kRC rows at a time, one chunk ahead of the arithmetic; the first chunk already before the exchange
+        const float* const xw_s = a.xw + srow * G;   // scalar bases of this step and row block
+        const float* const cp_s = cprev + (size_t)row0 * H;
+        vfloat4 xv[2][kRC];
+        float cp[2][kRC];
+        auto load_chunk = [&](int ci, vfloat4 (&x4)[kRC], float (&c1)[kRC]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < kRC; ++q) {
+                const int r = (ci * kRC + q) & 15, i = (ci * kRC) >> 4;
+                const int R = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);   // wave-uniform part of the row
+                x4[q] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(xw_s + (size_t)R * G + xoff));
+                c1[q] = (cp_s + (size_t)R * H)[uoff];
+            }
+        };
+        load_chunk(0, xv[0], cp[0]);
 
         // ---- (1) LayerNorm statistics of the h-branch rows.  A wave holds 64 rows x 128 columns: per row the 32 lanes of a
         // half wave sum their four columns (two passes: mean, then M2 around it); lane i32 = 16 i + r keeps row (i, r).
+        float* const pslot = part + (size_t)(s & 1) * 2 * nct * BM * 2;
+        vfloat2 xs = {0.f, 0.f};   // x-branch statistics of row `tid` (written before this launch): requested now, used after the exchange
+        if (tid < BM) xs = *reinterpret_cast<const vfloat2*>(a.stats + (srow + tid) * 4);
         {
             float my_m = 0.f, my_d = 0.f;
 #pragma unroll
@@ -212,119 +283,133 @@ __global__ __launch_bounds__(512, 2) void lstm_block_fwd_kernel(const BlockFwd a
                 }
             const int rr = i32 & 15;
             const int row = wm * 64 + (i32 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-            *reinterpret_cast<vfloat2*>(pl + (wn * 256 + row) * 2) = vfloat2{my_m, my_d};
-        }
-        __syncthreads();
-        float* const pslot = part + (size_t)(s & 1) * nct * 256 * 2;
-        if (tid < 256) {   // the two waves of a row (128 columns each) -> the workgroup's (mean, M2) over 256 columns
-            const vfloat2 p0 = *reinterpret_cast<const vfloat2*>(pl + tid * 2);
-            const vfloat2 p1 = *reinterpret_cast<const vfloat2*>(pl + (256 + tid) * 2);
-            const float dm = p0.x - p1.x;
-            *reinterpret_cast<vfloat2*>(pslot + ((size_t)ct * 256 + tid) * 2) =
-                vfloat2{0.5f * (p0.x + p1.x), p0.y + p1.y + 64.f * dm * dm};
+            // every wave publishes its own (mean, M2) over 128 columns: 2 nct partials per row
+            *reinterpret_cast<vfloat2*>(pslot + ((size_t)(2 * ct + wn) * BM + row) * 2) = vfloat2{my_m, my_d};
         }
         block_arrive(flag_p);
+        HPC_RLL_BLK_TICK(2)   // row partials + publish
         block_wait(flag_p, (unsigned)(nct * (s + 1)));
-        if (tid < 256) {
-            float ms = 0.f, m2 = 0.f;
-            float pm[16];
+        HPC_RLL_BLK_TICK(3)   // wait for the row block's partials
+        if (tid < BM) {
+            // Chan's update, one partial (128 columns) at a time, eight loads in flight: mean and M2 of the whole row
+            float mean = 0.f, m2 = 0.f, cnt = 0.f;
+            const float* pp = pslot + (size_t)tid * 2;
+            for (int c0 = 0; c0 < 2 * nct; c0 += 8) {
+                vfloat2 p[8];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int cc = c < nct ? c : 0;   // nct <= 16 (H <= 1024); idle slots re-read tile 0, unused
-                const vfloat2 p = *reinterpret_cast<const vfloat2*>(pslot + ((size_t)cc * 256 + tid) * 2);
-                pm[c] = p.x;
-                if (c < nct) { ms += p.x; m2 += p.y; }
+                for (int k = 0; k < 8; ++k)
+                    p[k] = *reinterpret_cast<const vfloat2*>(pp + (size_t)(c0 + k < 2 * nct ? c0 + k : 0) * BM * 2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + k < 2 * nct) {
+                        const float tot = cnt + 128.f, d = p[k].x - mean;
+                        mean += d * (128.f / tot);
+                        m2 += p[k].y + d * d * (cnt * 128.f / tot);
+                        cnt = tot;
+                    }
             }
-            const float mean = ms / (float)nct;
-            float dev = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c < nct) dev += (pm[c] - mean) * (pm[c] - mean);
-            const float rstd = rsqrtf((m2 + 256.f * dev) / (float)G + kLnEps);
-            float* st = a.stats + (srow + tid) * 4;
-            const vfloat2 xs = *reinterpret_cast<const vfloat2*>(st);
+            const float rstd = rsqrtf(m2 / (float)G + kLnEps);
             *reinterpret_cast<vfloat4*>(sl + tid * 4) = vfloat4{xs.x, xs.y, mean, rstd};
-            if (ct == 0) *reinterpret_cast<vfloat2*>(st + 2) = vfloat2{mean, rstd};
+            if (ct == 0) *reinterpret_cast<vfloat2*>(a.stats + (srow + tid) * 4 + 2) = vfloat2{mean, rstd};
         }
         __syncthreads();
+        HPC_RLL_BLK_TICK(4)   // combine
 
-        // ---- (2) gates, state update, saved tensors: lane-local (four gates of `unit` for 32 rows)
+        // ---- (2) gates and state update: lane-local (four gates of `unit` for 32 rows)
         {
-            const float* const xw_s = a.xw + srow * G;                        // scalar bases of this step and row block
-            const float* const cp_s = cprev + (size_t)row0 * H;
-            float* const hw_s = a.hw + srow * G;
             float* const c_s = a.c + srow * H;
             float* const h_s = a.hseq + srow * H;
+            constexpr int NCH = 32 / kRC;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int ci = 0; ci < NCH; ++ci) {
+                if (ci + 1 < NCH) load_chunk(ci + 1, xv[(ci + 1) & 1], cp[(ci + 1) & 1]);
 #pragma unroll
-                for (int r8 = 0; r8 < 16; r8 += kRC) {
-                    vfloat4 xv[kRC];
-                    float cp[kRC];
+                for (int q = 0; q < kRC; ++q) {
+                    const int r = (ci * kRC + q) & 15, i = (ci * kRC) >> 4;
+                    const int R = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(sl + (R + 4 * h) * 4);
+                    float pre[4];
 #pragma unroll
-                    for (int q = 0; q < kRC; ++q) {
-                        const int r = r8 + q;
-                        const int R = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);   // wave-uniform part of the row
-                        xv[q] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(xw_s + (size_t)R * G + xoff));
-                        cp[q] = (cp_s + (size_t)R * H)[uoff];
-                    }
-#pragma unroll
-                    for (int q = 0; q < kRC; ++q) {
-                        const int r = r8 + q;
-                        const int R = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);
-                        const vfloat4 st = *reinterpret_cast<const vfloat4*>(sl + (R + 4 * h) * 4);
-                        float pre[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            pre[j] = gate_pre(xv[q][j], st.x, st.y, gx[j], bx[j], acc[i][j][r], st.z, st.w, gh[j], bh[j], bb[j]);
-                        const float ig = gate_sigmoid(pre[0]), fg = gate_sigmoid(pre[1]), og = gate_sigmoid(pre[2]);
-                        const float ug = tanhf(pre[3]);
-                        const float cn = fg * cp[q] + ig * ug;
-                        (h_s + (size_t)R * H)[uoff] = og * tanhf(cn);
-                        (c_s + (size_t)R * H)[uoff] = cn;
-                        __builtin_nontemporal_store(vfloat4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]},
-                                                    reinterpret_cast<vfloat4*>(hw_s + (size_t)R * G + xoff));
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        pre[j] = gate_pre(xv[ci & 1][q][j], st.x, st.y, gx[j], bx[j], acc[i][j][r], st.z, st.w, gh[j], bh[j], bb[j]);
+                    const float ig = blk_sigmoid<FAST>(pre[0]), fg = blk_sigmoid<FAST>(pre[1]), og = blk_sigmoid<FAST>(pre[2]);
+                    const float ug = blk_tanh<FAST>(pre[3]);
+                    const float cn = fg * cp[ci & 1][q] + ig * ug;
+                    (h_s + (size_t)R * H)[uoff] = og * blk_tanh<FAST>(cn);
+                    (c_s + (size_t)R * H)[uoff] = cn;
                 }
+            }
         }
+        HPC_RLL_BLK_TICK(5)   // gates
         block_arrive(flag_h);
+        HPC_RLL_BLK_TICK(6)   // h / c stores drained, release fence, arrival
+    }
+    {   // the last step's pre-LayerNorm product
+        float* const hw_p = a.hw + ((size_t)(a.S - 1) * a.B + row0) * G;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int R = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);
+                __builtin_nontemporal_store(vfloat4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]},
+                                            reinterpret_cast<vfloat4*>(hw_p + (size_t)R * G + xoff));
+            }
     }
 }
 
-// Row blocks one launch can hold: every workgroup needs its own CU (co-residency).
-inline int block_rows_per_launch(int H) {
+// Row blocks one launch can hold: every workgroup needs its slot on a CU (co-residency).
+template <int MW> inline int block_rows_per_launch(int H) {
     const int nct = 4 * H / 256;
     const int cus = persist_cu_count();
-    return nct > 0 ? cus / nct : 0;
+    return nct > 0 ? cus * BlkCfg<MW>::wgs_per_cu / nct : 0;
 }
-inline size_t block_part_floats(int B, int H) { return (size_t)(B / 256) * 2 * (4 * H / 256) * 256 * 2; }
-inline size_t block_flag_words(int B) { return (size_t)(B / 256) * 2; }
+// (sized for the 128-row blocks: the larger of the two tilings)
+inline size_t block_part_floats(int B, int H) { return (size_t)(B / 128) * 2 * 2 * (4 * H / 256) * 128 * 2; }
+inline size_t block_flag_words(int B) { return (size_t)(B / 128) * 2; }
 
+// g_lstm_block: 0 off; bit 0 = on; bit 1 = 128-row blocks, two workgroups per CU (else 256-row blocks, one per CU);
+// bit 2 = libm gate functions instead of the hardware exp2 / reciprocal forms
+inline int block_mw() { return (g_lstm_block & 2) ? 2 : 4; }
+inline bool block_fast() { return (g_lstm_block & 4) == 0; }
+
+template <int MW, bool FAST> inline bool block_resident(int H) {
+    const int per = block_rows_per_launch<MW>(H);
+    return per >= 1 && persist_resident_t(lstm_block_fwd_kernel<MW, FAST>, BlkCfg<MW>::NTH, (4 * H / 256) * per, BlkCfg<MW>::lds_bytes);
+}
 inline bool block_fwd_ok(int B, int H, hipStream_t st) {
-    if (!g_lstm_block || !g_lstm_persist || !lstm_perm_shape(B, H) || !persist_runtime_ready(st)) return false;
-    if (block_rows_per_launch(H) < 1) return false;
-    return persist_resident_t(lstm_block_fwd_kernel, 512, (4 * H / 256) * block_rows_per_launch(H), kBlkLdsBytes);
+    if (!(g_lstm_block & 1) || !g_lstm_persist || !lstm_perm_shape(B, H) || !persist_runtime_ready(st)) return false;
+    if (block_mw() == 4) return block_fast() ? block_resident<4, true>(H) : block_resident<4, false>(H);
+    return block_fast() ? block_resident<2, true>(H) : block_resident<2, false>(H);
 }
 
 // All row blocks of one layer, in as many launches as the CU count asks for (C4: 16 row blocks x 16 column tiles = one).
-inline int launch_block_fwd(BlockFwd a, float* part, unsigned* flags, hipStream_t st) {
-    const int nrb = a.B / 256, per = block_rows_per_launch(a.H);
+template <int MW, bool FAST>
+inline int launch_block_fwd_t(BlockFwd a, float* part, unsigned* flags, hipStream_t st) {
+    typedef BlkCfg<MW> C;
+    const int nrb = a.B / C::BM, per = block_rows_per_launch<MW>(a.H);
     if (hipMemsetAsync(flags, 0, block_flag_words(a.B) * sizeof(unsigned), st) != hipSuccess) return last_error();
-    const hipError_t e = hipFuncSetAttribute((const void*)lstm_block_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)kBlkLdsBytes);
+    const hipError_t e = hipFuncSetAttribute((const void*)lstm_block_fwd_kernel<MW, FAST>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
     if (e != hipSuccess) return (int)e;
     a.nct = 4 * a.H / 256;
     a.skew_ticks = g_lstm_block_skew * 100;
+    a.prof = persist_prof();
     for (int rb = 0; rb < nrb; rb += per) {
         const int n = nrb - rb < per ? nrb - rb : per;
         a.rb0 = rb;
-        a.part = part + (size_t)rb * 2 * a.nct * 256 * 2;
+        a.part = part + (size_t)rb * 2 * 2 * a.nct * C::BM * 2;
         a.flags = flags + 2 * rb;
         persist_chain_before(st);
-        hipLaunchKernelGGL(lstm_block_fwd_kernel, dim3(n * a.nct), dim3(512), kBlkLdsBytes, st, a);
+        hipLaunchKernelGGL((lstm_block_fwd_kernel<MW, FAST>), dim3(n * a.nct), dim3(C::NTH), C::lds_bytes, st, a);
         persist_chain_after(st);
     }
+    persist_prof_report("row-block fwd: wait_h product partials wait_p combine gates arrive_h", 0, a.S, st);
     return last_error();
+}
+inline int launch_block_fwd(const BlockFwd& a, float* part, unsigned* flags, hipStream_t st) {
+    if (block_mw() == 4)
+        return block_fast() ? launch_block_fwd_t<4, true>(a, part, flags, st) : launch_block_fwd_t<4, false>(a, part, flags, st);
+    return block_fast() ? launch_block_fwd_t<2, true>(a, part, flags, st) : launch_block_fwd_t<2, false>(a, part, flags, st);
 }
 
 }  // namespace

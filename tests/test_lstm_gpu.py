@@ -409,9 +409,10 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
             assert rel_err(o, got) < max(base, 2.0 * rel_err(o, a)), (k, rel_err(o, got), rel_err(o, a))
 
 
+@pytest.mark.parametrize("mode", [1, 3, 5, 7])   # key 26: 256-row blocks / 128-row blocks (two per CU), hardware / libm gate functions
 @pytest.mark.parametrize("S,B,I,H,L,p,skew", [(6, 4096, 192, 768, 2, 0.0, 0), (4, 4096, 64, 1024, 1, 0.0, 7), (3, 8192, 48, 960, 1, 0.0, 0),
                                               (5, 4096, 36, 896, 2, 0.3, 0)])
-def test_lstm_row_block_kernel_matches_step_kernels(S, B, I, H, L, p, skew):
+def test_lstm_row_block_kernel_matches_step_kernels(S, B, I, H, L, p, skew, mode):
     """Large batches (B >= 4096, B % 256 == 0, 768 <= H <= 1024, H % 64 == 0) keep xw / hw gate-interleaved and run a layer's
     recurrence in ONE persistent kernel (csrc/lstm_block.hpp: product + LayerNorm exchange + cell per 256-row block;
     tune key 26 = 1, default) or as one product + one cell launch per step on the same layout (key 26 = 0).  Same saved
@@ -448,7 +449,7 @@ def test_lstm_row_block_kernel_matches_step_kernels(S, B, I, H, L, p, skew):
         N.tune_set(26, 0)
         step = run()
         assert N.lstm_last_forward_path() == 3
-        N.tune_set(26, 1)
+        N.tune_set(26, mode)
         N.tune_set(27, skew)
         blk = run()
         assert N.lstm_last_forward_path() == 4     # the persistent kernel is what ran (residency was granted)
@@ -460,7 +461,7 @@ def test_lstm_row_block_kernel_matches_step_kernels(S, B, I, H, L, p, skew):
         assert torch.isfinite(b).all(), k
         scale = float(a.abs().max())
         err = float((a - b).abs().max()) / scale
-        assert err < (5e-6 if k in ("y", "hn", "cn") else 5e-5), (k, err, scale)
+        assert err < (2e-5 if k in ("y", "hn", "cn") else 1e-4), (k, err, scale)   # rounding, amplified by S*L LayerNorm steps (measured 6.5e-6 at S*L = 12)
     # the oracle on a slice of the batch (rows are independent sequences): y / hn / cn / dx of the first 96 rows
     n = 96
     G4 = 4 * H
