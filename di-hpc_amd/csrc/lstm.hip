@@ -493,7 +493,7 @@ template <int NQ, bool SAVED /* gates are loaded, not recomputed */> struct Cell
     vfloat4 xv[NQ][4], hv[NQ][4], gv[SAVED ? NQ : 1][SAVED ? 4 : 1], cn[NQ], cp[NQ], dci[NQ], dh[NQ];
     float mx, rx, mh, rh;
 };
-template <int NQ, bool SAVED, bool PERM = false>
+template <int NQ, bool SAVED>
 __device__ __forceinline__ void cell_bwd4_load(const CellBwdArgs& a, int b, CellBwdRow<NQ, SAVED>& r) {
     const int H = a.H, G = 4 * H;
     const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -505,8 +505,8 @@ __device__ __forceinline__ void cell_bwd4_load(const CellBwdArgs& a, int b, Cell
         const int uu = u0 < H ? u0 : 0;   // idle quads re-read quad 0 (no divergent branch around a load), results unused
         const size_t o = (size_t)b * H + uu;
         const size_t og0 = (size_t)b * G + uu;
-        load_gq<PERM, true>(a.xw + (size_t)b * G, H, uu, r.xv[qq]);
-        load_gq<PERM, true>(a.hw + (size_t)b * G, H, uu, r.hv[qq]);
+        load_gq<false, true>(a.xw + (size_t)b * G, H, uu, r.xv[qq]);
+        load_gq<false, true>(a.hw + (size_t)b * G, H, uu, r.hv[qq]);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             if (SAVED) r.gv[SAVED ? qq : 0][SAVED ? g : 0] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.gates + og0 + g * H));
@@ -519,7 +519,7 @@ __device__ __forceinline__ void cell_bwd4_load(const CellBwdArgs& a, int b, Cell
 // ACC: instead of storing the gate adjoint `da` for a later column-reduction pass over (S*B, 4H), the workgroup adds
 // da, da*xhat_x, da*xhat_h of its row to per-column accumulators in LDS (`acc`, 3 x 4H floats, every column owned by
 // exactly one thread: no synchronisation) -- see lstm_cell_bwd4_rows_kernel.
-template <int NQ, bool SAVED, bool ACC, bool PERM = false>
+template <int NQ, bool SAVED, bool ACC>
 __device__ __forceinline__ void cell_bwd4_compute(const CellBwdArgs& a, int b, const CellBwdRow<NQ, SAVED>& r, float* red,
                                                   float* acc) {
     const int H = a.H, G = 4 * H;
@@ -627,8 +627,8 @@ __device__ __forceinline__ void cell_bwd4_compute(const CellBwdArgs& a, int b, c
                 oh[g][i] = rh * (dyh - a2 - (r.hv[qq][g][i] - mh) * rh * a3);
             }
         }
-        store_gq<PERM, true>(a.dxw + (size_t)b * G, H, u0, ox);
-        store_gq<PERM, false>(a.dhw + (size_t)b * G, H, u0, oh);   // read next by this step's dh product: keep it cached
+        store_gq<false, true>(a.dxw + (size_t)b * G, H, u0, ox);
+        store_gq<false, false>(a.dhw + (size_t)b * G, H, u0, oh);   // read next by this step's dh product: keep it cached
     }
 }
 
@@ -652,7 +652,6 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd4_kernel(const CellBwdArgs a
 // and spills (147.3).  At B = 1024..2048 the row walk loses 2-3 % (too few rows per workgroup to pay for the
 // accumulator round trip), so it starts at 8 rows per workgroup; B = 8192: H = 1024 36.2 -> 35.5 ms (S = 16), H = 512
 // 43.1 -> 43.5 (S = 32, L = 2), so it starts at H = 768.
-template <bool PERM>
 __global__ __launch_bounds__(256) void lstm_cell_bwd4_rows_kernel(const CellBwdArgs a, float* __restrict__ colacc,
                                                                   int acc_init, int B) {
     __shared__ float red[16];
@@ -666,12 +665,150 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd4_rows_kernel(const CellBwdA
     __syncthreads();   // (the owner of a column in the row function is another thread than here unless H % 256 == 0)
     for (int b = r0; b < r1; ++b) {
         CellBwdRow<1, false> r;   // (this path always recomputes the gates: cell_rows_shape)
-        cell_bwd4_load<1, false, PERM>(a, b, r);
-        cell_bwd4_compute<1, false, true, PERM>(a, b, r, red, acc);
+        cell_bwd4_load<1, false>(a, b, r);
+        cell_bwd4_compute<1, false, true>(a, b, r, red, acc);
     }
     __syncthreads();
     for (int i = threadIdx.x * 4; i < 3 * G; i += 1024)
         *reinterpret_cast<vfloat4*>(mine + i) = *reinterpret_cast<const vfloat4*>(acc + i);
+}
+
+// The row-walking backward cell for GATE-INTERLEAVED pre-activations (lstm_perm_shape).  Thread t owns the hidden units
+// t, t + 256, t + 512, t + 768 (those below H): a unit's four gates are ONE float4 of xw / hw / dxw / dhw and consecutive
+// lanes hold consecutive units, so every access instruction of a wave is one contiguous span -- 1 KB for the (rows, 4H)
+// tensors, 256 B for the (rows, H) ones.  (The unit-QUAD mapping of the standard layout would make a lane's data 64
+// contiguous bytes moved as four 16-byte pieces at a 64-byte lane stride: harmless for loads, but the streaming stores of
+// dxw / dhw then reach memory as quarter lines -- 90 -> 127 us per step at C4; redistributing through LDS instead cost
+// more than it saved: 176 us.)  Same arithmetic per element as cell_bwd4_compute; the four row sums and the per-column
+// accumulators are summed in another order (fp32 rounding).  `pp`: gamma_x, gamma_h, beta_x, beta_h, bias of the layer in
+// the interleaved column order ([5][4H], perm_params_kernel); the column accumulators are interleaved too
+// (lstm_colfinal_kernel un-permutes).
+constexpr int kPermUnits = 4;   // H <= 1024
+struct PermRow { vfloat4 xv[kPermUnits], hv[kPermUnits]; float cn[kPermUnits], cp[kPermUnits], dci[kPermUnits], dh[kPermUnits]; float mx, rx, mh, rh; };
+__device__ __forceinline__ void cell_bwd_perm_load(const CellBwdArgs& a, int b, PermRow& r) {
+    const int H = a.H, G = 4 * H;
+    const float* st = a.stats + (size_t)b * 4;
+    r.mx = st[0]; r.rx = st[1]; r.mh = st[2]; r.rh = st[3];
+#pragma unroll
+    for (int k = 0; k < kPermUnits; ++k) {
+        const int u = (int)threadIdx.x + 256 * k;
+        const int uu = u < H ? u : 0;   // idle units re-read unit 0 (no divergent branch around a load), results unused
+        const size_t o = (size_t)b * H + uu;
+        r.xv[k] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.xw + (size_t)b * G + 4 * uu));
+        r.hv[k] = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(a.hw + (size_t)b * G + 4 * uu));
+        r.cn[k] = __builtin_nontemporal_load(a.c_new + o);
+        r.cp[k] = a.c_prev[o];
+        r.dci[k] = a.dc_in ? a.dc_in[o] : 0.f;
+        r.dh[k] = a.dh_a ? a.dh_a[o] : 0.f;
+    }
+}
+__device__ __forceinline__ void cell_bwd_perm_compute(const CellBwdArgs& a, int b, const PermRow& r, float* red, float* acc,
+                                                      const float* __restrict__ pp) {
+    const int H = a.H, G = 4 * H;
+    const float mx = r.mx, rx = r.rx, mh = r.mh, rh = r.rh;
+    vfloat4 da[kPermUnits];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kPermUnits; ++k) {
+        const int u = (int)threadIdx.x + 256 * k;
+        if (u >= H) {
+            da[k] = vfloat4{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
+        const size_t o = (size_t)b * H + u;
+        const vfloat4 gxv = *reinterpret_cast<const vfloat4*>(pp + 4 * u);
+        const vfloat4 ghv = *reinterpret_cast<const vfloat4*>(pp + G + 4 * u);
+        const vfloat4 bxv = *reinterpret_cast<const vfloat4*>(pp + 2 * G + 4 * u);
+        const vfloat4 bhv = *reinterpret_cast<const vfloat4*>(pp + 3 * G + 4 * u);
+        const vfloat4 bv = *reinterpret_cast<const vfloat4*>(pp + 4 * G + 4 * u);
+        float dh = r.dh[k];
+        // split-K partials of dh (written by the product just before this launch: cache hits), four in flight, slice order
+        for (int z = 0; a.dh_b && z < a.nsplit; z += 4) {
+            float p[4];
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz) p[zz] = (z + zz < a.nsplit) ? a.dh_b[(size_t)(z + zz) * a.part_stride + o] : 0.f;
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz)
+                if (z + zz < a.nsplit) dh += p[zz];
+        }
+        float gv[4];   // the forward's own expression (the gates are not saved at these shapes)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float pre = gate_pre(r.xv[k][g], mx, rx, gxv[g], bxv[g], r.hv[k][g], mh, rh, ghv[g], bhv[g], bv[g]);
+            gv[g] = g < 3 ? gate_sigmoid(pre) : tanhf(pre);
+        }
+        const float ig = gv[0], fg = gv[1], og = gv[2], ug = gv[3];
+        const float tc = tanhf(r.cn[k]);
+        const float dc = r.dci[k] + dh * og * (1.f - tc * tc);
+        da[k] = vfloat4{dc * ug * ig * (1.f - ig), dc * r.cp[k] * fg * (1.f - fg), dh * tc * og * (1.f - og), dc * ig * (1.f - ug * ug)};
+        a.dc_prev[o] = dc * fg;
+        vfloat4 xh, hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            xh[g] = (r.xv[k][g] - mx) * rx;
+            hh[g] = (r.hv[k][g] - mh) * rh;
+            const float dyx = da[k][g] * gxv[g], dyh = da[k][g] * ghv[g];
+            s[0] += dyx; s[1] += dyx * xh[g];
+            s[2] += dyh; s[3] += dyh * hh[g];
+        }
+        vfloat4* a0 = reinterpret_cast<vfloat4*>(acc + 4 * u);
+        vfloat4* a1 = reinterpret_cast<vfloat4*>(acc + G + 4 * u);
+        vfloat4* a2 = reinterpret_cast<vfloat4*>(acc + 2 * G + 4 * u);
+        *a0 += da[k];
+        *a1 += da[k] * xh;
+        *a2 += da[k] * hh;
+    }
+    block_allsum<4>(s, red);
+    const float inv_g = 1.f / (float)G;
+    const float a0 = s[0] * inv_g, a1 = s[1] * inv_g, a2 = s[2] * inv_g, a3 = s[3] * inv_g;
+#pragma unroll
+    for (int k = 0; k < kPermUnits; ++k) {
+        const int u = (int)threadIdx.x + 256 * k;
+        if (u >= H) continue;
+        const vfloat4 gxv = *reinterpret_cast<const vfloat4*>(pp + 4 * u);
+        const vfloat4 ghv = *reinterpret_cast<const vfloat4*>(pp + G + 4 * u);
+        vfloat4 ox, oh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float dyx = da[k][g] * gxv[g], dyh = da[k][g] * ghv[g];
+            ox[g] = rx * (dyx - a0 - (r.xv[k][g] - mx) * rx * a1);
+            oh[g] = rh * (dyh - a2 - (r.hv[k][g] - mh) * rh * a3);
+        }
+        __builtin_nontemporal_store(ox, reinterpret_cast<vfloat4*>(a.dxw + (size_t)b * G + 4 * u));
+        *reinterpret_cast<vfloat4*>(a.dhw + (size_t)b * G + 4 * u) = oh;   // read next by this step's dh product: keep it cached
+    }
+}
+__global__ __launch_bounds__(256) void lstm_cell_bwd_perm_rows_kernel(const CellBwdArgs a, const float* __restrict__ pp,
+                                                                      float* __restrict__ colacc, int acc_init, int B) {
+    __shared__ float red[16];
+    extern __shared__ __attribute__((aligned(16))) float acc[];   // [3][4H], interleaved columns
+    const int G = 4 * a.H;
+    float* mine = colacc + (size_t)blockIdx.x * 3 * G;
+    const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int r0 = (int)((long)blockIdx.x * B / gridDim.x), r1 = (int)((long)(blockIdx.x + 1) * B / gridDim.x);
+    for (int i = threadIdx.x * 4; i < 3 * G; i += 1024)
+        *reinterpret_cast<vfloat4*>(acc + i) = acc_init ? zero4 : *reinterpret_cast<const vfloat4*>(mine + i);
+    __syncthreads();
+    for (int b = r0; b < r1; ++b) {
+        PermRow r;
+        cell_bwd_perm_load(a, b, r);
+        cell_bwd_perm_compute(a, b, r, red, acc, pp);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x * 4; i < 3 * G; i += 1024)
+        *reinterpret_cast<vfloat4*>(mine + i) = *reinterpret_cast<const vfloat4*>(acc + i);
+}
+// pp[k][4u + g] = the k-th parameter vector (gamma_x, gamma_h, beta_x, beta_h, bias) at its standard position g*H + u
+__global__ __launch_bounds__(256) void perm_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ bias, float* __restrict__ pp, int H) {
+    const int q = blockIdx.x * 256 + threadIdx.x, G = 4 * H;
+    if (q >= G) return;
+    const int u = q >> 2, g = q & 3, col = g * H + u;
+    pp[q] = gamma[col];
+    pp[G + q] = gamma[G + col];
+    pp[2 * G + q] = beta[col];
+    pp[3 * G + q] = beta[G + col];
+    pp[4 * G + q] = bias[col];
 }
 
 // ------------------------------------------------------------------------------------------------ column reductions
@@ -709,14 +846,15 @@ __global__ __launch_bounds__(256) void lstm_colreduce_kernel(const float* __rest
 }
 __global__ __launch_bounds__(256) void lstm_colfinal_kernel(const float* __restrict__ partials, int chunks, int G,
                                                             float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= G) return;
+                                                            float* __restrict__ dbeta, int perm /* partial columns are gate-interleaved */) {
+    const int pc = blockIdx.x * 256 + threadIdx.x;   // position in the partials
+    if (pc >= G) return;
+    const int col = perm ? (pc & 3) * (G / 4) + (pc >> 2) : pc;
     float s[3] = {0.f, 0.f, 0.f};
 #pragma unroll 8   // 24 independent loads in flight per thread (512 chunks after the row-walking cell: 212 -> ~30 us)
     for (int c = 0; c < chunks; ++c)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s[k] += partials[((size_t)c * 3 + k) * G + col];
+        for (int k = 0; k < 3; ++k) s[k] += partials[((size_t)c * 3 + k) * G + pc];
     dbias[col] = s[0];
     dbeta[col] = s[0];
     dbeta[G + col] = s[0];
@@ -864,10 +1002,10 @@ inline bool cell_rows_shape(int B, int H) {
     return cell_recompute_gates(B, H) && H % 4 == 0 && H >= 768 && H <= 1024 && g_cell_rows_wgs > 0 && B >= 8 * g_cell_rows_wgs;
 }
 inline void launch_cell_bwd_rows(int B, int nwg, hipStream_t st, const CellBwdArgs& a, float* colacc, int acc_init,
-                                 bool perm = false) {
+                                 const float* pp = nullptr /* interleaved layout: its parameter table */) {
     const size_t lds = (size_t)3 * 4 * a.H * sizeof(float);
-    if (perm) hipLaunchKernelGGL(lstm_cell_bwd4_rows_kernel<true>, dim3(nwg), dim3(256), lds, st, a, colacc, acc_init, B);
-    else hipLaunchKernelGGL(lstm_cell_bwd4_rows_kernel<false>, dim3(nwg), dim3(256), lds, st, a, colacc, acc_init, B);
+    if (pp) hipLaunchKernelGGL(lstm_cell_bwd_perm_rows_kernel, dim3(nwg), dim3(256), lds, st, a, pp, colacc, acc_init, B);
+    else hipLaunchKernelGGL(lstm_cell_bwd4_rows_kernel, dim3(nwg), dim3(256), lds, st, a, colacc, acc_init, B);
 }
 
 }  // namespace
@@ -884,7 +1022,8 @@ struct Ws {
     LayerWs layer[16];
     float *pstash;   // bias (L,4H) then ln_beta (L,2,4H), parked by the forward for a gate-recomputing backward
     float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg, *wpart, *dwave, *whT, *wxT;
-    float *whP, *wxP, *blk_part, *blk_flags;   // gate-interleaved weight copies, row-block exchange (lstm_perm_shape only)
+    float *whP, *wxP, *blk_part, *blk_flags, *pperm;   // gate-interleaved weight copies, row-block exchange, interleaved
+                                                       // parameter table of the layer (lstm_perm_shape only)
     size_t total;
 };
 inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
@@ -922,6 +1061,7 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.wxP = take(perm ? (size_t)(I > H ? I : H) * G : 0);
     w.blk_part = take(perm ? block_part_floats(B, H) : 0);
     w.blk_flags = take(perm ? block_flag_words(B) : 0);
+    w.pperm = take(perm ? 5 * G : 0);
     {   // persistent small-batch paths: {value, tag} exchange words (per-layer kernels / layer wavefront)
         size_t words = xchg_layout(B, H).total_words;
         WaveCfg wc{};
@@ -1292,7 +1432,7 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
                                    (const float*)lw.stats, (long)SB, (int)G, w.colpart);
             hipLaunchKernelGGL(lstm_colfinal_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st,
                                (const float*)w.colpart, chunks, (int)G, dbias + (size_t)l * G,
-                               dln_gamma + (size_t)l * 2 * G, dln_beta + (size_t)l * 2 * G);
+                               dln_gamma + (size_t)l * 2 * G, dln_beta + (size_t)l * 2 * G, perm ? 1 : 0);
         }
     };
     WaveCfg wb{};
@@ -1319,6 +1459,9 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
         if (perm) {   // this layer's interleaved weight copies (the forward's were overwritten by the layers above)
             launch_perm_cols(wh + (size_t)l * H * G, w.whP, H, H, st);
             launch_perm_cols(wx + wx_offs[l], w.wxP, l == 0 ? I : H, H, st);
+            hipLaunchKernelGGL(perm_params_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, ln_gamma + (size_t)l * 2 * G,
+                               (const float*)(w.pstash + (size_t)L * G + (size_t)l * 2 * G), (const float*)(w.pstash + (size_t)l * G),
+                               w.pperm, H);
         }
         const float* wh_l = perm ? (const float*)w.whP : wh + (size_t)l * H * G;
         const float* gamma_l = ln_gamma + (size_t)l * 2 * G;
@@ -1355,7 +1498,7 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
                                  lw.stats + (size_t)s * B * 4, gamma_l, w.pstash + (size_t)L * G + (size_t)l * 2 * G,
                                  w.pstash + (size_t)l * G, w.dgate + (size_t)s * B * G, w.dxw + (size_t)s * B * G,
                                  w.dhw + (size_t)s * B * G, w.dc, H};
-            if (rows_wgs) launch_cell_bwd_rows(B, rows_wgs, st, ca, w.colpart, s == S - 1 ? 1 : 0, perm);
+            if (rows_wgs) launch_cell_bwd_rows(B, rows_wgs, st, ca, w.colpart, s == S - 1 ? 1 : 0, perm ? w.pperm : nullptr);
             else launch_cell_bwd(B, st, ca);
             // dh_prev (B,H) = dHW_s (B,G) @ Wh^T, as an NN product against the transposed copy
             GemmArgs g{w.dhw + (size_t)s * B * G, nn_dh ? (const float*)w.whT : wh_l, w.dh, B, H, (int)G, (long)G, 1,

@@ -8,8 +8,19 @@ import sqlite3
 import sys
 con = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in con.execute("pragma table_info(kernels)").fetchall()]
-grid = next((c for c in ("grid_size", "grid_size_x", "grid_x") if c in cols), None)
-wg = next((c for c in ("workgroup_size", "workgroup_size_x", "workgroup_x") if c in cols), None)
+print("columns of `kernels`:", cols)
+
+
+def dims(stem):
+    """SQL expression for the product of the x / y / z extents named <stem>[_x|_y|_z] (whatever subset exists)."""
+    have = [c for c in (f"{stem}_x", f"{stem}_y", f"{stem}_z") if c in cols]
+    if have:
+        return "(" + " * ".join(f"max({c}, 1)" if False else c for c in have) + ")"
+    return stem if stem in cols else None
+
+
+grid = dims("grid_size") or dims("grid")
+wg = dims("workgroup_size") or dims("workgroup")
 sel = "name" + (f", {grid}" if grid else ", 0") + (f", {wg}" if wg else ", 0")
 rows = con.execute(f"select {sel}, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
                    f"group by {sel} order by sum(duration) desc").fetchall()
