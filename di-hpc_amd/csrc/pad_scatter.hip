@@ -231,6 +231,99 @@ __global__ __launch_bounds__(256) void pad1d_packed_kernel(const float* __restri
     }
 }
 
+// Round 4: WAVE-synchronous tiles in OUTPUT space (tests/tools/micro/padbw.hip: 226 us = 6.2 TB/s at n = 2^20, L = 127, where
+// the workgroup kernel above takes 276-293 and two plain fills of the outputs 159).  A wave owns 1024 consecutive elements
+// (256 aligned quads) of the flat (n * L) output stream, whatever rows they fall in.  Because the rows are packed, the source
+// of those elements is ONE contiguous span of at most 1024 floats: staged into the wave's own LDS slice with aligned
+// 16-byte loads -- no workgroup barrier, no ragged quads at tile ends (only the very last quad of the tensor can be
+// partial), one float multiply instead of a division per quad and two row lookups per quad instead of two per element.
+// Row of a quad: t = c_lo + 4 q < 1024 + L, rr = (int)((t + 0.5) * (1 / L)) in fp32 -- exact: (t + 0.5) / L is at least
+// 0.5 / L away from an integer and the rounding error is below 4 (1024 + L) / L * 2^-24 < 0.5 / L for L <= 16384.
+// 32 <= L <= 16384 (at most 34 rows per tile); same results as pad1d_packed_kernel bit for bit.
+__global__ __launch_bounds__(256) void pad1d_packed_wave_kernel(const float* __restrict__ flat, const int64_t* __restrict__ table,
+                                                                float* __restrict__ new_x, int32_t* __restrict__ mask, long n,
+                                                                unsigned L, float inv_l, float fill, int ifill) {
+    typedef int vint4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float tile_all[4][1032];
+    __shared__ int s_rel_all[4][40], s_len_all[4][40];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* const tile = tile_all[wv];
+    int* const s_rel = s_rel_all[wv];
+    int* const s_len = s_len_all[wv];
+    const uintptr_t base = reinterpret_cast<uintptr_t>(flat);
+    const unsigned long total = (unsigned long)n * L;
+    const long ntiles = (long)((total + 1023) / 1024);
+    for (long w = (long)blockIdx.x * 4 + wv; w < ntiles; w += (long)gridDim.x * 4) {
+        const unsigned long o0 = (unsigned long)w * 1024, o1 = o0 + 1024 < total ? o0 + 1024 : total;
+        const long r_lo = (long)(o0 / L), r_hi = (long)((o1 - 1) / L);
+        const unsigned c_lo = (unsigned)(o0 - (unsigned long)r_lo * L), c_hi = (unsigned)(o1 - 1 - (unsigned long)r_hi * L);
+        const int nr = (int)(r_hi - r_lo + 1);
+        long my_off = 0;
+        int my_len = 0;
+        if (lane < nr) {
+            const int64_t* e = table + (size_t)(r_lo + lane) * 4;
+            my_off = (long)(((uintptr_t)e[0] - base) >> 2);
+            const int64_t l = e[3];
+            my_len = (int)(l < (int64_t)L ? l : (int64_t)L);   // a length beyond max_len (unchecked precondition) is truncated
+        }
+        const long off_lo = __shfl(my_off, 0, 64), off_hi = __shfl(my_off, nr - 1, 64);
+        const int len_lo = __shfl(my_len, 0, 64), len_hi = __shfl(my_len, nr - 1, 64);
+        const long span_lo = off_lo + ((int)c_lo < len_lo ? (int)c_lo : len_lo);
+        const long span_hi = off_hi + ((int)c_hi + 1 < len_hi ? (int)c_hi + 1 : len_hi);
+        // 16-byte chunks aligned by ADDRESS: the first / last chunk may reach up to 12 bytes outside [span_lo, span_hi) but
+        // never across a page, and each contains a valid element: the read cannot fault, the extra lanes are never used
+        const long lo4 = span_lo - (long)(((base >> 2) + (unsigned long)span_lo) & 3UL);
+        // rows truncated to L keep the span <= 1024 floats; a table whose offsets are not the packed ones (hand-made) could
+        // exceed the slice: such a tile reads its elements straight from memory
+        const bool fits = span_hi - lo4 <= 1028 && span_hi >= span_lo;
+        if (lane <= nr) {
+            s_rel[lane] = lane < nr ? (int)(my_off - lo4) : 0;
+            s_len[lane] = lane < nr ? my_len : 0;
+        }
+        if (fits) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const long p = lo4 + 4 * (long)(lane + 64 * j);
+                if (p < span_hi) *reinterpret_cast<vfloat4*>(tile + 4 * (lane + 64 * j)) = *reinterpret_cast<const vfloat4*>(flat + p);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // (same-wave LDS operations execute in order: the slice is visible below)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = lane + 64 * j;
+            const unsigned long o = o0 + 4 * (unsigned long)q;
+            if (o >= o1) break;
+            const unsigned t = c_lo + 4 * (unsigned)q;
+            const unsigned rr = (unsigned)(((float)t + 0.5f) * inv_l);
+            const unsigned c = t - rr * L;
+            const int rel0 = s_rel[rr], len0 = s_len[rr], rel1 = s_rel[rr + 1], len1 = s_len[rr + 1];
+            vfloat4 v;
+            vint4 mk;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned cc = c + k;
+                const bool nxt = cc >= L;
+                if (nxt) cc -= L;
+                const int ln = nxt ? len1 : len0, rl = nxt ? rel1 : rel0;
+                const bool in = (int)cc < ln;
+                float val = fill;
+                if (in) val = fits ? tile[rl + (int)cc] : flat[lo4 + rl + (int)cc];
+                v[k] = val;
+                mk[k] = in ? 1 : ifill;
+            }
+            if (o + 4 <= o1) {
+                __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(new_x + o));
+                __builtin_nontemporal_store(mk, reinterpret_cast<vint4*>(mask + o));
+            } else {   // the last quad of the tensor when n * L is no multiple of 4
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (o + k < o1) { new_x[o + k] = v[k]; mask[o + k] = mk[k]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next tile
+    }
+}
+
 // Inverse: the workgroup's RB padded rows are read as 16-byte quads, their valid prefixes collected in LDS at their
 // packed positions, and the contiguous span of `flat` is written with aligned 16-byte stores (element-wise at the two
 // ragged ends, which belong to the neighbouring workgroups).  table rows {flat offset (elements), 1, 1, length}.
@@ -414,10 +507,21 @@ __global__ __launch_bounds__(256) void packed_scan_sums_kernel(int64_t* __restri
     }
 }
 
+// RAW_SUMS: `sums` holds the chunk totals as packed_chunk_sums_kernel left them (no scan launch in between): the workgroup
+// adds up the chunks before its own (<= 1024 of them; one dependent launch and its gap less, ~8 us of a 280 us pad call)
+template <bool RAW_SUMS>
 __global__ __launch_bounds__(256) void packed_table_kernel(const int64_t* __restrict__ lengths, long n,
                                                            const int64_t* __restrict__ sums, int64_t base,
                                                            int64_t stride, int64_t* __restrict__ table) {
     __shared__ int64_t lds[4];
+    int64_t before = 0;
+    if (RAW_SUMS) {
+        int64_t v = 0;
+        for (long j = threadIdx.x; j < (long)blockIdx.x; j += 256) v += sums[j];
+        (void)block_incl_scan_i64(v, lds, &before);
+    } else {
+        before = sums[blockIdx.x];
+    }
     // thread t owns 8 CONSECUTIVE elements so that its serial prefix is cheap
     const long first = (long)blockIdx.x * kScanChunk + (long)threadIdx.x * 8;
     int64_t len[8];
@@ -428,7 +532,7 @@ __global__ __launch_bounds__(256) void packed_table_kernel(const int64_t* __rest
         s += len[k];
     }
     int64_t total;
-    int64_t off = sums[blockIdx.x] + block_incl_scan_i64(s, lds, &total) - s;
+    int64_t off = before + block_incl_scan_i64(s, lds, &total) - s;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (first + k < n) {
@@ -699,6 +803,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __
 }  // namespace
 }  // namespace hpc_rll
 
+namespace hpc_rll { int g_pad_wave = 1; }   // hpc_rll_tune_set key 28: packed Pad1D on wave tiles in output space (0 = the round-3 workgroup kernel)
 namespace hpc_rll { int g_scatter_threads = 1024; int g_scatter_bwd_lds_kb = 64; int g_scatter_lds_fwd = 1; int g_scatter_npb = 0; }
 using namespace hpc_rll;
 
@@ -763,6 +868,14 @@ extern "C" int hpc_rll_pad1d_packed_forward(const float* flat, const int64_t* ta
     const bool ok = RB >= 1 && (reinterpret_cast<uintptr_t>(new_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(flat) & 3) == 0;
     if (!ok) return hpc_rll_pad_forward(table, new_x, mask, n, 1, 1, max_len, value, stream);
+    if (max_len >= 32 && max_len <= 16384 && g_pad_wave) {   // wave tiles in output space (round 4)
+        const long ntiles = (long)(((unsigned long)n * (unsigned long)max_len + 1023) / 1024);
+        long wb = (ntiles + 3) / 4;
+        if (wb > 8192) wb = 8192;
+        hipLaunchKernelGGL(pad1d_packed_wave_kernel, dim3((unsigned)wb), dim3(256), 0, (hipStream_t)stream, flat, table, new_x, mask,
+                           (long)n, (unsigned)max_len, 1.0f / (float)max_len, (float)value, value);
+        return last_error();
+    }
     long blocks = (n + RB - 1) / RB;
     if (blocks > (1L << 20)) blocks = 1L << 20;
     const size_t lds = ((((size_t)RB * max_len + 8 + 1) & ~(size_t)1)) * 4 + (size_t)(RB + 1) * 8;
@@ -800,8 +913,13 @@ extern "C" int hpc_rll_packed_table(const int64_t* lengths, int64_t n, int64_t b
     if (nchunks > 0x7fffffffL) return HPC_RLL_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(packed_chunk_sums_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, lengths, (long)n, scratch);
+    if (nchunks <= 1024) {
+        hipLaunchKernelGGL(packed_table_kernel<true>, dim3((unsigned)nchunks), dim3(256), 0, st, lengths, (long)n, scratch, base,
+                           stride, table);
+        return last_error();
+    }
     hipLaunchKernelGGL(packed_scan_sums_kernel, dim3(1), dim3(256), 0, st, scratch, nchunks);
-    hipLaunchKernelGGL(packed_table_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, lengths, (long)n, scratch, base,
+    hipLaunchKernelGGL(packed_table_kernel<false>, dim3((unsigned)nchunks), dim3(256), 0, st, lengths, (long)n, scratch, base,
                        stride, table);
     return last_error();
 }

@@ -153,6 +153,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * (lstm_block.hpp); 0 = one product + one cell launch per step (same layout, same saved tensors); set before the forward.
  * key 27: start skew of that kernel's row blocks in microseconds (0 ... 200, default 0): row block r waits r x this
  * before its first step, which spreads the HBM-bound epilogues of the row blocks over the step.
+ * key 28: packed Pad1D (hpc_rll_pad1d_packed_forward, 32 <= max_len <= 16384): 1 (default) = wave-synchronous tiles of 1024
+ * consecutive OUTPUT elements (their packed source is one contiguous span, staged through the wave's own LDS slice);
+ * 0 = the round-3 kernel (16 rows per workgroup).  Identical results.
  */
 int hpc_rll_tune_set(int key, int value);
 

@@ -160,6 +160,25 @@ def suite_c3(T=256, B=16384, N=128):
     t_f, t_b = fwd_bwd(lambda: m(value, reward, weight), [value])
     report("td_lambda", shape, t_f, 16 * TB, t_b, 8 * TB)
     add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(value, reward, weight), [value]), (16 * TB, 8 * TB)) for x in pair])
+    # The torch-side floor of a `.backward()` call on this box, in this process: the smallest possible
+    # op through the autograd engine with the same output size -- y = 2 x on a (T+1, B) tensor, backward = ONE elementwise
+    # kernel of torch's own (8 T B bytes, the same traffic as TD-lambda's backward kernel).  What TD-lambda's API-level
+    # backward takes beyond this is the library's; the rest is the engine handing the graph task to its device thread and
+    # back.  The kernel-level reading (hipGraph replay) is listed beside it.
+    yy = value * 2.0
+    gg = torch.ones_like(yy)
+
+    def floor_bwd():
+        value.grad = None
+        yy.backward(gg, retain_graph=True)
+
+    t_floor = timed(floor_bwd)
+    rows[-1].update(autograd_floor_bwd_ms=t_floor * 1e3, bwd_over_autograd_floor_ms=(t_b - t_floor) * 1e3,
+                    autograd_floor_note="y = 2*x on a (T+1,B) tensor, y.backward(): torch's own single elementwise kernel "
+                                        "through the same engine, same process, same box")
+    if not QUIET:
+        print(json.dumps(rows[-1]), flush=True)
+    del yy, gg
     m = VTrace(T, B, N)
     t_f, t_b = fwd_bwd(lambda: sum(m(target, behaviour, action, value, reward)), [target, value])
     # algorithmic minimum: two logits reads (+ action + O(TB)) forward; logits read + grad write backward

@@ -102,6 +102,73 @@ __global__ __launch_bounds__(256) void lds_kernel(const float* __restrict__ flat
     }
 }
 
+// round 4: WAVE-synchronous tiles in OUTPUT space.  A wave owns 1024 consecutive output elements (256 aligned quads) of the
+// flat (n*L) output stream -- whatever rows they fall in; the packed source of those elements is ONE contiguous span of at
+// most 1024 floats, staged into the wave's own LDS slice with aligned 16-byte loads; no workgroup barrier, no ragged
+// quads, one float division per quad (exact: see the product kernel), two row lookups per quad.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void wave_kernel(const float* __restrict__ flat, const long* __restrict__ off,
+                                                   const int* __restrict__ len_, float* __restrict__ x, int* __restrict__ m,
+                                                   long n, unsigned L, float invL) {
+    __shared__ __attribute__((aligned(16))) float tile_all[4][1032];
+    __shared__ int s_rel_all[4][48], s_len_all[4][48];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* tile = tile_all[wv];
+    int* s_rel = s_rel_all[wv];
+    int* s_len = s_len_all[wv];
+    const unsigned long total = (unsigned long)n * L;
+    const long ntiles = (long)((total + 1023) / 1024);
+    for (long w = (long)blockIdx.x * 4 + wv; w < ntiles; w += (long)gridDim.x * 4) {
+        const unsigned long o0 = (unsigned long)w * 1024, o1 = o0 + 1024 < total ? o0 + 1024 : total;
+        const long r_lo = (long)(o0 / L), r_hi = (long)((o1 - 1) / L);
+        const unsigned c_lo = (unsigned)(o0 - (unsigned long)r_lo * L), c_hi = (unsigned)(o1 - 1 - (unsigned long)r_hi * L);
+        const int nr = (int)(r_hi - r_lo + 1);
+        long my_off = 0; int my_len = 0;
+        if (lane < nr) { my_off = off[r_lo + lane]; my_len = len_[r_lo + lane]; }
+        const long off_lo = __shfl(my_off, 0, 64), off_hi = __shfl(my_off, nr - 1, 64);
+        const int len_lo = __shfl(my_len, 0, 64), len_hi = __shfl(my_len, nr - 1, 64);
+        const long span_lo = off_lo + ((int)c_lo < len_lo ? (int)c_lo : len_lo);
+        const long span_hi = off_hi + ((int)c_hi + 1 < len_hi ? (int)c_hi + 1 : len_hi);
+        const long lo4 = span_lo & ~3L;
+        if (lane < nr) { s_rel[lane] = (int)(my_off - lo4); s_len[lane] = my_len; }
+        if (lane == nr) { s_rel[lane] = 0; s_len[lane] = 0; }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const long p = lo4 + 4 * (long)(lane + 64 * j);
+            if (p < span_hi) *reinterpret_cast<vfloat4*>(tile + 4 * (lane + 64 * j)) = *reinterpret_cast<const vfloat4*>(flat + p);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = lane + 64 * j;
+            const unsigned long o = o0 + 4 * (unsigned long)q;
+            if (o >= o1) break;
+            const unsigned t = c_lo + 4 * (unsigned)q;
+            const unsigned rr = (unsigned)(((float)t + 0.5f) * invL);
+            const unsigned c = t - rr * L;
+            const int rel0 = s_rel[rr], len0 = s_len[rr], rel1 = s_rel[rr + 1], len1 = s_len[rr + 1];
+            vfloat4 v; vint4 mk;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned cc = c + k;
+                const bool nxt = cc >= L;
+                if (nxt) cc -= L;
+                const int ln = nxt ? len1 : len0, rl = nxt ? rel1 : rel0;
+                const bool in = (int)cc < ln;
+                v[k] = in ? tile[rl + (int)cc] : 0.f;
+                mk[k] = in ? 1 : 0;
+            }
+            if (o + 4 <= o1) {
+                __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(x + o));
+                __builtin_nontemporal_store(mk, reinterpret_cast<vint4*>(m + o));
+            } else {
+                for (int k = 0; k < 4; ++k) if (o + k < o1) { x[o + k] = v[k]; m[o + k] = mk[k]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- the product kernel, verbatim (di-hpc_amd/csrc/pad_scatter.hip)
 __global__ __launch_bounds__(256) void pad1d_packed_kernel(const float* __restrict__ flat, const int64_t* __restrict__ table,
                                                            float* __restrict__ new_x, int32_t* __restrict__ mask, long n,
@@ -214,6 +281,24 @@ int main() {
             const size_t lds = ((((size_t)RB * L + 8 + 1) & ~(size_t)1)) * 4 + (size_t)(RB + 1) * 8;
             float t = timeit([&] { hipLaunchKernelGGL(pad1d_packed_kernel, dim3(g), dim3(256), lds, 0, flat, (const int64_t*)dtab, x, m, n, L, inv, RB, 0.f, 0); });
             printf("product kernel RB=%d grid %d: %.1f us (%.0f GB/s)\n", RB, g, t, by / t / 1e3);
+        }
+    }
+    {   // round 4: wave tiles in output space; verified against the LDS-staged kernel's output
+        std::vector<float> hx((size_t)n * L), hx2((size_t)n * L); std::vector<int> hm((size_t)n * L), hm2((size_t)n * L);
+        std::vector<float> hf(tot + 64);
+        for (long i = 0; i < tot; ++i) hf[i] = (float)(i % 9973) + 0.5f;
+        hipMemcpy(flat, hf.data(), (tot + 64) * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(lds_kernel<16>, dim3(8192), dim3(256), (16 * L + 8) * 4, 0, flat, doff, dlen, x, m, n, L, inv);
+        hipMemcpy(hx.data(), x, (size_t)n * L * 4, hipMemcpyDeviceToHost); hipMemcpy(hm.data(), m, (size_t)n * L * 4, hipMemcpyDeviceToHost);
+        hipMemset(x, 0xff, (size_t)n * L * 4); hipMemset(m, 0xff, (size_t)n * L * 4);
+        hipLaunchKernelGGL(wave_kernel<0>, dim3(8192), dim3(256), 0, 0, flat, doff, dlen, x, m, n, L, 1.0f / L);
+        hipMemcpy(hx2.data(), x, (size_t)n * L * 4, hipMemcpyDeviceToHost); hipMemcpy(hm2.data(), m, (size_t)n * L * 4, hipMemcpyDeviceToHost);
+        long bad = 0;
+        for (size_t i = 0; i < (size_t)n * L; ++i) if (hx[i] != hx2[i] || hm[i] != hm2[i]) ++bad;
+        printf("wave kernel vs LDS-staged kernel: %ld mismatching elements of %zu\n", bad, (size_t)n * L);
+        for (int g : {2048, 4096, 8192, 16384, 65536}) {
+            float t = timeit([&] { hipLaunchKernelGGL(wave_kernel<0>, dim3(g), dim3(256), 0, 0, flat, doff, dlen, x, m, n, L, 1.0f / L); });
+            printf("wave tiles in output space, grid %6d: %.1f us (%.0f GB/s)\n", g, t, by / t / 1e3);
         }
     }
     float f = timeit([&] { hipMemsetAsync(x, 0, n * L * 4, 0); hipMemsetAsync(m, 0, n * L * 4, 0); });
