@@ -350,7 +350,10 @@ def test_lstm_dropout(B):
 
 @pytest.mark.parametrize("S,B,I,H,L", [(64, 3, 1792, 384, 3), (9, 8, 40, 1024, 2), (7, 5, 12, 1000, 2), (5, 1, 7, 65, 1),
                                        (12, 2, 16, 257, 2), (4, 7, 5, 3, 3), (3, 4, 8, 512, 1), (1, 2, 6, 20, 3),
-                                       (2, 1, 3, 5, 2), (33, 4, 9, 130, 4), (5, 3, 4, 512, 2)])
+                                       (2, 1, 3, 5, 2), (33, 4, 9, 130, 4), (5, 3, 4, 512, 2),
+                                       # mid-batch shapes of the latency table (tests/tools/r04_lstm_mid_table.py): step path
+                                       # in both runs, pinned against the fp64 oracle like the others
+                                       (6, 64, 32, 1024, 1), (5, 256, 48, 512, 2), (4, 16, 40, 384, 1)])
 def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
     """B <= 4 runs the persistent kernels (lstm_persist.hpp / lstm_wave.hpp; the B > 4 cases here exercise the step path twice); hpc_rll_tune_set(3, 0) forces the step-kernel
     path (GEMM + cell kernel per step).  Same math, different summation order in the recurrent products, and fp32
