@@ -1117,6 +1117,7 @@ extern "C" int64_t hpc_rll_lstm_workspace_y_offset(int S, int B, int I, int H, i
 
 namespace hpc_rll { namespace {
 std::atomic<int> g_lstm_last_path{-1};   // hpc_rll_lstm_last_forward_path (diagnostic)
+std::atomic<int> g_lstm_last_bwd_path{-1};   // hpc_rll_lstm_last_backward_path
 // y_hseq: y doubles as the last layer's h sequence (the caller hands the SAME y to the backward, which reads it there):
 // the cells write y directly, the workspace's own slot for it stays unused, no (S,B,H) copy.
 int lstm_forward_impl(const float* x, const float* h0, const float* c0, const float* wx,
@@ -1437,6 +1438,7 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
     };
     WaveCfg wb{};
     if (w.dwave && wave_bwd_ok(S, B, H, L, &wb, st)) {   // all layers in one launch (lstm_wave.hpp)
+        g_lstm_last_bwd_path.store(2, std::memory_order_relaxed);
         const size_t words = 2 * wb.hx_words + wb.sx_words;
         if (hipMemsetAsync(w.xchg, 0, words * sizeof(u64), st) != hipSuccess) return last_error();
         const LayerWs& l0 = w.layer[0];
@@ -1490,7 +1492,16 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
                              : (!persist && cell_rows_shape(B, H) && cell_al16(d_out) &&
                               cell_al16(dhn) && cell_al16(dcn) && cell_al16(c0) && cell_al16(ws) && cell_al16(ln_gamma))
                                  ? (B < g_cell_rows_wgs ? B : g_cell_rows_wgs) : 0;
-        for (int s = S - 1; s >= 0 && !persist; --s) {
+        // large batches on the interleaved layout: the whole backward recurrence of the layer in one persistent kernel
+        const bool blockb = perm && !persist && block_bwd_ok(B, H, st);
+        g_lstm_last_bwd_path.store(persist ? 1 : blockb ? 4 : perm ? 3 : 0, std::memory_order_relaxed);
+        if (blockb) {
+            BlockBwd ba{d_out, dh_carry, dc_carry, lw.xw, lw.hw, lw.c, c0 + (size_t)l * BH, lw.stats, w.pperm, w.whP, w.dxw, w.dhw,
+                        w.dgate, w.dc, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, nullptr, nullptr, nullptr, S, B, H, 0, 0, 0, nullptr};
+            const int brc = launch_block_bwd(ba, w.blk_part, reinterpret_cast<unsigned*>(w.blk_flags), w.colpart, st);
+            if (brc) return brc;
+        }
+        for (int s = S - 1; s >= 0 && !persist && !blockb; --s) {
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
             const CellBwdArgs ca{d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dh_parts, (long)BH, dc_carry,
                                  lw.gates ? (const float*)(lw.gates + (size_t)s * B * G) : (const float*)nullptr,
@@ -1510,13 +1521,13 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
         }
         int rc = last_error();
         if (rc) return rc;
-        if (!persist) {
+        if (!persist && !blockb) {
             hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((BH + 255) / 256)), dim3(256), 0, st,
                                (const float*)w.dh, dh_parts, (long)BH, dh0 + (size_t)l * BH);
             if ((rc = copy_async(dc0 + (size_t)l * BH, w.dc, BH, st))) return rc;
         }
         float* dxin = l == 0 ? dx : seq_bufs[flip];
-        layer_grads(l, w.dgate, w.dxw, w.dhw, dxin, rows_wgs);
+        layer_grads(l, w.dgate, w.dxw, w.dhw, dxin, blockb ? B / 128 : rows_wgs);
         if (l > 0) {
             if (dropout_p > 0.f) {   // backward of the dropout between layer l-1 and l: same mask, same scale
                 const long n = (long)(SB * H);
@@ -1556,6 +1567,8 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
 // 2 = layer wavefront (B <= 4, L >= 2), 3 = step kernels on gate-interleaved pre-activations (large batch), 4 = persistent
 // row-block kernel (large batch, lstm_block.hpp); -1 = no forward yet.
 extern "C" int hpc_rll_lstm_last_forward_path(void) { return g_lstm_last_path.load(std::memory_order_relaxed); }
+// ... and the most recent hpc_rll_lstm_backward* call (last layer processed): same codes.
+extern "C" int hpc_rll_lstm_last_backward_path(void) { return g_lstm_last_bwd_path.load(std::memory_order_relaxed); }
 
 // The pair a framework binding uses (ABI 4): y is the caller's own (S,B,H) tensor AND the last layer's saved h sequence.
 // The forward's cells write it directly (no copy, nothing of the workspace is handed out), the backward gets the same y

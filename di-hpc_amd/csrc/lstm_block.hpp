@@ -33,8 +33,9 @@
 #include "wave.hpp"
 
 namespace hpc_rll {
-int g_lstm_block = 1;        // hpc_rll_tune_set key 26: 0 = step kernels (same layout); bit 0 = persistent row-block forward,
-                             // bit 1 = 128-row blocks (two workgroups per CU), bit 2 = libm gate functions
+int g_lstm_block = 9;        // hpc_rll_tune_set key 26: 0 = step kernels (same layout); bit 0 = persistent row-block forward,
+                             // bit 1 = 128-row blocks (two workgroups per CU), bit 2 = libm gate functions (forward),
+                             // bit 3 = persistent row-block backward, bit 4 = its k-depth 16 instead of 32
 int g_lstm_block_skew = 10;  // hpc_rll_tune_set key 27: microseconds between the starts of consecutive row blocks (C4: 69.9 -> 65.9 ms)
 namespace {
 
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(128 * MW, 2) void lstm_block_fwd_kernel(const Block
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values live in scalar registers: row
     const int wm = wave % MW, wn = wave / MW, h = lane >> 5, i32 = lane & 31;   // addresses = scalar base + per-lane offset
+    const float* const slp = sl + (wm * 64 + 4 * h) * 4;   // the lane's row records: one address + compile-time offsets
     const int rbl = (int)blockIdx.x / a.nct, ct = (int)blockIdx.x % a.nct;
     const int H = a.H, G = 4 * H, nct = a.nct;
     const long row0 = (long)(a.rb0 + rbl) * BM;   // first batch row of the row block
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(128 * MW, 2) void lstm_block_fwd_kernel(const Block
                 for (int q = 0; q < kRC; ++q) {
                     const int r = (ci * kRC + q) & 15, i = (ci * kRC) >> 4;
                     const int R = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(sl + (R + 4 * h) * 4);
+                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(slp + (i * 32 + (r & 3) + 8 * (r >> 2)) * 4);
                     float pre[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -364,7 +366,10 @@ template <int MW> inline int block_rows_per_launch(int H) {
     return nct > 0 ? cus * BlkCfg<MW>::wgs_per_cu / nct : 0;
 }
 // (sized for the 128-row blocks: the larger of the two tilings)
-inline size_t block_part_floats(int B, int H) { return (size_t)(B / 128) * 2 * 2 * (4 * H / 256) * 128 * 2; }
+inline size_t block_part_floats(int B, int H) {   // the larger of the forward's and the backward's exchange buffers
+    const size_t f = (size_t)(B / 128) * 2 * 2 * (4 * H / 256) * 128 * 2, b = (size_t)(B / 128) * 2 * 4 * ((H + 127) / 128) * 128 * 4;
+    return f > b ? f : b;
+}
 inline size_t block_flag_words(int B) { return (size_t)(B / 128) * 2; }
 
 // g_lstm_block: 0 off; bit 0 = on; bit 1 = 128-row blocks, two workgroups per CU (else 256-row blocks, one per CU);
@@ -410,6 +415,414 @@ inline int launch_block_fwd(const BlockFwd& a, float* part, unsigned* flags, hip
     if (block_mw() == 4)
         return block_fast() ? launch_block_fwd_t<4, true>(a, part, flags, st) : launch_block_fwd_t<4, false>(a, part, flags, st);
     return block_fast() ? launch_block_fwd_t<2, true>(a, part, flags, st) : launch_block_fwd_t<2, false>(a, part, flags, st);
+}
+
+// ---- epilogue memory operations as BUFFER instructions: address = descriptor (4 scalar registers, the array's base for this
+// step and row block) + a per-lane byte offset that never changes (the lane's unit / row-half) + a scalar byte offset (the
+// wave-uniform row).  With flat global addressing the compiler hoisted the 64-bit address of every (array, row) pair of the
+// unrolled epilogue out of the step loop -- 11 arrays x 32 rows x 2 registers -- and the backward kernel spilled 800
+// registers; in this form no vector register holds an address at all.  AUX 2 = streaming (nontemporal) hint.
+typedef unsigned int blk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t blk_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+template <int AUX> __device__ __forceinline__ vfloat4 blk_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(vfloat4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
+}
+template <int AUX> __device__ __forceinline__ float blk_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX));
+}
+template <int AUX> __device__ __forceinline__ void blk_st4(vfloat4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(blk_u32x4, v), r, (int)voff, (int)soff, AUX);
+}
+template <int AUX> __device__ __forceinline__ void blk_st1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, AUX);
+}
+
+// ================================================================================================== backward
+// The backward recurrence of a layer in ONE kernel (tune key 26 bit 3).  Per step (time runs backwards):
+//     dh_s = dy_s + dHW_{s+1} @ Wh^T                 (M = B, N = H, K = 4H: the product)
+//     cell adjoint of (dh_s, dc) -> da (4 gates), both LayerNorm adjoints -> dXW_s, dHW_s, dc
+// which the step path runs as one product launch (256 us at C4) + one HBM-bound cell launch (103 us) that cannot overlap.
+// Here: tile = 128 batch rows x 128 hidden units with the FULL K (no split-K partials to exchange), both operands
+// k-contiguous (dHW rows; the rows of the gate-interleaved Wh copy as they lie) = the NT LDS-DMA loop of gemm_f32_kernel
+// (raw rows, k convention of DmaStage), 8 waves of 64 x 32, one workgroup per CU; a lane ends up with dh of ONE hidden unit for
+// 32 rows, so the cell adjoint is lane-local: its inputs are that unit's four gates of xw / hw (one float4 each).  A row
+// block (128 rows) is covered by nnt = H / 128 workgroups, which meet twice per step:
+//   (1) the four LayerNorm-adjoint row sums (sum dy_g, sum dy_g xhat, for both branches) over all 4H columns: every wave
+//       publishes its partial over its 32 units, all combine;
+//   (2) dHW_s complete: it is the next step's A operand (all 4H columns of the row block).
+// The gate adjoints of a lane's 32 (row, unit) pairs cross exchange (1) through a scratch buffer (written before, read back
+// after, together with xw / hw: an L2 round trip -- held in registers they cost 128 of the 256 and the kernel spilled
+// 900); dc travels through the (B, H) buffer the step path uses (read-modify-write by the same lane every step); the bias / gamma / beta column sums are accumulated in registers over ALL steps (a lane owns its unit's
+// four gate columns for the whole sequence) and reduced once at the end -> colacc[row block][3][4H] for
+// lstm_colfinal_kernel.  Gates are recomputed with the epilogue's own forms (blk_sigmoid / blk_tanh).
+struct BlockBwd {
+    const float *dy, *dhn, *dcn;        // (S,B,H) / (B,H) / (B,H); each may be null (= zero)
+    const float *xw, *hw;               // (S,B,4H) gate-interleaved, as the forward saved them
+    const float *c, *c0;                // (S,B,H), (B,H)
+    const float* stats;                 // (S,B,4)
+    const float* pp;                    // [5][4H] interleaved parameters: gamma_x, gamma_h, beta_x, beta_h, bias
+    const float* whp;                   // (H, 4H) Wh with gate-interleaved columns
+    float *dxw, *dhw;                   // (S,B,4H) gate-interleaved
+    float* dgate;                       // (S,B,4H) scratch: the gate adjoints between the two passes of a step (L2 round trip)
+    float *dc, *dh0, *dc0;              // (B,H) each; dc: scratch carried from step to step
+    float* colacc;                      // [row blocks of this launch][3][4H] interleaved column sums
+    float* part;                        // [row blocks of this launch][2][4 nnt][128][4]
+    unsigned* flags;                    // [row blocks of this launch][2]
+    int S, B, H, rb0, nnt;
+    int skew_ticks;
+    u64* prof;
+};
+
+template <int BK> struct BlkBwdCfg {
+    static constexpr int BM = 128, BN = 128, NTH = 512;
+    static constexpr int tile_floats = 2 * BK * BM + 2 * BK * BN < 32 * NTH ? 32 * NTH : 2 * BK * BM + 2 * BK * BN;   // operand tiles; also
+                                                                                    // the accumulator dump [32][NTH] of the epilogue
+    static constexpr int lds_floats = tile_floats + BM * 4 + BM * 4 + 3 * 4 * BN;   // + stats, sums, column sums
+    static constexpr size_t lds_bytes = 96 * 1024;   // one workgroup per CU
+    static_assert(lds_floats * sizeof(float) <= lds_bytes, "row-block backward LDS");
+};
+
+constexpr int kRCB = 2;   // rows per load chunk of the backward epilogue (the 32 gate adjoints hold 128 registers)
+template <int BK, bool FAST>
+__global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a) {
+    typedef BlkBwdCfg<BK> C;
+    constexpr int BM = C::BM, BN = C::BN, NTH = C::NTH, NQ = BK / 8;
+    extern __shared__ __attribute__((aligned(16))) float blk_lds[];
+    float* const As = blk_lds;                    // [2][BM rows][BK]
+    float* const Bs = As + 2 * BK * BM;           // [2][BN rows (units)][BK]
+    float* const sl = blk_lds + C::tile_floats;   // [BM][4] mean_x, rstd_x, mean_h, rstd_h of this step's rows
+    float* const sa = sl + BM * 4;                // [BM][4] the four LayerNorm-adjoint row sums / 4H
+    float* const cl = sa + BM * 4;                // [3][4 BN] column sums of the workgroup (final reduction only)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1, h = lane >> 5, i32 = lane & 31;
+    // the lane's row records in sl / sa: ONE address each + compile-time offsets (written as sl + (row) * 4 the compiler
+    // materialised all 32 addresses per array as loop invariants and spilled them)
+    const float* const slp = sl + (wm * 64 + 4 * h) * 4;
+    const float* const sap = sa + (wm * 64 + 4 * h) * 4;
+    const int rbl = (int)blockIdx.x / a.nnt, nt = (int)blockIdx.x % a.nnt;
+    const int H = a.H, G = 4 * H, nnt = a.nnt;
+    const long row0 = (long)(a.rb0 + rbl) * BM;
+    const int unit = nt * BN + wn * 32 + i32;
+    unsigned* const flag_s = a.flags + 2 * rbl;
+    unsigned* const flag_h = flag_s + 1;
+    float* const part = a.part + (size_t)rbl * 2 * 4 * nnt * BM * 4;
+    const vfloat4 gx = *reinterpret_cast<const vfloat4*>(a.pp + 4 * unit);
+    const vfloat4 gh = *reinterpret_cast<const vfloat4*>(a.pp + G + 4 * unit);
+    const vfloat4 bx = *reinterpret_cast<const vfloat4*>(a.pp + 2 * G + 4 * unit);
+    const vfloat4 bh = *reinterpret_cast<const vfloat4*>(a.pp + 3 * G + 4 * unit);
+    const vfloat4 bb = *reinterpret_cast<const vfloat4*>(a.pp + 4 * G + 4 * unit);
+    const unsigned xoff = (unsigned)(4 * h) * (unsigned)G + 4u * (unsigned)unit;
+    const unsigned uoff = (unsigned)(4 * h) * (unsigned)H + (unsigned)unit;
+    if (a.skew_ticks > 0 && rbl > 0) {
+        const long long t0 = wall_clock64(), want = (long long)rbl * a.skew_ticks;
+        while (wall_clock64() - t0 < want) __builtin_amdgcn_s_sleep(32);
+    }
+    const int ktiles = G / BK;
+    int a_off[NQ], b_off[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        a_off[q] = lds_pos<BK>(wm * 64 + i32, h * (BK / 2) + 4 * q);
+        b_off[q] = lds_pos<BK>(wn * 32 + i32, h * (BK / 2) + 4 * q);
+    }
+    const float inv_g = 1.f / (float)G;
+    vfloat4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0, cs2 = cs0;   // column sums of this lane's four gate columns, all steps
+    const bool prof_on = a.prof && blockIdx.x == gridDim.x / 2 && tid == 0;
+    u64 tprev_ = prof_on ? wall_clock64() : 0;
+
+    // the product: acc = A[row block rows, all 4H] @ whp[units of the tile, all 4H]^T
+    f32x16 acc[2];
+    auto product = [&](const float* arows) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        DmaStage<BM, BK, NTH> da;
+        DmaStage<BN, BK, NTH> db;
+        da.init(arows, G, 0, 0);
+        db.init(a.whp + (size_t)(nt * BN) * G, G, 0, 0);
+        da.issue(As);
+        db.issue(Bs);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < ktiles) {
+                da.issue(As + (buf ^ 1) * BK * BM);
+                db.issue(Bs + (buf ^ 1) * BK * BN);
+            }
+            const float* __restrict__ as = As + buf * BK * BM;
+            const float* __restrict__ bs = Bs + buf * BK * BN;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                gf4 av[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const gf4*>(as + a_off[q] + i * 32 * BK);
+                const gf4 bv = *reinterpret_cast<const gf4*>(bs + b_off[q]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    };
+
+    for (int s = a.S - 1; s >= 0; --s) {
+        const size_t srow = (size_t)s * a.B + row0;
+        const bool last = s == a.S - 1;
+        if (!last) {
+            block_wait(flag_h, (unsigned)(nnt * (a.S - 1 - s)));   // dHW_{s+1} of this row block is complete
+            HPC_RLL_BLK_TICK(0)
+            product(a.dhw + (srow + a.B) * G);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+        HPC_RLL_BLK_TICK(1)
+        if (tid < BM) *reinterpret_cast<vfloat4*>(sl + tid * 4) = *reinterpret_cast<const vfloat4*>(a.stats + (srow + tid) * 4);
+        __syncthreads();
+
+        // ---- pass A: gate adjoints of the lane's 32 (row, unit) pairs, LayerNorm-adjoint row sums, column sums.
+        // The product's accumulators go through LDS (the operand tiles are dead now): pair k = 16 i + r of every lane at
+        // accl[k][tid].  That turns the epilogue into ROLLED loops over chunks of four consecutive rows -- fully unrolled
+        // (the accumulator registers can only be indexed statically) it was 10 k instructions and spilled 500 registers.
+        float* const accl = blk_lds;   // [32][NTH] floats = the 64 KB of the operand tiles (BK = 32)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accl[(16 * i + r) * NTH + tid] = acc[i][r];
+        const __amdgpu_buffer_rsrc_t r_xw = blk_rsrc(a.xw + srow * G), r_hw = blk_rsrc(a.hw + srow * G);
+        const __amdgpu_buffer_rsrc_t r_dg = blk_rsrc(a.dgate + srow * G);
+        const __amdgpu_buffer_rsrc_t r_cn = blk_rsrc(a.c + srow * H);
+        const __amdgpu_buffer_rsrc_t r_cp = blk_rsrc(s == 0 ? a.c0 + (size_t)row0 * H : a.c + (srow - a.B) * H);
+        const bool has_dy = a.dy != nullptr, has_dhn = last && a.dhn != nullptr, has_dci = !last || a.dcn != nullptr;
+        const __amdgpu_buffer_rsrc_t r_dy = blk_rsrc(has_dy ? a.dy + srow * H : a.c);
+        const __amdgpu_buffer_rsrc_t r_dhn = blk_rsrc(has_dhn ? a.dhn + (size_t)row0 * H : a.c);
+        const __amdgpu_buffer_rsrc_t r_dci = blk_rsrc(last ? (a.dcn ? a.dcn + (size_t)row0 * H : a.c) : a.dc + (size_t)row0 * H);
+        const __amdgpu_buffer_rsrc_t r_dco = blk_rsrc((s == 0 ? a.dc0 : a.dc) + (size_t)row0 * H);
+        const unsigned xob = 4u * xoff, uob = 4u * uoff;             // the lane's byte offsets
+        const unsigned gb = 4u * (unsigned)G, hb = 4u * (unsigned)H;   // bytes per row
+        // chunk c = rows Rc .. Rc + 3 of the wave (pairs k = 4 c .. 4 c + 3): Rc = 64 wm + 32 (c >> 2) + 8 (c & 3)
+        auto chunk_row = [&](int c) __attribute__((always_inline)) { return (unsigned)(wm * 64 + (c >> 2) * 32 + 8 * (c & 3)); };
+        vfloat4 my = {0.f, 0.f, 0.f, 0.f};
+        {
+            struct In { vfloat4 x[4], hh[4]; float cn[4], cp[4], dci[4], dy[4]; };
+            auto load_chunk = [&](int c, In& v) __attribute__((always_inline)) {
+                const unsigned Rc = chunk_row(c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned R = Rc + q;
+                    v.x[q] = blk_ld4<0>(r_xw, xob, R * gb);   // (read again in pass B: no streaming hint)
+                    v.hh[q] = blk_ld4<0>(r_hw, xob, R * gb);
+                    v.cn[q] = blk_ld1<0>(r_cn, uob, R * hb);
+                    v.cp[q] = blk_ld1<0>(r_cp, uob, R * hb);
+                    v.dci[q] = has_dci ? blk_ld1<0>(r_dci, uob, R * hb) : 0.f;
+                    float d = has_dy ? blk_ld1<0>(r_dy, uob, R * hb) : 0.f;
+                    if (has_dhn) d += blk_ld1<0>(r_dhn, uob, R * hb);
+                    v.dy[q] = d;
+                }
+            };
+            auto do_chunk = [&](int c, const In& v) __attribute__((always_inline)) {
+                const unsigned Rc = chunk_row(c);
+                const float* stp = slp + ((c >> 2) * 32 + 8 * (c & 3)) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned R = Rc + q;
+                    const int k = 4 * c + q;
+                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(stp + 4 * q);
+                    const vfloat4 x4 = v.x[q], h4 = v.hh[q];
+                    float pre[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pre[g] = gate_pre(x4[g], st.x, st.y, gx[g], bx[g], h4[g], st.z, st.w, gh[g], bh[g], bb[g]);
+                    const float ig = blk_sigmoid<FAST>(pre[0]), fg = blk_sigmoid<FAST>(pre[1]), og = blk_sigmoid<FAST>(pre[2]);
+                    const float ug = blk_tanh<FAST>(pre[3]);
+                    const float dh = accl[k * NTH + tid] + v.dy[q];
+                    const float tc = blk_tanh<FAST>(v.cn[q]);
+                    const float dc = v.dci[q] + dh * og * (1.f - tc * tc);
+                    const vfloat4 d4 = {dc * ug * ig * (1.f - ig), dc * v.cp[q] * fg * (1.f - fg), dh * tc * og * (1.f - og),
+                                        dc * ig * (1.f - ug * ug)};
+                    blk_st4<0>(d4, r_dg, xob, R * gb);
+                    blk_st1<0>(dc * fg, r_dco, uob, R * hb);
+                    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+                    vfloat4 xh, hh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        xh[g] = (x4[g] - st.x) * st.y;
+                        hh[g] = (h4[g] - st.z) * st.w;
+                        const float dyx = d4[g] * gx[g], dyh = d4[g] * gh[g];
+                        p0 += dyx; p1 += dyx * xh[g];
+                        p2 += dyh; p3 += dyh * hh[g];
+                    }
+                    cs0 += d4;
+                    cs1 += d4 * xh;
+                    cs2 += d4 * hh;
+                    p0 = half_sum_all(p0); p1 = half_sum_all(p1); p2 = half_sum_all(p2); p3 = half_sum_all(p3);
+                    if (i32 == k) my = vfloat4{p0, p1, p2, p3};   // lane i32 = 16 i + r = k keeps row k of its half
+                }
+            };
+            In va, vb;
+            load_chunk(0, va);
+#pragma unroll 1
+            for (int c = 0; c < 8; c += 2) {   // two chunks per trip: the two input sets alternate statically
+                load_chunk(c + 1, vb);
+                do_chunk(c, va);
+                if (c + 2 < 8) load_chunk(c + 2, va);
+                do_chunk(c + 1, vb);
+            }
+        }
+        float* const pslot = part + (size_t)(s & 1) * 4 * nnt * BM * 4;
+        {
+            const int rr = i32 & 15;
+            const int row = wm * 64 + (i32 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            *reinterpret_cast<vfloat4*>(pslot + ((size_t)(4 * nt + wn) * BM + row) * 4) = my;
+        }
+        block_arrive(flag_s);
+        HPC_RLL_BLK_TICK(2)
+        block_wait(flag_s, (unsigned)(nnt * (a.S - s)));
+        HPC_RLL_BLK_TICK(3)
+        if (tid < BM) {
+            vfloat4 t = {0.f, 0.f, 0.f, 0.f};
+            const float* pp = pslot + (size_t)tid * 4;
+            for (int c0 = 0; c0 < 4 * nnt; c0 += 8) {
+                vfloat4 p[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    p[k] = *reinterpret_cast<const vfloat4*>(pp + (size_t)(c0 + k < 4 * nnt ? c0 + k : 0) * BM * 4);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + k < 4 * nnt) t += p[k];
+            }
+            *reinterpret_cast<vfloat4*>(sa + tid * 4) = t * inv_g;
+        }
+        __syncthreads();
+        HPC_RLL_BLK_TICK(4)
+
+        // ---- pass B: dXW_s, dHW_s of the lane's pairs (gate adjoints, xw, hw read back: this lane's own lines, from L2)
+        {
+            const __amdgpu_buffer_rsrc_t r_dxw = blk_rsrc(a.dxw + srow * G), r_dhw = blk_rsrc(a.dhw + srow * G);
+            struct In { vfloat4 x[4], hh[4], d[4]; };
+            auto load_chunk = [&](int c, In& v) __attribute__((always_inline)) {
+                const unsigned Rc = chunk_row(c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v.x[q] = blk_ld4<2>(r_xw, xob, (Rc + q) * gb);
+                    v.hh[q] = blk_ld4<2>(r_hw, xob, (Rc + q) * gb);
+                    v.d[q] = blk_ld4<2>(r_dg, xob, (Rc + q) * gb);
+                }
+            };
+            auto do_chunk = [&](int c, const In& v) __attribute__((always_inline)) {
+                const unsigned Rc = chunk_row(c);
+                const int lo = ((c >> 2) * 32 + 8 * (c & 3)) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(slp + lo + 4 * q);
+                    const vfloat4 av = *reinterpret_cast<const vfloat4*>(sap + lo + 4 * q);
+                    vfloat4 ox, oh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float dyx = v.d[q][g] * gx[g], dyh = v.d[q][g] * gh[g];
+                        ox[g] = st.y * (dyx - av.x - (v.x[q][g] - st.x) * st.y * av.y);
+                        oh[g] = st.w * (dyh - av.z - (v.hh[q][g] - st.z) * st.w * av.w);
+                    }
+                    blk_st4<2>(ox, r_dxw, xob, (Rc + q) * gb);
+                    blk_st4<0>(oh, r_dhw, xob, (Rc + q) * gb);   // the next product's operand
+                }
+            };
+            In va, vb;
+            load_chunk(0, va);
+#pragma unroll 1
+            for (int c = 0; c < 8; c += 2) {
+                load_chunk(c + 1, vb);
+                do_chunk(c, va);
+                if (c + 2 < 8) load_chunk(c + 2, va);
+                do_chunk(c + 1, vb);
+            }
+        }
+        HPC_RLL_BLK_TICK(5)
+        block_arrive(flag_h);
+        HPC_RLL_BLK_TICK(6)
+    }
+    // ---- dh0 = dHW_0 @ Wh^T, dc0 is already in place
+    block_wait(flag_h, (unsigned)(nnt * a.S));
+    product(a.dhw + (size_t)row0 * G);
+    {
+        float* const dh0 = a.dh0 + (size_t)row0 * H;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int R = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);
+                (dh0 + (size_t)R * H)[uoff] = acc[i][r];
+            }
+    }
+    // ---- column sums: the 4 lanes-sets that share a unit (two halves x two row waves) meet in LDS; fixed order
+    __syncthreads();
+    for (int e = tid; e < 3 * 4 * BN; e += NTH) cl[e] = 0.f;
+    __syncthreads();
+    for (int turn = 0; turn < 4; ++turn) {   // (wm, h) = turn: each column gets exactly one writer per turn
+        if (wm * 2 + h == turn) {
+            float* c = cl + 4 * (wn * 32 + i32);
+            *reinterpret_cast<vfloat4*>(c) += cs0;
+            *reinterpret_cast<vfloat4*>(c + 4 * BN) += cs1;
+            *reinterpret_cast<vfloat4*>(c + 2 * 4 * BN) += cs2;
+        }
+        __syncthreads();
+    }
+    float* const mine = a.colacc + (size_t)rbl * 3 * G;
+    for (int e = tid; e < 3 * 4 * BN; e += NTH) {
+        const int k3 = e / (4 * BN), c = e - k3 * 4 * BN;
+        mine[(size_t)k3 * G + 4 * nt * BN + c] = cl[e];
+    }
+}
+
+inline bool lstm_block_bwd_shape(int B, int H) { return lstm_perm_shape(B, H) && H % 128 == 0 && B % 128 == 0; }
+inline int block_bwd_rows_per_launch(int H) {
+    const int nnt = H / 128;
+    return nnt > 0 ? persist_cu_count() / nnt : 0;
+}
+inline size_t block_bwd_part_floats(int B, int H) { return (size_t)(B / 128) * 2 * 4 * (H / 128) * 128 * 4; }
+inline int block_bwd_bk() { return (g_lstm_block & 16) ? 16 : 32; }
+
+template <int BK> inline bool block_bwd_resident(int H) {
+    const int per = block_bwd_rows_per_launch(H);
+    return per >= 1 && persist_resident_t(lstm_block_bwd_kernel<BK, true>, 512, (H / 128) * per, BlkBwdCfg<BK>::lds_bytes);
+}
+inline bool block_bwd_ok(int B, int H, hipStream_t st) {
+    if (!(g_lstm_block & 8) || !g_lstm_persist || !lstm_block_bwd_shape(B, H) || !persist_runtime_ready(st)) return false;
+    return block_bwd_bk() == 16 ? block_bwd_resident<16>(H) : block_bwd_resident<32>(H);
+}
+template <int BK>
+inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
+    typedef BlkBwdCfg<BK> C;
+    const int nrb = a.B / 128, per = block_bwd_rows_per_launch(a.H);
+    if (hipMemsetAsync(flags, 0, block_flag_words(a.B) * sizeof(unsigned), st) != hipSuccess) return last_error();
+    const hipError_t e = hipFuncSetAttribute((const void*)lstm_block_bwd_kernel<BK, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)C::lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    a.nnt = a.H / 128;
+    a.skew_ticks = g_lstm_block_skew * 100;
+    a.prof = persist_prof();
+    for (int rb = 0; rb < nrb; rb += per) {
+        const int n = nrb - rb < per ? nrb - rb : per;
+        a.rb0 = rb;
+        a.part = part + (size_t)rb * 2 * 4 * a.nnt * 128 * 4;
+        a.flags = flags + 2 * rb;
+        a.colacc = colacc + (size_t)rb * 3 * 4 * a.H;
+        persist_chain_before(st);
+        hipLaunchKernelGGL((lstm_block_bwd_kernel<BK, true>), dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
+        persist_chain_after(st);
+    }
+    persist_prof_report("row-block bwd: wait_h product passA+publish wait_s combine passB arrive_h", 0, a.S, st);
+    return last_error();
+}
+inline int launch_block_bwd(const BlockBwd& a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
+    return block_bwd_bk() == 16 ? launch_block_bwd_t<16>(a, part, flags, colacc, st) : launch_block_bwd_t<32>(a, part, flags, colacc, st);
 }
 
 }  // namespace

@@ -375,6 +375,7 @@ PYBIND11_MODULE(hpc_torch_utils_network, m) {
     });
     m.def("lstm_last_forward_path", []() { return hpc_rll_lstm_last_forward_path(); },
           "kernels the last LSTM forward ran on: 0 step, 1 per-layer persistent, 2 wavefront, 3 interleaved step, 4 row-block");
+    m.def("lstm_last_backward_path", []() { return hpc_rll_lstm_last_backward_path(); }, "the same for the last LSTM backward");
     m.def("async_error", []() { return hpc_rll_async_error(); },
           "sticky status of the persistent small-batch LSTM kernels: 0, or HPC_RLL_ETIMEOUT (-4) once one gave up waiting");
     m.def("clear_async_error", []() { check(hpc_rll_clear_async_error(), "hpc_rll_clear_async_error"); },

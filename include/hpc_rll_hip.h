@@ -150,7 +150,11 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * key 26: LayerNorm-LSTM at large batch (B >= 4096, B % 256 == 0, 768 <= H <= 1024, H % 64 == 0; gate-interleaved
  * pre-activations): 1 (default) = the recurrence of a layer's forward runs in ONE persistent kernel whose workgroups
  * (256 rows x 256 gate columns, one per CU) do the cell in the product's epilogue and synchronise per 256-row block
- * (lstm_block.hpp); 0 = one product + one cell launch per step (same layout, same saved tensors); set before the forward.
+ * (lstm_block.hpp); 0 = one product + one cell launch per step (same layout, same saved tensors).  A bit mask: bit 0 the
+ * persistent forward, bit 1 its 128-row variant (two workgroups per CU; measured slower), bit 2 libm instead of hardware
+ * exp2 / reciprocal in its gates, bit 3 the persistent BACKWARD (128 rows x 128 hidden units per workgroup, full K, cell
+ * adjoint and both LayerNorm adjoints in the product's epilogue; H % 128 == 0), bit 4 its k-depth 16 instead of 32.
+ * Default 9 = forward + backward.  Forward and backward paths can be mixed freely (same saved tensors).
  * key 27: start skew of that kernel's row blocks in microseconds (0 ... 200, default 0): row block r waits r x this
  * before its first step, which spreads the HBM-bound epilogues of the row blocks over the step.
  * key 28: packed Pad1D (hpc_rll_pad1d_packed_forward, 32 <= max_len <= 16384): 1 (default) = wave-synchronous tiles of 1024
@@ -363,6 +367,7 @@ int hpc_rll_lstm_backward_y(const float* dy, const float* dhn, const float* dcn,
  * persistent kernels (B <= 4), 2 = layer wavefront (B <= 4, L >= 2), 3 = step kernels on gate-interleaved pre-activations
  * (large batch), 4 = persistent row-block kernel (large batch, tune key 26); -1 = no forward yet. */
 int hpc_rll_lstm_last_forward_path(void);
+int hpc_rll_lstm_last_backward_path(void);   /* the same for the most recent hpc_rll_lstm_backward* call (its last layer) */
 /* Asynchronous status of the persistent small-batch LSTM kernels (B <= 4).  Their workgroups exchange data through
  * memory and must all be resident at once; that is checked against the runtime's occupancy figure at dispatch and
  * launches of one process are serialised per device, but ANOTHER PROCESS holding compute units for seconds can still

@@ -412,7 +412,8 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
             assert rel_err(o, got) < max(base, 2.0 * rel_err(o, a)), (k, rel_err(o, got), rel_err(o, a))
 
 
-@pytest.mark.parametrize("mode", [1, 3, 5, 7])   # key 26: 256-row blocks / 128-row blocks (two per CU), hardware / libm gate functions
+# key 26 (bit mask): 1 persistent forward, +2 its 128-row blocks (two per CU), +4 libm gate functions, +8 persistent backward, +16 its k-depth 16
+@pytest.mark.parametrize("mode", [9, 1, 8, 11, 13, 25])
 @pytest.mark.parametrize("S,B,I,H,L,p,skew", [(6, 4096, 192, 768, 2, 0.0, 0), (4, 4096, 64, 1024, 1, 0.0, 7), (3, 8192, 48, 960, 1, 0.0, 0),
                                               (5, 4096, 36, 896, 2, 0.3, 0)])
 def test_lstm_row_block_kernel_matches_step_kernels(S, B, I, H, L, p, skew, mode):
@@ -451,14 +452,16 @@ def test_lstm_row_block_kernel_matches_step_kernels(S, B, I, H, L, p, skew, mode
     try:
         N.tune_set(26, 0)
         step = run()
-        assert N.lstm_last_forward_path() == 3
+        assert N.lstm_last_forward_path() == 3 and N.lstm_last_backward_path() == 3
         N.tune_set(26, mode)
         N.tune_set(27, skew)
         blk = run()
-        assert N.lstm_last_forward_path() == 4     # the persistent kernel is what ran (residency was granted)
+        # the persistent kernels are what ran (residency was granted); the backward one needs H % 128 == 0
+        assert N.lstm_last_forward_path() == (4 if mode & 1 else 3)
+        assert N.lstm_last_backward_path() == (4 if (mode & 8) and H % 128 == 0 else 3)
     finally:
-        N.tune_set(26, 1)
-        N.tune_set(27, 0)
+        N.tune_set(26, 9)
+        N.tune_set(27, 10)
     names = "y hn cn dx dh0 dc0 dwx dwh dbias dgamma dbeta".split()
     for k, a, b in zip(names, step, blk):
         assert torch.isfinite(b).all(), k

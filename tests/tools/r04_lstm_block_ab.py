@@ -39,7 +39,7 @@ def timed(fn, n=2, rounds=3):
 
 
 rows = []
-configs = [tuple(int(v) for v in c.split(':')) for c in os.environ.get('CONFIGS', '0:0,1:0,5:0,3:0,7:0,1:10,3:10,3:4,3:0,1:0,0:0').split(',')]
+configs = [tuple(int(v) for v in c.split(':')) for c in os.environ.get('CONFIGS', '0:0,1:10,9:10,25:10,9:0,9:16,1:10,0:0').split(',')]
 for blk, skew in configs:
     N.tune_set(26, blk)
     N.tune_set(27, skew)
@@ -57,7 +57,7 @@ for blk, skew in configs:
     t_b = timed(bwd)
     torch.cuda.synchronize()
     assert N.async_error() == 0
-    r = {"key26": blk, "key27_skew_us": skew, "path": path, "fwd_ms": t_f, "fwd_frac": flops_f / (t_f * 1e-3) / PEAK,
+    r = {"key26": blk, "key27_skew_us": skew, "path": path, "bwd_path": N.lstm_last_backward_path(), "fwd_ms": t_f, "fwd_frac": flops_f / (t_f * 1e-3) / PEAK,
          "bwd_ms": t_b, "bwd_frac": 2 * flops_f / (t_b * 1e-3) / PEAK, "y_checksum": float(y.double().sum().item())}
     rows.append(r)
     print(json.dumps(r), flush=True)
