@@ -58,7 +58,7 @@ struct GemmArgs {
 enum GemmMode { kContigMN = 0, kContigK = 1, kGeneric = 2, kDmaK = 3 };   // kDmaK: k-contiguous, staged by LDS-DMA (DmaStage)
 
 // LDS address (in floats) of position pp (0..BK-1) of the PERMUTED row x of a tile with BK floats per row.
-template <int BK> __device__ __forceinline__ int lds_sw(int x) { return BK == 16 ? ((x >> 2) & 3) : ((x >> 1) & 7); }
+template <int BK> __device__ __forceinline__ int lds_sw(int x) { return BK == 16 ? ((x >> 2) & 3) : BK == 32 ? ((x >> 1) & 7) : (x & 15); }   // (64: 256-byte rows, 16 chunks)
 template <int BK> __device__ __forceinline__ int lds_pos(int x, int pp) {
     return x * BK + ((((pp >> 2) ^ lds_sw<BK>(x)) << 2) | (pp & 3));
 }

@@ -1497,7 +1497,7 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
         g_lstm_last_bwd_path.store(persist ? 1 : blockb ? 4 : perm ? 3 : 0, std::memory_order_relaxed);
         if (blockb) {
             BlockBwd ba{d_out, dh_carry, dc_carry, lw.xw, lw.hw, lw.c, c0 + (size_t)l * BH, lw.stats, w.pperm, w.whP, w.dxw, w.dhw,
-                        w.dgate, w.dc, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, nullptr, nullptr, nullptr, S, B, H, 0, 0, 0, nullptr};
+                        w.dgate, w.dc, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, nullptr, nullptr, nullptr, S, B, H, 0, 0, 0, nullptr, 0};
             const int brc = launch_block_bwd(ba, w.blk_part, reinterpret_cast<unsigned*>(w.blk_flags), w.colpart, st);
             if (brc) return brc;
         }

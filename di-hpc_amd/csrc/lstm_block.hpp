@@ -473,6 +473,7 @@ struct BlockBwd {
     int S, B, H, rb0, nnt;
     int skew_ticks;
     u64* prof;
+    int xcd_map;                        // the 8-row-block groups of the launch are laid out XCD-major (see the kernel)
 };
 
 template <int BK> struct BlkBwdCfg {
@@ -480,7 +481,7 @@ template <int BK> struct BlkBwdCfg {
     static constexpr int tile_floats = 2 * BK * BM + 2 * BK * BN < 32 * NTH ? 32 * NTH : 2 * BK * BM + 2 * BK * BN;   // operand tiles; also
                                                                                     // the accumulator dump [32][NTH] of the epilogue
     static constexpr int lds_floats = tile_floats + BM * 4 + BM * 4 + 3 * 4 * BN;   // + stats, sums, column sums
-    static constexpr size_t lds_bytes = 96 * 1024;   // one workgroup per CU
+    static constexpr size_t lds_bytes = BK == 64 ? 144 * 1024 : 96 * 1024;   // one workgroup per CU
     static_assert(lds_floats * sizeof(float) <= lds_bytes, "row-block backward LDS");
 };
 
@@ -502,7 +503,16 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
     // materialised all 32 addresses per array as loop invariants and spilled them)
     const float* const slp = sl + (wm * 64 + 4 * h) * 4;
     const float* const sap = sa + (wm * 64 + 4 * h) * 4;
-    const int rbl = (int)blockIdx.x / a.nnt, nt = (int)blockIdx.x % a.nnt;
+    // Workgroup id -> (row block, unit tile).  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own
+    // L2.  The A operand of a row block (128 rows x 4H of dHW, 2 MB) is read by all nnt of its workgroups and by nobody else:
+    // put them on ONE XCD (ids x, x + 8, x + 16, ...), so that it crosses the fabric once instead of nnt times; every XCD then
+    // streams all of Wh (16 MB per step, shared by its 32 workgroups) instead of one tile of it.  (Linear order otherwise.)
+    int rbl = (int)blockIdx.x / a.nnt, nt = (int)blockIdx.x % a.nnt;
+    if (a.xcd_map) {
+        const int id = (int)blockIdx.x, grp = 8 * a.nnt;
+        rbl = (id / grp) * 8 + (id & 7);
+        nt = (id % grp) >> 3;
+    }
     const int H = a.H, G = 4 * H, nnt = a.nnt;
     const long row0 = (long)(a.rb0 + rbl) * BM;
     const int unit = nt * BN + wn * 32 + i32;
@@ -787,7 +797,7 @@ inline int block_bwd_rows_per_launch(int H) {
     return nnt > 0 ? persist_cu_count() / nnt : 0;
 }
 inline size_t block_bwd_part_floats(int B, int H) { return (size_t)(B / 128) * 2 * 4 * (H / 128) * 128 * 4; }
-inline int block_bwd_bk() { return (g_lstm_block & 16) ? 16 : 32; }
+inline int block_bwd_bk() { return (g_lstm_block & 16) ? 16 : (g_lstm_block & 32) ? 64 : 32; }
 
 template <int BK> inline bool block_bwd_resident(int H) {
     const int per = block_bwd_rows_per_launch(H);
@@ -795,7 +805,7 @@ template <int BK> inline bool block_bwd_resident(int H) {
 }
 inline bool block_bwd_ok(int B, int H, hipStream_t st) {
     if (!(g_lstm_block & 8) || !g_lstm_persist || !lstm_block_bwd_shape(B, H) || !persist_runtime_ready(st)) return false;
-    return block_bwd_bk() == 16 ? block_bwd_resident<16>(H) : block_bwd_resident<32>(H);
+    return block_bwd_bk() == 16 ? block_bwd_resident<16>(H) : block_bwd_bk() == 64 ? block_bwd_resident<64>(H) : block_bwd_resident<32>(H);
 }
 template <int BK>
 inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
@@ -814,6 +824,7 @@ inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* c
         a.part = part + (size_t)rb * 2 * 4 * a.nnt * 128 * 4;
         a.flags = flags + 2 * rb;
         a.colacc = colacc + (size_t)rb * 3 * 4 * a.H;
+        a.xcd_map = (n % 8 == 0 && !(g_lstm_block & 64)) ? 1 : 0;
         persist_chain_before(st);
         hipLaunchKernelGGL((lstm_block_bwd_kernel<BK, true>), dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
         persist_chain_after(st);
@@ -822,7 +833,8 @@ inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* c
     return last_error();
 }
 inline int launch_block_bwd(const BlockBwd& a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
-    return block_bwd_bk() == 16 ? launch_block_bwd_t<16>(a, part, flags, colacc, st) : launch_block_bwd_t<32>(a, part, flags, colacc, st);
+    return block_bwd_bk() == 16 ? launch_block_bwd_t<16>(a, part, flags, colacc, st)
+           : block_bwd_bk() == 64 ? launch_block_bwd_t<64>(a, part, flags, colacc, st) : launch_block_bwd_t<32>(a, part, flags, colacc, st);
 }
 
 }  // namespace
