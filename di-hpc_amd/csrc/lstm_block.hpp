@@ -377,13 +377,23 @@ inline size_t block_flag_words(int B) { return (size_t)(B / 128) * 2; }
 inline int block_mw() { return (g_lstm_block & 2) ? 2 : 4; }
 inline bool block_fast() { return (g_lstm_block & 4) == 0; }
 
+// The row blocks of a layer run in launches of `per` (co-residency); a last launch that fills less than 70 % of the CUs
+// (e.g. B = 4352: 16 + 1 row blocks of 256) would cost a whole recurrence for a few rows: such shapes keep the step kernels.
+inline bool block_launches_fill(int nrb, int per, int wgs_per_rb) {
+    const int cus = persist_cu_count();
+    if (per < 1 || cus < 1) return false;
+    const int tail = nrb % per;
+    return tail == 0 || (long)tail * wgs_per_rb * 10 >= (long)cus * 7;
+}
 template <int MW, bool FAST> inline bool block_resident(int H) {
     const int per = block_rows_per_launch<MW>(H);
     return per >= 1 && persist_resident_t(lstm_block_fwd_kernel<MW, FAST>, BlkCfg<MW>::NTH, (4 * H / 256) * per, BlkCfg<MW>::lds_bytes);
 }
 inline bool block_fwd_ok(int B, int H, hipStream_t st) {
     if (!(g_lstm_block & 1) || !g_lstm_persist || !lstm_perm_shape(B, H) || !persist_runtime_ready(st)) return false;
-    if (block_mw() == 4) return block_fast() ? block_resident<4, true>(H) : block_resident<4, false>(H);
+    const int mw = block_mw(), nrb = B / (64 * mw), per = mw == 4 ? block_rows_per_launch<4>(H) : block_rows_per_launch<2>(H);
+    if (!block_launches_fill(nrb, per, mw == 4 ? 4 * H / 256 : 2 * H / 256)) return false;   // (128-row blocks share a CU in pairs)
+    if (mw == 4) return block_fast() ? block_resident<4, true>(H) : block_resident<4, false>(H);
     return block_fast() ? block_resident<2, true>(H) : block_resident<2, false>(H);
 }
 
@@ -805,6 +815,7 @@ template <int BK> inline bool block_bwd_resident(int H) {
 }
 inline bool block_bwd_ok(int B, int H, hipStream_t st) {
     if (!(g_lstm_block & 8) || !g_lstm_persist || !lstm_block_bwd_shape(B, H) || !persist_runtime_ready(st)) return false;
+    if (!block_launches_fill(B / 128, block_bwd_rows_per_launch(H), H / 128)) return false;
     return block_bwd_bk() == 16 ? block_bwd_resident<16>(H) : block_bwd_bk() == 64 ? block_bwd_resident<64>(H) : block_bwd_resident<32>(H);
 }
 template <int BK>
