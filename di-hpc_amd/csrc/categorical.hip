@@ -832,7 +832,7 @@ extern "C" int hpc_rll_tune_set(int key, int value) {
     if (key == 14 && value >= 1 && value <= 64) { hpc_rll::g_gemm_thr_ktiles = value; return HPC_RLL_OK; }
     if (key == 15 && value >= 0 && value <= 8) { hpc_rll::g_cell_vec4 = value; return HPC_RLL_OK; }
     if (key == 16 && (value == 0 || value == 1)) { hpc_rll::g_gemm_tile256 = value; return HPC_RLL_OK; }
-    if (key == 17 && (value == 0 || value == 1)) { hpc_rll::g_scatter_lds_fwd = value; return HPC_RLL_OK; }
+    if (key == 17 && value >= 0 && value <= 2) { hpc_rll::g_scatter_lds_fwd = value; return HPC_RLL_OK; }
     if (key == 18 && (value == 0 || (value >= 4 && value <= 64 && value % 4 == 0))) { hpc_rll::g_scatter_npb = value; return HPC_RLL_OK; }
     if (key == 19 && value >= 256 && value <= 16384) { hpc_rll::g_scan_wave_target = value; return HPC_RLL_OK; }
     if (key == 20 && (value == 0 || (value >= 64 && value <= 1024))) { hpc_rll::g_cell_rows_wgs = value; return HPC_RLL_OK; }

@@ -759,6 +759,61 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
     }
 }
 
+// Round 4 experiment (tune key 17 = 2): WAVE tiles, no LDS, no workgroup barrier -- the structure that took the packed pad
+// kernel from 5.0 to 6.2 TB/s.  A wave owns 1024 consecutive cells (256 quads, 4 per lane) of the map of one batch element
+// and CG = 16 channels: the owners of its 16 cells sit in 16 registers of the lane for all 16 channels; per channel it
+// writes its 4 KB piece of the plane with four 1 KB nontemporal stores, gathering x[b, m, n] for the (few: 6 % at C5)
+// cells that have an owner.  Needs HW % 4 == 0 and a 16-byte aligned `out`.
+template <bool ADD>
+__global__ __launch_bounds__(256) void scatter_out_wave_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                               float* __restrict__ out, int M, int N, int HW, int tiles_per_plane,
+                                                               int groups, long nwaves) {
+    constexpr int CG = 16;
+    const int lane = threadIdx.x & 63;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= nwaves) return;
+    const int cg = (int)(wv % groups);
+    const long r = wv / groups;
+    const int tp = (int)(r % tiles_per_plane);
+    const int b = (int)(r / tiles_per_plane);
+    const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
+    const int32_t* __restrict__ first_g = ADD ? head : head + HW;
+    const int32_t* __restrict__ next_g = head + 2 * HW;
+    const float* __restrict__ xb = x + (size_t)b * M * N;
+    int4 f[4];
+    int cell[4];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cell[j] = tp * 1024 + 4 * (lane + 64 * j);
+        f[j] = cell[j] < HW ? *reinterpret_cast<const int4*>(first_g + cell[j]) : int4{-1, -1, -1, -1};
+        any = any || ((f[j].x & f[j].y & f[j].z & f[j].w) >= 0);
+    }
+    const int n0 = cg * CG;
+    for (int c = 0; c < CG && n0 + c < N; ++c) {
+        const int n = n0 + c;
+        float* __restrict__ op = out + ((size_t)b * N + n) * HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vfloat4 o = {0.f, 0.f, 0.f, 0.f};
+            if (any && (f[j].x & f[j].y & f[j].z & f[j].w) >= 0) {
+                const int32_t fi[4] = {f[j].x, f[j].y, f[j].z, f[j].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float a = 0.f;
+                    if (fi[k] >= 0) {
+                        a = xb[(size_t)fi[k] * N + n];
+                        if (ADD)
+                            for (int32_t m = next_g[fi[k]]; m >= 0; m = next_g[m]) a += xb[(size_t)m * N + n];
+                    }
+                    o[k] = a;
+                }
+            }
+            if (cell[j] < HW) __builtin_nontemporal_store(o, reinterpret_cast<vfloat4*>(op + cell[j]));
+        }
+    }
+}
+
 // backward: workgroup = (b, group of NG channels); stage NG planes of grad_out in LDS, gather per entity.
 // The planes are one contiguous span of grad_out: staged with nontemporal float4 loads, 1024 threads and up to
 // 128 KB per workgroup so that every thread has several 16-byte loads in flight (a pure read streams at 7 TB/s on this
@@ -1142,6 +1197,14 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     // (tests/tools/r02_scatter_probe.py, profiles/r02_scatter_probe.json): configs[4] cover 0.953 -> 0.919 ms (4.81 ->
     // 4.99 TB/s), reference test shape (16x16 maps) cover 51 -> 46 us, add 68 -> 53 us; `add` on large maps is a tie at
     // 64 channels per workgroup (0.893 ms, 5.13 TB/s) and a loss at 32, so it keeps the cells-per-thread kernel there.
+    if (g_scatter_lds_fwd == 2 && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0) {   // wave tiles (experiment)
+        const int tpp = (int)((HW + 1023) / 1024), groups = (N + 15) / 16;
+        const long nwaves = (long)B * tpp * groups;
+        const unsigned blocks = (unsigned)((nwaves + 3) / 4);
+        if (add) hipLaunchKernelGGL(scatter_out_wave_kernel<true>, dim3(blocks), dim3(256), 0, st, x, ws, out, M, N, (int)HW, tpp, groups, nwaves);
+        else hipLaunchKernelGGL(scatter_out_wave_kernel<false>, dim3(blocks), dim3(256), 0, st, x, ws, out, M, N, (int)HW, tpp, groups, nwaves);
+        return last_error();
+    }
     const bool lds_pays = !add || HW * 4 <= 8 * 1024 || g_scatter_npb != 0;
     if (g_scatter_lds_fwd && lds_pays && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0 && B <= 65535 &&
         (size_t)HW * 4 <= 32 * 1024) {

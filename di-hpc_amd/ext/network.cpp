@@ -86,11 +86,14 @@ struct LstmGrads { Tensor dx, dh0, dc0, dwx, dwh, dbias, dgamma, dbeta; };
 void lstm_backward_launch(const LstmDims& d, const Tensor& dy, const Tensor& dhn, const Tensor& dcn, const Tensor& x,
                           const Tensor& h0, const Tensor& c0, const Tensor& wx, const Tensor& wh, const Tensor& gamma,
                           const Tensor& ws, const LstmGrads& g, double dropout, uint64_t seed, int64_t fwd_epoch = -1,
-                          const Tensor& y_hseq = Tensor()) {
-    // a timeout seen now may be this graph's own forward: its saved activations cannot be trusted
+                          const Tensor& y_hseq = Tensor(), bool fwd_persistent = true) {
+    // a timeout seen now may be this graph's own forward: its saved activations cannot be trusted.  (fwd_persistent: the
+    // forward ran on kernels that can time out at all -- the small-batch persistent / wavefront kernels or, round 4, the
+    // large-batch row-block kernel; callers that do not know pass true and the B <= 4 rule of round 2 decides)
     const bool recovered = lstm_recover_from_timeout("nothing");
-    TORCH_CHECK(!(d.B <= kPersistMaxB && (recovered || (fwd_epoch >= 0 && fwd_epoch != g_persist_epoch.load()))),
-                "hpc_rll LSTM backward: the forward pass of this graph ran on a persistent small-batch kernel around the time "
+    const bool could_time_out = fwd_epoch >= 0 ? fwd_persistent : d.B <= kPersistMaxB;
+    TORCH_CHECK(!(could_time_out && (recovered || (fwd_epoch >= 0 && fwd_epoch != g_persist_epoch.load()))),
+                "hpc_rll LSTM backward: the forward pass of this graph ran on a persistent kernel around the time "
                 "one of them timed out; its saved activations may be invalid.  Run the forward pass again (it now uses the "
                 "step kernels).");
     if (y_hseq.defined()) {
@@ -211,12 +214,17 @@ void LstmBackward(const OptList& in, const OptList& out, double dropout, std::op
 }
 
 struct LstmFn : public ag::Function<LstmFn> {
-    static ag::tensor_list forward(ag::AutogradContext* ctx, const Tensor& x, const Tensor& wx, const Tensor& wh,
-                                   const Tensor& bias, const Tensor& gamma, const Tensor& beta, const Tensor& h0,
-                                   const Tensor& c0, double dropout, int64_t seed, bool y_saved) {
-        const LstmDims d = lstm_dims(x, h0, wx, wh);
-        lstm_check_params(d, c0, bias, gamma, beta);
+    static ag::tensor_list forward(ag::AutogradContext* ctx, const Tensor& x_in, const Tensor& wx_in, const Tensor& wh_in,
+                                   const Tensor& bias_in, const Tensor& gamma_in, const Tensor& beta_in, const Tensor& h0_in,
+                                   const Tensor& c0_in, double dropout, int64_t seed, bool y_saved) {
+        const LstmDims d = lstm_dims(x_in, h0_in, wx_in, wh_in);
+        lstm_check_params(d, c0_in, bias_in, gamma_in, beta_in);
         c10::DeviceGuard g(d.dev);
+        // the large-batch kernels use 16-byte accesses everywhere (the C ABI returns HPC_RLL_EALIGN otherwise): an operand
+        // that is contiguous but starts off a 16-byte boundary (a view into a larger buffer) is copied once
+        auto al16 = [](const Tensor& t) { return (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) ? t.clone() : t; };
+        const Tensor x = al16(x_in), wx = al16(wx_in), wh = al16(wh_in), bias = al16(bias_in), gamma = al16(gamma_in),
+                     beta = al16(beta_in), h0 = al16(h0_in), c0 = al16(c0_in);
         Tensor hn = new_f32({d.L, d.B, d.H}, d.dev), cn = new_f32({d.L, d.B, d.H}, d.dev);
         Tensor ws = new_f32({lstm_ws_floats(d, dropout)}, d.dev);
         // y is its OWN (S,B,H) tensor in every mode (as a view of the saved workspace it pinned the whole
@@ -234,6 +242,7 @@ struct LstmFn : public ag::Function<LstmFn> {
         ctx->saved_data["bias_shape"] = bias.sizes().vec();
         ctx->saved_data["beta_shape"] = beta.sizes().vec();
         ctx->saved_data["persist_epoch"] = g_persist_epoch.load();
+        ctx->saved_data["persistent_fwd"] = hpc_rll_lstm_last_forward_path() != 0 && hpc_rll_lstm_last_forward_path() != 3;
         return {y, hn, cn};
     }
     static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {
@@ -241,7 +250,11 @@ struct LstmFn : public ag::Function<LstmFn> {
         const Tensor &x = s[0], &h0 = s[1], &c0 = s[2], &wx = s[3], &wh = s[4], &gamma = s[5], &ws = s[6];
         const LstmDims d = lstm_dims(x, h0, wx, wh);
         c10::DeviceGuard g(d.dev);
-        auto cont = [](const Tensor& t) { return t.defined() ? t.contiguous() : t; };
+        auto cont = [](const Tensor& t) {   // contiguous and 16-byte aligned (see forward)
+            if (!t.defined()) return t;
+            Tensor c = t.contiguous();
+            return (reinterpret_cast<uintptr_t>(c.data_ptr()) & 15) ? c.clone() : c;
+        };
         LstmGrads gr;
         gr.dx = ctx->needs_input_grad(0) ? at::empty_like(x) : undef();   // x without grad: layer-0 dx GEMM is skipped
         gr.dh0 = at::empty_like(h0);
@@ -253,7 +266,8 @@ struct LstmFn : public ag::Function<LstmFn> {
         gr.dbeta = new_f32(ctx->saved_data["beta_shape"].toIntVector(), d.dev);
         lstm_backward_launch(d, cont(grads[0]), cont(grads[1]), cont(grads[2]), x, h0, c0, wx, wh, gamma, ws, gr,
                              ctx->saved_data["dropout"].toDouble(), (uint64_t)ctx->saved_data["seed"].toInt(),
-                             ctx->saved_data["persist_epoch"].toInt(), s.size() > 7 ? s[7] : Tensor());
+                             ctx->saved_data["persist_epoch"].toInt(), s.size() > 7 ? s[7] : Tensor(),
+                             ctx->saved_data["persistent_fwd"].toBool());
         return {gr.dx, gr.dwx, gr.dwh, gr.dbias, gr.dgamma, gr.dbeta, gr.dh0, gr.dc0, undef(), undef(), undef()};
     }
 };

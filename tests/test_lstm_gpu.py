@@ -490,6 +490,38 @@ def test_lstm_row_block_kernel_matches_step_kernels(S, B, I, H, L, p, skew, mode
             assert e < (2e-5 if k != "dx" else 2e-4), (k, e)
 
 
+def test_lstm_row_block_kernel_with_operands_off_a_16_byte_boundary():
+    """The large-batch kernels use 16-byte accesses (the C ABI answers HPC_RLL_EALIGN to a pointer off that boundary);
+    the extension copies such an operand once instead of failing: x / h0 / c0 / dy that are contiguous views starting
+    4 bytes into a larger buffer give the same bits as aligned copies, forward and backward."""
+    import hpc_torch_utils_network as N
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    S, B, I, H, L = 3, 4096, 40, 768, 1
+    torch.manual_seed(41)
+    m = LSTM(S, B, I, H, L).to(DEV)
+
+    def off(shape):
+        n = int(np.prod(shape))
+        t = torch.randn(n + 1, device=DEV)[1:].view(*shape)
+        assert t.data_ptr() % 16 == 4 and t.is_contiguous()
+        return t
+
+    x, h0, c0, gy = off((S, B, I)), off((L, B, H)), off((L, B, H)), off((S, B, H))
+    res = []
+    for al in (False, True):
+        for q in m.parameters():
+            q.grad = None
+        xs, hs, cs = ((t.clone() if al else t).detach().requires_grad_(True) for t in (x, h0, c0))
+        y, (hn, cn) = m(xs, (hs, cs))
+        assert N.lstm_last_forward_path() == 4
+        y.backward(gy.clone() if al else gy)
+        torch.cuda.synchronize()
+        assert N.async_error() == 0
+        res.append([t.detach().clone() for t in (y, hn, cn, xs.grad, hs.grad, cs.grad, m.wx.grad, m.wh.grad)])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("S,B,I,H,L", [(24, 3, 64, 384, 1), (16, 3, 48, 96, 3), (12, 4, 32, 512, 2)])   # per-layer / wavefront / mixed
 def test_persistent_lstm_survives_a_busy_device(S, B, I, H, L):
     """VERDICT r01 item 5.  The persistent kernels need all their workgroups resident at once.  (a) A kernel that holds
