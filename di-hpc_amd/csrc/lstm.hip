@@ -1013,6 +1013,7 @@ inline void launch_cell_bwd_rows(int B, int nwg, hipStream_t st, const CellBwdAr
 #include "lstm_persist.hpp"
 #include "lstm_wave.hpp"
 #include "lstm_block.hpp"
+#include "lstm_mid.hpp"
 namespace hpc_rll {
 namespace {
 
@@ -1024,6 +1025,7 @@ struct Ws {
     float *dgate, *dxw, *dhw, *dh, *dc, *dseq_a, *dseq_b, *colpart, *hw_part, *xchg, *wpart, *dwave, *whT, *wxT;
     float *whP, *wxP, *blk_part, *blk_flags, *pperm;   // gate-interleaved weight copies, row-block exchange, interleaved
                                                        // parameter table of the layer (lstm_perm_shape only)
+    float *mid;      // mid-batch persistent forward: flags + LayerNorm partials (lstm_mid_shape only)
     size_t total;
 };
 inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
@@ -1062,6 +1064,7 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.blk_part = take(perm ? block_part_floats(B, H) : 0);
     w.blk_flags = take(perm ? block_flag_words(B) : 0);
     w.pperm = take(perm ? 5 * G : 0);
+    w.mid = take(mid_ws_floats(S, B, H));
     {   // persistent small-batch paths: {value, tag} exchange words (per-layer kernels / layer wavefront)
         size_t words = xchg_layout(B, H).total_words;
         WaveCfg wc{};
@@ -1194,7 +1197,10 @@ int lstm_forward_impl(const float* x, const float* h0, const float* c0, const fl
                   I % 4 == 0))
         return HPC_RLL_EALIGN;   // these shapes run 16-byte kernels only
     const bool block = perm && block_fwd_ok(B, H, st);
+    // mid-size batches: one persistent kernel per layer with the product on the matrix cores (lstm_mid.hpp)
+    const bool mid = S > 0 && !persist && !perm && mid_fwd_ok(B, H, st);
     if (persist) g_lstm_last_path.store(1, std::memory_order_relaxed);
+    if (mid) g_lstm_last_path.store(5, std::memory_order_relaxed);
     if (perm) g_lstm_last_path.store(block ? 4 : 3, std::memory_order_relaxed);
     for (int l = 0; l < L && perm; ++l) {
         const int in_l = l == 0 ? I : H;
@@ -1281,10 +1287,19 @@ int lstm_forward_impl(const float* x, const float* h0, const float* c0, const fl
             if (prc) return prc;
             persist_prof_report("fwd", l, S, st);
         }
+        if (mid) {
+            hipLaunchKernelGGL(lstm_rowstats_kernel, dim3((unsigned)SB), dim3(256), 0, st, (const float*)lw.xw, (int)G,
+                               lw.stats);
+            MidFwd a{lw.xw, wh_l, bias + (size_t)l * G, ln_gamma + (size_t)l * 2 * G, ln_beta + (size_t)l * 2 * G,
+                     h0 + (size_t)l * BH, c0 + (size_t)l * BH, lw.hw, lw.gates, lw.c, lw.hseq, lw.stats,
+                     nullptr, nullptr, nullptr, nullptr, S, B, 0, H, 0, 0, 0, 0, nullptr};
+            const int mrc = launch_mid_fwd(a, w.mid, l, st);
+            if (mrc) return mrc;
+        }
         const int sk_rec = gemm_splitk(B, (int)G, H);
-        const bool nt_rec = !persist && S > 0 && !gemm_nn_dma_ok(B, (int)G, H, sk_rec) && gemm_dma_ok(B, (int)G, H, sk_rec);
+        const bool nt_rec = !persist && !mid && S > 0 && !gemm_nn_dma_ok(B, (int)G, H, sk_rec) && gemm_dma_ok(B, (int)G, H, sk_rec);
         if (nt_rec) launch_transpose(wh_l, w.whT, H, (int)G, st);      // (H, G) -> (G, H): B(k=h, n=g) = whT[g*H + h]
-        for (int s = 0; s < S && !persist; ++s) {
+        for (int s = 0; s < S && !persist && !mid; ++s) {
             const float* h_prev = s == 0 ? h0 + (size_t)l * BH : lw.hseq + (size_t)(s - 1) * BH;
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
             float* hw_s = lw.hw + (size_t)s * B * G;

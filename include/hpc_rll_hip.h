@@ -160,6 +160,14 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * key 28: packed Pad1D (hpc_rll_pad1d_packed_forward, 32 <= max_len <= 16384): 1 (default) = wave-synchronous tiles of 1024
  * consecutive OUTPUT elements (their packed source is one contiguous span, staged through the wave's own LDS slice);
  * 0 = the round-3 kernel (16 rows per workgroup).  Identical results.
+ * key 29: LayerNorm-LSTM forward at mid-size batches (5 <= B <= 256, 64 <= H <= 1024, H % 16 == 0): 1 or 2 = one
+ * persistent kernel per layer -- Wh resident in LDS (16 gate columns per workgroup), the recurrent product on the matrix
+ * cores straight from h_{s-1} in L2, two exchanges per step without cache-wide fences (lstm_mid.hpp); 2 (default) cuts the
+ * batch into two independent streams (two 8-wave workgroups per CU: one stream's product runs while the other waits for
+ * an exchange) where two copies of a Wh slice fit a CU's LDS; 0 = one split-K product + one cell launch per step.  Same
+ * saved tensors (the backward is the step kernels' either way).
+ * key 30: replicas (1 ... 32, default 8) of the words every workgroup of that kernel polls (its flags and final row
+ * statistics): 256 pollers on one cache line cost 4.4 us per exchange, a single one sees a store after 0.6 us.
  */
 int hpc_rll_tune_set(int key, int value);
 
@@ -365,7 +373,8 @@ int hpc_rll_lstm_backward_y(const float* dy, const float* dhn, const float* dcn,
 /* Diagnostic: the kernels the most recent hpc_rll_lstm_forward* call of this process ran its recurrence on.  0 = one product
  * + one cell launch per step (what src/torch_utils/network/lstm.cu:145-161 does with three launches), 1 = per-layer
  * persistent kernels (B <= 4), 2 = layer wavefront (B <= 4, L >= 2), 3 = step kernels on gate-interleaved pre-activations
- * (large batch), 4 = persistent row-block kernel (large batch, tune key 26); -1 = no forward yet. */
+ * (large batch), 4 = persistent row-block kernel (large batch, tune key 26), 5 = persistent mid-batch kernel (5 <= B <= 256,
+ * tune key 29); -1 = no forward yet. */
 int hpc_rll_lstm_last_forward_path(void);
 int hpc_rll_lstm_last_backward_path(void);   /* the same for the most recent hpc_rll_lstm_backward* call (its last layer) */
 /* Asynchronous status of the persistent small-batch LSTM kernels (B <= 4).  Their workgroups exchange data through
