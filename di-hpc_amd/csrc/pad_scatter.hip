@@ -690,7 +690,8 @@ __global__ __launch_bounds__(1024) void scatter_out4_kernel(const float* __restr
 template <bool ADD>
 __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __restrict__ x,
                                                               const int32_t* __restrict__ idx,
-                                                              float* __restrict__ out, int M, int N, int HW, int npb) {
+                                                              float* __restrict__ out, int M, int N, int HW, int npb,
+                                                              int order) {
     extern __shared__ float s_dyn[];
     const int b = blockIdx.y;
     const int n0 = blockIdx.x * npb;
@@ -733,11 +734,21 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
     // 64-bit division by the plane size: 1.07 G stores x 40 / 64 lanes x 4 cycles / 1024 SIMDs = 1.1 ms at C5, the time it
     // took).  Now the lane's (channel, cell) position advances incrementally (one division before the loop), and a quad of
     // cells without an owner -- 78 % of them at 256 entities on a 64 x 64 map -- is one LDS read, three ANDs and the store.
-    long u = u0 + lane;
+    // order 0: every wave streams its own contiguous sixteenth of the span (64 KiB-class pieces).  Round-4 experiments
+    // (tests/tools/micro/writebw3.hip: a pure-write stream runs at 6.5 TB/s when the stores a CU has in flight form whole
+    // 4 KiB-aligned blocks, 4.5-5.9 otherwise): order 1 = all 16 waves write ONE contiguous 16 KiB per round, order 2 = only
+    // the first four waves stream, one 4 KiB block per round.
+    long u = u0 + lane, uend = u1;
+    int ustep = 64;
+    if (order == 1) { u = threadIdx.x; uend = units; ustep = 1024; }
+    if (order == 2) {
+        if (wave >= 4) return;
+        u = threadIdx.x; uend = units; ustep = 256;
+    }
     int n = (int)(u / hw4);
     int c4 = (int)(u - (long)n * hw4);                       // float4 index inside the plane
     const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (; u < u1; u += 64) {
+    for (; u < uend; u += ustep) {
         const int4 f = *reinterpret_cast<const int4*>(s_first + 4 * c4);
         vfloat4 o = zero4;
         if ((f.x & f.y & f.z & f.w) >= 0) {                   // some cell of the quad has an owner (owners are >= 0, empty is -1)
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
             }
         }
         __builtin_nontemporal_store(o, ob + u);
-        c4 += 64;
+        c4 += ustep;
         while (c4 >= hw4) { c4 -= hw4; ++n; }
     }
 }
@@ -1224,8 +1235,9 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
                 if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return last_error();
             }
             const dim3 grid((N + npb - 1) / npb, B);
-            if (add) hipLaunchKernelGGL(scatter_out_lds_kernel<true>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb);
-            else hipLaunchKernelGGL(scatter_out_lds_kernel<false>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb);
+            const int order = g_scatter_lds_fwd >= 3 ? g_scatter_lds_fwd - 2 : 0;
+            if (add) hipLaunchKernelGGL(scatter_out_lds_kernel<true>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order);
+            else hipLaunchKernelGGL(scatter_out_lds_kernel<false>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order);
             return last_error();
         }
     }

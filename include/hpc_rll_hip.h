@@ -168,6 +168,10 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * saved tensors (the backward is the step kernels' either way).
  * key 30: replicas (1 ... 32, default 8) of the words every workgroup of that kernel polls (its flags and final row
  * statistics): 256 pollers on one cache line cost 4.4 us per exchange, a single one sees a store after 0.6 us.
+ * key 31: one-hot gradients (the backward of the q / dist / IQN / QR-DQN n-step TD losses: all zeros except K values per
+ * sample): outputs of at least this many MiB (default 256; 0 = never) are written as a fill in the store pattern that
+ * reaches the part's write rate (one 256-thread workgroup per CU, grid-stride, 16-byte stores: 6.3-6.5 TB/s against
+ * 4.5-5.9 for every other shape of the same loop) plus a second launch for the values.  Identical results.
  */
 int hpc_rll_tune_set(int key, int value);
 

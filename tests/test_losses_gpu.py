@@ -555,6 +555,39 @@ def test_c51_samples_per_wave_kernel_ragged(B, sw):
 
 
 # ------------------------------------------------------------------------------------------------ misc
+@pytest.mark.parametrize("op,B,N,K", [("c51", 20011, 6, 51), ("c51", 4096, 64, 51), ("qrdqn", 33000, 5, 32), ("qrdqn", 9001, 7, 20),
+                                      ("qrdqn", 5000, 3, 64), ("qrdqn", 3000, 4, 76), ("c51", 7000, 3, 18)])
+def test_onehot_gradient_as_fill_plus_values_is_bit_identical(op, B, N, K):
+    """Large one-hot gradients (tune key 31) are written as a fill in the store pattern that reaches the part's write rate
+    plus the K values per sample as whole 128-byte lines; against the one-launch kernel (key 31 = 0) on ragged batches, rows
+    that are and are not multiples of a line (N * K * 4 % 128), K above and below the 32 lanes of a sample (64, 76, 18),
+    every action including 0 and N - 1 (the line rounding stops at the row's ends): the gradients must be the same bits."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.td import DistNStepTD, QRDQNNStepTDError
+    T = 2
+    rng = np.random.default_rng(B + K)
+    a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+    a[:N] = np.arange(N)
+    r, done, w = f32(rng, T, B), (rng.random(B) < 0.3).astype(np.float32), rng.random(B).astype(np.float32)
+    x = (np.abs(f32(rng, B, N, K)) + 1e-3).astype(np.float32)
+    nx = np.abs(f32(rng, B, N, K))
+    res = {}
+    try:
+        for key in (0, 1):                      # 1 MiB threshold: every shape here takes the fill path
+            U.tune_set(31, key)
+            xx = G(x, True)
+            if op == "c51":
+                loss, _ = DistNStepTD(T, B, N, K)(xx, G(nx), G(a), G(na), G(r), G(done), G(w), 0.97, -5., 5.)
+            else:
+                loss, _ = QRDQNNStepTDError(K, T, B, N)(xx, G(nx), G(a), G(na), G(r), G(done), 0.95, G(w), None)
+            (loss * 3.0).backward()
+            res[key] = xx.grad.clone()
+    finally:
+        U.tune_set(31, 256)
+    assert int((res[0] != 0).sum()) > B * K // 2
+    assert torch.equal(res[0], res[1]), (int((res[0] != res[1]).sum()), (res[0] != res[1]).nonzero()[:4].tolist())
+
+
 def test_losses_are_deterministic():
     """No float atomics: two runs give bit-identical losses and gradients."""
     from hpc_rll.rl_utils.vtrace import VTrace

@@ -35,7 +35,7 @@ for (B, M, N, H, W) in ((4096, 256, 64, 64, 64), (256, 256, 256, 16, 16), (1024,
     out = torch.empty(B, N, H, W, device=dev)
     nbytes = 4 * B * M * N + 16 * B * M + 4 * B * N * H * W
     for typ in ("cover", "add"):
-        cfgs = [(0, 0), (1, 0), (2, 0), (1, 64), (1, 32)]
+        cfgs = [(0, 0), (1, 0), (3, 0), (4, 0), (3, 64), (4, 64), (4, 16)]
         res = {c: [] for c in cfgs}
         ref = None
         for rnd in range(4):
