@@ -25,6 +25,8 @@
 
 #include "hpc_rll_hip.h"
 #include "wave.hpp"
+#include "colscan.hpp"
+#include "ppo_op.hpp"
 
 namespace hpc_rll {
 namespace {
@@ -311,6 +313,64 @@ __global__ __launch_bounds__(256) void categorical_fwd_noent_kernel(const float*
                                                                     float* __restrict__ logp_out,
                                                                     float* __restrict__ ent_out, long rows, int N) {
     categorical_fwd_body<G, VEC, E, false>(logits, action, logp_out, ent_out, rows, N);
+}
+
+// PPO forward in ONE launch: a group reads the SAME row of both policy heads (new: log p and entropy, old: log p), its last
+// lane applies the per-sample loss arithmetic (ppo_op.hpp) and keeps five running sums; workgroup sums -> partials -> the
+// last workgroup folds them (colscan.hpp).  Replaces two categorical launches + the sample launch: at B = 65536, N = 128 the
+// forward is 67 MB of reads, i.e. launch boundaries, not bytes, were most of its 24 us.  Per-sample outputs are the bits of
+// the three-launch path (same functions); the five sums group the rows differently (rounding).
+template <int G, int VEC, int E>
+__global__ __launch_bounds__(256) void ppo_fwd_fused_kernel(const float* __restrict__ logits_new,
+                                                            const float* __restrict__ logits_old,
+                                                            const int64_t* __restrict__ action, const PpoOp op, long rows,
+                                                            int N, float* __restrict__ partials, const ScanFold fold) {
+    constexpr int GPB = 256 / G;
+    constexpr int R = 4;   // rows per group and iteration: 4 rows x 2 heads x E loads in flight per lane (the grid is at most 512 workgroups)
+    __shared__ float red[PpoOp::NACC * 4];
+    const int gl = threadIdx.x % G;
+    const int gi = threadIdx.x / G;
+    const bool full = N == G * VEC * E;
+    const long stride = (long)gridDim.x * GPB * R;
+    float acc[PpoOp::NACC];
+#pragma unroll
+    for (int k = 0; k < PpoOp::NACC; ++k) acc[k] = 0.f;
+    for (long bb = (long)blockIdx.x * GPB * R; bb < rows; bb += stride) {
+        RowSlice<G, VEC, E> rn[R], ro[R];
+        long a[R];
+        PpoOp::In in[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            long row = bb + (long)k * GPB + gi;
+            if (row >= rows) row = rows - 1;             // (re-reads the last row; the sample op below is guarded)
+            rn[k].load(logits_new + row * (long)N, N, gl);
+            ro[k].load(logits_old + row * (long)N, N, gl);
+            a[k] = action[row];
+            in[k] = op.load(row);                        // (every lane: the same address per group, one request)
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int ai = (a[k] >= 0 && a[k] < (long)N) ? (int)a[k] : -1;
+            float lpn, h, lpo, h_unused;
+            rn[k].finish(N, gl);
+            ro[k].finish(N, gl);
+            row_stats_fwd<G, VEC, E>(rn[k], N, gl, ai, full, lpn, h);
+            row_stats_fwd<G, VEC, E>(ro[k], N, gl, ai, full, lpo, h_unused);
+            const long row = bb + (long)k * GPB + gi;
+            if (gl == G - 1 && row < rows) op.apply(row, in[k], lpn, h, lpo, acc);
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < PpoOp::NACC; ++k) {
+        const float s = wave_sum(acc[k]);
+        if (lane == 0) red[k * 4 + w] = s;
+    }
+    __syncthreads();
+    float sum = 0.f;
+    if (threadIdx.x < PpoOp::NACC)
+        sum = (red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1]) + (red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
+    publish_sums<PpoOp::NACC, 256>(sum, partials, fold);
 }
 
 // grad[row,i] = g1*c1[row]*(1[i==a] - p_i) + g2*c2[row]*(-p_i*(log p_i + H))
@@ -743,7 +803,39 @@ bool launch_bwd(const RowCfg& cfg, hipStream_t st, const float* logits, const in
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+#define HPC_RLL_PPO_CASE(G_, V_, E_)                                                                                      \
+    if (cfg.g == G_ && cfg.vec == V_ && cfg.e == E_) {                                                                    \
+        const long per = (256 / G_) * 4;                                                                                  \
+        long grid = (rows + per - 1) / per;                                                                               \
+        const long gmax = g_ppo_fused == 1 ? kFoldMaxGrid : g_ppo_fused == 2 ? 2048 : 4096;                               \
+        if (grid > gmax) grid = gmax;                                                                                     \
+        const ScanFold fold = make_fold(st, PpoOp::NACC, scales, out5, grid);                                             \
+        hipLaunchKernelGGL((ppo_fwd_fused_kernel<G_, V_, E_>), dim3((unsigned)grid), dim3(256), 0, st, logits_new,        \
+                           logits_old, action, op, rows, N, partials, fold);                                              \
+        const hipError_t e = hipGetLastError();                                                                           \
+        *rc = e == hipSuccess ? HPC_RLL_OK : (int)e;                                                                      \
+        if (*rc == HPC_RLL_OK && !fold.out) *rc = finalize_sums(partials, (int)grid, PpoOp::NACC, scales, out5, st);      \
+        return true;                                                                                                      \
+    }
+
 }  // namespace
+
+int g_ppo_fused = 1;   // hpc_rll_tune_set key 32: 0 off; 1 = at most 512 workgroups, sums folded in the launch; 2 / 3 = at most 2048 / 4096 workgroups + a finalize launch
+
+// Rows of at most 16 pieces per lane group (N <= 512 with 16-byte loads): the configurations of the row kernels that keep a
+// row in one DPP row.  Anything else: false, the caller runs the three launches.
+bool ppo_forward_fused(const float* logits_new, const float* logits_old, const int64_t* action, const PpoOp& op, long rows,
+                       int N, float* partials, const float* scales, float* out5, hipStream_t st, int* rc) {
+    if (rows <= 0 || N <= 0) return false;
+    if ((N % 4) != 0 && N <= kSmallMaxN) return false;          // (the small-N forward has its own kernel)
+    const RowCfg cfg = row_cfg(N, al16(logits_new) && al16(logits_old));
+    if (cfg.e > 2 || cfg.g > 16) return false;                  // registers: two heads x R rows x E pieces per lane
+    HPC_RLL_PPO_CASE(1, 4, 1) HPC_RLL_PPO_CASE(2, 4, 1) HPC_RLL_PPO_CASE(4, 4, 1) HPC_RLL_PPO_CASE(8, 4, 1)
+    HPC_RLL_PPO_CASE(16, 4, 1) HPC_RLL_PPO_CASE(16, 4, 2)
+    HPC_RLL_PPO_CASE(1, 1, 1) HPC_RLL_PPO_CASE(2, 1, 1) HPC_RLL_PPO_CASE(4, 1, 1) HPC_RLL_PPO_CASE(8, 1, 1)
+    HPC_RLL_PPO_CASE(16, 1, 1) HPC_RLL_PPO_CASE(16, 1, 2)
+    return false;
+}
 
 // Internal C++ entry points used by vtrace.hip / upgo.hip / ppo.hip (same library).
 int categorical_forward(const float* logits, const int64_t* action, float* logp, float* ent, long rows, int N,
@@ -813,7 +905,7 @@ int categorical_backward(const float* logits, const int64_t* action, const float
 
 }  // namespace hpc_rll
 
-namespace hpc_rll { extern int g_gemm_bk; extern int g_scatter_threads; extern int g_lstm_persist; extern int g_lstm_xchg_rep; extern int g_lstm_jw; extern int g_gemm_big_target; extern int g_gemm_big_tile128; extern int g_lstm_wave; extern int g_scatter_bwd_lds_kb; extern int g_gemm_xcd; extern int g_lstm_nn_bwd; extern int g_lstm_dh_big; extern int g_gemm_lat_target; extern int g_gemm_thr_ktiles; extern int g_cell_vec4; extern int g_gemm_tile256; extern int g_scatter_lds_fwd; extern int g_scatter_npb; extern int g_scan_wave_target; extern int g_cell_rows_wgs; extern int g_scan_fold; extern int g_split_algo; extern int g_gemm_exp; extern int g_sample_batch; extern int g_gemm_dma; extern int g_lstm_block; extern int g_lstm_block_skew; extern int g_pad_wave; extern int g_lstm_mid; extern int g_lstm_mid_rep; extern int g_onehot_fill_mb; }
+namespace hpc_rll { extern int g_gemm_bk; extern int g_scatter_threads; extern int g_lstm_persist; extern int g_lstm_xchg_rep; extern int g_lstm_jw; extern int g_gemm_big_target; extern int g_gemm_big_tile128; extern int g_lstm_wave; extern int g_scatter_bwd_lds_kb; extern int g_gemm_xcd; extern int g_lstm_nn_bwd; extern int g_lstm_dh_big; extern int g_gemm_lat_target; extern int g_gemm_thr_ktiles; extern int g_cell_vec4; extern int g_gemm_tile256; extern int g_scatter_lds_fwd; extern int g_scatter_npb; extern int g_scan_wave_target; extern int g_cell_rows_wgs; extern int g_scan_fold; extern int g_split_algo; extern int g_gemm_exp; extern int g_sample_batch; extern int g_gemm_dma; extern int g_lstm_block; extern int g_lstm_block_skew; extern int g_pad_wave; extern int g_lstm_mid; extern int g_lstm_mid_rep; extern int g_onehot_fill_mb; extern int g_ppo_fused; }
 extern "C" int hpc_rll_tune_set(int key, int value) {
     if (key == 0 && value >= 1 && value <= 64) { hpc_rll::g_blocks_per_cu = value; return HPC_RLL_OK; }
     if (key == 1 && (value == 0 || value == 16 || value == 32)) { hpc_rll::g_gemm_bk = value; return HPC_RLL_OK; }
@@ -846,6 +938,7 @@ extern "C" int hpc_rll_tune_set(int key, int value) {
     if (key == 29 && value >= 0 && value <= 2) { hpc_rll::g_lstm_mid = value; return HPC_RLL_OK; }
     if (key == 30 && value >= 1 && value <= 32) { hpc_rll::g_lstm_mid_rep = value; return HPC_RLL_OK; }
     if (key == 31 && value >= 0 && value <= 65536) { hpc_rll::g_onehot_fill_mb = value; return HPC_RLL_OK; }
+    if (key == 32 && value >= 0 && value <= 3) { hpc_rll::g_ppo_fused = value; return HPC_RLL_OK; }
     if (key == 24 && (value == 0 || value == 1 || value == 8 || value == 16 || value == 32 || value == 64)) { hpc_rll::g_sample_batch = value; return HPC_RLL_OK; }
     return HPC_RLL_EINVAL;
 }

@@ -78,27 +78,41 @@ __device__ __forceinline__ void publish_sums(float sum, float* __restrict__ part
     if (!fold.out) return;
     constexpr int NWAVES = NT / 64;
     __shared__ int s_last;
-    __shared__ double s_fin[NWAVES];
     const int lane = threadIdx.x & 63, wr = threadIdx.x >> 6;
     __syncthreads();   // every partial of this workgroup is out
     if (threadIdx.x == 0)
         s_last = __hip_atomic_fetch_add(fold.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!s_last) return;   // uniform: the last workgroup to arrive adds all partials
+    // Round 4: ALL NACC * ceil(grid / NT) partials of a thread are requested before the first use, the NACC sums share one
+    // barrier -- the first version walked the sums one after the other (a memory round trip and two barriers each: ~7 us of
+    // serial tail for PPO's five sums, more than its kernels' work at B = 65536).  Same additions in the same order.
+    constexpr int MAXI = (int)((kFoldMaxGrid + NT - 1) / NT);
+    float v[NACC][MAXI];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            const unsigned i = threadIdx.x + j * NT;
+            v[k][j] = i < gridDim.x ? __hip_atomic_load(partials + (size_t)k * gridDim.x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : 0.f;
+        }
+    __shared__ double s_fin2[NACC][NWAVES];
+#pragma unroll
     for (int k = 0; k < NACC; ++k) {
         double s = 0.0;
-        for (unsigned i = threadIdx.x; i < gridDim.x; i += NT)
-            s += (double)__hip_atomic_load(partials + (size_t)k * gridDim.x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j)
+            if (threadIdx.x + j * NT < gridDim.x) s += (double)v[k][j];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        if (lane == 0) s_fin[wr] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot = 0.0;
-            for (int i = 0; i < NWAVES; ++i) tot += s_fin[i];
-            fold.out[k] = (float)(tot * (double)fold.scale[k]);
-        }
-        __syncthreads();
+        if (lane == 0) s_fin2[k][wr] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double tot = 0.0;
+        for (int i = 0; i < NWAVES; ++i) tot += s_fin2[threadIdx.x][i];
+        fold.out[threadIdx.x] = (float)(tot * (double)fold.scale[threadIdx.x]);
     }
     if (threadIdx.x == 0) __hip_atomic_store(fold.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

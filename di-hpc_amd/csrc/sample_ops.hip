@@ -12,6 +12,7 @@
 
 #include "colscan.hpp"
 #include "hpc_rll_hip.h"
+#include "ppo_op.hpp"
 #include "stream_write.hpp"
 
 namespace hpc_rll {
@@ -20,6 +21,11 @@ int categorical_forward(const float* logits, const int64_t* action, float* logp,
                         hipStream_t st);
 int categorical_backward(const float* logits, const int64_t* action, const float* c1, const float* g1,
                          const float* c2, const float* g2, float* grad, long rows, int N, hipStream_t st);
+struct PpoOp;
+// categorical.hip: both policy heads and the per-sample loss in ONE launch; false = shape not covered (caller runs three)
+bool ppo_forward_fused(const float* logits_new, const float* logits_old, const int64_t* action, const PpoOp& op, long rows,
+                       int N, float* partials, const float* scales, float* out5, hipStream_t st, int* rc);
+extern int g_ppo_fused;
 
 namespace {
 
@@ -51,51 +57,6 @@ __global__ __launch_bounds__(256) void sample_kernel(const Op op, long n, float*
         sum = (red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1]) + (red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
     publish_sums<NACC, 256>(sum, partials, fold);   // with a fold: the last workgroup also finalises the sums (colscan.hpp)
 }
-
-// ---------------------------------------------------------------------------------------------- PPO
-struct PpoOp {
-    static constexpr int NACC = 5;
-    const float *logp_new, *ent, *logp_old, *value_new, *value_old, *adv, *ret, *weight;
-    float *coef_logp, *coef_ent, *gv_unit;
-    float clip, dual_clip, scale;
-    int use_value_clip;
-    __device__ void operator()(long i, float (&acc)[NACC]) const {
-        const float w = weight ? weight[i] : 1.f;
-        const float lpn = logp_new[i], lpo = logp_old[i], a = adv[i];
-        const float ratio = expf(lpn - lpo);
-        const float s1 = ratio * a;
-        const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
-        const float s2 = rc * a;
-        // min(s1, s2): s1 wins ties (identical value and identical derivative whenever they tie inside the clip range)
-        float inner = s1, dinner = s1;  // d inner / d logp_new = ratio * adv on the s1 branch
-        if (s2 < s1) { inner = s2; dinner = (rc == ratio) ? s1 : 0.f; }
-        if (dual_clip >= 1.f) {          // reference encodes "None" as 0 (rl_utils/ppo.py:136-137, ppo_kernel.h:188)
-            const float d = dual_clip * a;
-            if (d > inner) { inner = d; dinner = 0.f; }
-        }
-        acc[0] -= inner * w;
-        coef_logp[i] = -dinner * w * scale;
-        const float vn = value_new[i], r = ret[i];
-        float v = (r - vn) * (r - vn);
-        float dv = -(r - vn);            // d(0.5 v)/d value_new on the unclipped branch
-        if (use_value_clip) {
-            const float vo = value_old[i];
-            const float dvo = vn - vo;
-            const bool saturated = dvo > clip || dvo < -clip;   // d vclip / d value_new = 0 only when the clamp is active
-            const float vc = vo + fminf(fmaxf(dvo, -clip), clip);
-            const float v2 = (r - vc) * (r - vc);
-            // NB: with an inactive clamp vo + (vn - vo) can differ from vn by an ulp in fp32, so v2 may exceed v
-            // although mathematically equal; the gradient must then still flow (found by tests/test_fuzz_gpu.py)
-            if (v2 > v) { v = v2; dv = saturated ? 0.f : -(r - vc); }
-        }
-        acc[1] = fmaf(v, w, acc[1]);
-        gv_unit[i] = dv * w * scale;
-        acc[2] = fmaf(ent[i], w, acc[2]);
-        coef_ent[i] = w * scale;
-        acc[3] += lpo - lpn;
-        acc[4] += (ratio > 1.f + clip || ratio < 1.f - clip) ? 1.f : 0.f;
-    }
-};
 
 // ---------------------------------------------------------------------------------------------- q n-step TD
 __device__ __forceinline__ float h_transform(float x, float eps) {
@@ -251,7 +212,11 @@ int onehot_scatter(const float* g, const float* buf, const int64_t* action, floa
 using namespace hpc_rll;
 
 // ws layout (floats): [coef_logp B | coef_ent B | gv_unit B | logp_new B | ent B | logp_old B | partials]
-extern "C" int64_t hpc_rll_ppo_workspace_floats(int B) { return 6 * (int64_t)B + 8 * (((int64_t)B + 255) / 256 + 1); }
+// (partials: 5 sums x the workgroups of the launch -- ceil(B / 256) for the three-launch forward, up to 4096 for the fused one)
+extern "C" int64_t hpc_rll_ppo_workspace_floats(int B) {
+    const int64_t blocks = ((int64_t)B + 255) / 256 + 1;
+    return 6 * (int64_t)B + 8 * (blocks > 4097 ? blocks : 4097);
+}
 
 extern "C" int hpc_rll_ppo_forward(const float* logits_new, const float* logits_old, const int64_t* action,
                                    const float* value_new, const float* value_old, const float* adv,
@@ -265,15 +230,17 @@ extern "C" int hpc_rll_ppo_forward(const float* logits_new, const float* logits_
         return HPC_RLL_EINVAL;
     float *coef_logp = ws, *coef_ent = ws + B, *gv_unit = ws + 2 * (size_t)B, *lpn = ws + 3 * (size_t)B,
           *ent = ws + 4 * (size_t)B, *lpo = ws + 5 * (size_t)B, *partials = ws + 6 * (size_t)B;
-    int rc = categorical_forward(logits_new, action, lpn, ent, B, N, st);
+    PpoOp op{lpn, ent, lpo, value_new, value_old, adv, ret, weight, coef_logp, coef_ent, gv_unit,
+             clip_ratio, dual_clip, scale, use_value_clip};
+    // approx_kl and clipfrac are plain (unweighted) means over the LOCAL batch: scale by 1/B
+    const float sc[5] = {scale, 0.5f * scale, scale, 1.f / (float)B, 1.f / (float)B};
+    int rc = HPC_RLL_OK;
+    if (g_ppo_fused && ppo_forward_fused(logits_new, logits_old, action, op, B, N, partials, sc, out5, st, &rc)) return rc;
+    rc = categorical_forward(logits_new, action, lpn, ent, B, N, st);
     if (rc) return rc;
     rc = categorical_forward(logits_old, action, lpo, nullptr, B, N, st);
     if (rc) return rc;
-    PpoOp op{lpn, ent, lpo, value_new, value_old, adv, ret, weight, coef_logp, coef_ent, gv_unit,
-             clip_ratio, dual_clip, scale, use_value_clip};
     const int blocks = (B + 255) / 256;
-    // approx_kl and clipfrac are plain (unweighted) means over the LOCAL batch: scale by 1/B
-    const float sc[5] = {scale, 0.5f * scale, scale, 1.f / (float)B, 1.f / (float)B};
     const ScanFold fold = make_fold(st, 5, sc, out5, blocks);
     hipLaunchKernelGGL(sample_kernel<PpoOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials, fold);
     rc = last_error();

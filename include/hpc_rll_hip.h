@@ -172,6 +172,10 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * sample): outputs of at least this many MiB (default 256; 0 = never) are written as a fill in the store pattern that
  * reaches the part's write rate (one 256-thread workgroup per CU, grid-stride, 16-byte stores: 6.3-6.5 TB/s against
  * 4.5-5.9 for every other shape of the same loop) plus a second launch for the values.  Identical results.
+ * key 32: PPO forward (hpc_rll_ppo_forward) for rows of up to 512 logits: 1 (default) = ONE launch -- a lane group reads the
+ * same row of both policy heads, its last lane applies the per-sample loss, the sums are folded by the last workgroup;
+ * 0 = two categorical launches + the sample launch.  Same per-sample coefficients (the backward's inputs), the five sums
+ * add the rows in another grouping.
  */
 int hpc_rll_tune_set(int key, int value);
 

@@ -242,6 +242,42 @@ def test_ppo_oracle(B, N, dual, uvc):
     assert grad_err(vn64.grad.numpy(), dvn.grad.cpu().numpy()) < GTOL
 
 
+@pytest.mark.parametrize("B,N,dual,uvc", [(65536 + 19, 128, None, True), (4096, 18, 3.0, True), (70001, 6, None, False), (513, 256, 1.5, True),
+                                          (40000, 64, None, True), (1000, 20, None, False), (9, 2, 2.0, True)])
+def test_ppo_fused_forward_against_three_launches(B, N, dual, uvc):
+    """tune key 32: ONE launch (both policy heads of a row in one lane group, the per-sample loss in its last lane, folded
+    sums; csrc/categorical.hip: ppo_fwd_fused_kernel) against two categorical launches + the sample launch.  The per-sample
+    coefficients the backward consumes come from the same functions: both gradients must be the same BITS; the three
+    losses and the two info means add the rows in another grouping (rounding).  Row widths of every fused configuration
+    (N = 2 ... 256, 4- and 16-byte loads), ragged batches, more rows than one sweep of the 512-workgroup grid, masked actions."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.ppo import PPO
+    rng = np.random.default_rng(B + N)
+    ln = f32(rng, B, N)
+    lo = (ln + 0.3 * f32(rng, B, N)).astype(np.float32)
+    a = rng.integers(0, N, (B,)).astype(np.int64)
+    if N > 4:
+        ln[::7, 1] = -np.inf                                  # masked actions (never the taken one)
+        a[a == 1] = 2
+    vn, vo, adv, ret = f32(rng, B), f32(rng, B), f32(rng, B), f32(rng, B)
+    w = rng.random(B).astype(np.float32)
+    res = {}
+    try:
+        for key in (0, 1):
+            U.tune_set(32, key)
+            dln, dvn = G(ln, True), G(vn, True)
+            ls, info = PPO(B, N)(dln, G(lo), G(a), dvn, G(vo), G(adv), G(ret), G(w), 0.2, uvc, dual)
+            (ls[0] + 0.7 * ls[1] - 0.01 * ls[2]).backward()
+            res[key] = ([x.item() for x in ls], list(info), dln.grad.clone(), dvn.grad.clone())
+    finally:
+        U.tune_set(32, 1)
+    (l0, i0, g0, v0), (l1, i1, g1, v1) = res[0], res[1]
+    assert torch.equal(g0, g1) and torch.equal(v0, v1)
+    assert torch.isfinite(g1).all()
+    for x, y in zip(l0 + i0, l1 + i1):
+        assert abs(x - y) <= 2e-6 * max(abs(x), 1e-3), (x, y)
+
+
 def test_ppo_reference_inputs():
     """tests/test_ppo.py:10-27 literally: B=N=128, clip 0.2, value clip on, no dual clip, and EVERY float input an independent
     randn -- logits_old unrelated to logits_new (ratios from e^-5 to e^5, most samples clipped), negative weights, negative

@@ -203,6 +203,10 @@ def suite_ppo(B=65536, N=128):
     gl, gv = torch.empty(B, N, device=dev), torch.empty(B, device=dev)
     t_b = timed(lambda: U.PPOBackward([g1, g1, g1, ln.detach(), a, ws], [gl, gv]))
     report("ppo", f"B={B} N={N}", t_f, 2 * 4 * B * N + 8 * B + 20 * B, t_b, 2 * 4 * B * N + 8 * B)
+    # the host out of the picture (one pybind call per forward is ~20 us of CPU; the kernels take less): hipGraph replays
+    t_fk = timed_graph(lambda: U.PPOForward([ln.detach(), lo, a, vn.detach(), vo, adv, ret, None], [out5, ws], True, 0.2, 0.0))
+    t_bk = timed_graph(lambda: U.PPOBackward([g1, g1, g1, ln.detach(), a, ws], [gl, gv]))
+    add_kernel_times(t_fk, 2 * 4 * B * N + 8 * B + 20 * B, t_bk, 2 * 4 * B * N + 8 * B)
 
 
 def suite_c4(S=128, B=4096, I=1024, H=1024, L=1):
