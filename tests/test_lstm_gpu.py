@@ -589,7 +589,8 @@ def test_lstm_row_block_kernel_with_operands_off_a_16_byte_boundary():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("S,B,I,H,L", [(24, 3, 64, 384, 1), (16, 3, 48, 96, 3), (12, 4, 32, 512, 2)])   # per-layer / wavefront / mixed
+@pytest.mark.parametrize("S,B,I,H,L", [(24, 3, 64, 384, 1), (16, 3, 48, 96, 3), (12, 4, 32, 512, 2),   # per-layer / wavefront / mixed
+                                       (10, 48, 24, 256, 2), (8, 20, 16, 1024, 1)])   # mid-batch kernel: two streams / one stream of 256 workgroups
 def test_persistent_lstm_survives_a_busy_device(S, B, I, H, L):
     """VERDICT r01 item 5.  The persistent kernels need all their workgroups resident at once.  (a) A kernel that holds
     EVERY compute unit completely (two 1024-thread workgroups with 80 KB of LDS each per CU) for ~150 ms runs on a second stream while the B <= 4 LSTM forward+backward
