@@ -1064,7 +1064,10 @@ inline Ws carve(float* base, int S, int B, int I, int H, int L, bool dropout) {
     w.blk_part = take(perm ? block_part_floats(B, H) : 0);
     w.blk_flags = take(perm ? block_flag_words(B) : 0);
     w.pperm = take(perm ? 5 * G : 0);
-    w.mid = take(mid_ws_floats(S, B, H));
+    {   // (forward and backward of the mid-batch kernels share the region: never live at the same time)
+        const size_t mf = mid_ws_floats(S, B, H), mb = mid_bwd_ws_floats(S, B, H);
+        w.mid = take(mf > mb ? mf : mb);
+    }
     {   // persistent small-batch paths: {value, tag} exchange words (per-layer kernels / layer wavefront)
         size_t words = xchg_layout(B, H).total_words;
         WaveCfg wc{};
@@ -1198,7 +1201,7 @@ int lstm_forward_impl(const float* x, const float* h0, const float* c0, const fl
         return HPC_RLL_EALIGN;   // these shapes run 16-byte kernels only
     const bool block = perm && block_fwd_ok(B, H, st);
     // mid-size batches: one persistent kernel per layer with the product on the matrix cores (lstm_mid.hpp)
-    const bool mid = S > 0 && !persist && !perm && mid_fwd_ok(B, H, st);
+    const bool mid = S > 0 && !persist && !perm && cell_al16(ws) && mid_fwd_ok(B, H, st);   // (16-byte accesses to the workspace)
     if (persist) g_lstm_last_path.store(1, std::memory_order_relaxed);
     if (mid) g_lstm_last_path.store(5, std::memory_order_relaxed);
     if (perm) g_lstm_last_path.store(block ? 4 : 3, std::memory_order_relaxed);
@@ -1500,7 +1503,16 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
             if (prc) return prc;
             persist_prof_report("bwd", l, S, st);
         }
-        if (!persist && nn_dh) launch_transpose(wh_l, w.whT, H, (int)G, st);   // (H, G) -> (G, H): B(k=g, n=h) = whT[g*H + h]
+        // mid-size batches: the backward recurrence of the layer in one persistent kernel (lstm_mid.hpp)
+        const bool midb = !persist && !perm && lw.gates && cell_al16(ws) && mid_bwd_ok(B, H, st);
+        if (midb) {
+            MidBwd ma{d_out, dh_carry, dc_carry, lw.gates, lw.c, c0 + (size_t)l * BH, lw.xw, lw.hw, lw.stats, gamma_l, wh_l,
+                      w.dgate, w.dxw, w.dhw, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, nullptr, nullptr, nullptr, nullptr,
+                      S, B, H, 0, 0, 0, 0, nullptr};
+            const int mrc = launch_mid_bwd(ma, w.mid, l, st);
+            if (mrc) return mrc;
+        }
+        if (!persist && !midb && nn_dh) launch_transpose(wh_l, w.whT, H, (int)G, st);   // (H, G) -> (G, H): B(k=g, n=h) = whT[g*H + h]
         // large batches: the cell walks several rows per workgroup and keeps the bias / gamma / beta column sums (no
         // dgate buffer, no reduction pass) -- 16-byte accesses, so every base pointer must be 16-byte aligned
         const int rows_wgs = perm ? (g_cell_rows_wgs > 0 ? g_cell_rows_wgs : 512)   // (the only cell of this layout)
@@ -1509,14 +1521,14 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
                                  ? (B < g_cell_rows_wgs ? B : g_cell_rows_wgs) : 0;
         // large batches on the interleaved layout: the whole backward recurrence of the layer in one persistent kernel
         const bool blockb = perm && !persist && block_bwd_ok(B, H, st);
-        g_lstm_last_bwd_path.store(persist ? 1 : blockb ? 4 : perm ? 3 : 0, std::memory_order_relaxed);
+        g_lstm_last_bwd_path.store(persist ? 1 : midb ? 5 : blockb ? 4 : perm ? 3 : 0, std::memory_order_relaxed);
         if (blockb) {
             BlockBwd ba{d_out, dh_carry, dc_carry, lw.xw, lw.hw, lw.c, c0 + (size_t)l * BH, lw.stats, w.pperm, w.whP, w.dxw, w.dhw,
                         w.dgate, w.dc, dh0 + (size_t)l * BH, dc0 + (size_t)l * BH, nullptr, nullptr, nullptr, S, B, H, 0, 0, 0, nullptr, 0};
             const int brc = launch_block_bwd(ba, w.blk_part, reinterpret_cast<unsigned*>(w.blk_flags), w.colpart, st);
             if (brc) return brc;
         }
-        for (int s = S - 1; s >= 0 && !persist && !blockb; --s) {
+        for (int s = S - 1; s >= 0 && !persist && !blockb && !midb; --s) {
             const float* c_prev = s == 0 ? c0 + (size_t)l * BH : lw.c + (size_t)(s - 1) * BH;
             const CellBwdArgs ca{d_out ? d_out + (size_t)s * BH : (const float*)nullptr, dh_carry, dh_parts, (long)BH, dc_carry,
                                  lw.gates ? (const float*)(lw.gates + (size_t)s * B * G) : (const float*)nullptr,
@@ -1536,7 +1548,7 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
         }
         int rc = last_error();
         if (rc) return rc;
-        if (!persist && !blockb) {
+        if (!persist && !blockb && !midb) {
             hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((BH + 255) / 256)), dim3(256), 0, st,
                                (const float*)w.dh, dh_parts, (long)BH, dh0 + (size_t)l * BH);
             if ((rc = copy_async(dc0 + (size_t)l * BH, w.dc, BH, st))) return rc;

@@ -176,6 +176,11 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * same row of both policy heads, its last lane applies the per-sample loss, the sums are folded by the last workgroup;
  * 0 = two categorical launches + the sample launch.  Same per-sample coefficients (the backward's inputs), the five sums
  * add the rows in another grouping.
+ * key 33: the persistent mid-batch LSTM BACKWARD (the shapes of key 29; one launch per layer: the LayerNorm-adjoint row sums
+ * and dHW exchanged on the forward kernel's protocol, dh_prev = dHW @ Wh^T on v_mfma_f32_4x4x1_16b_f32 against rows of Wh
+ * resident in LDS): 1 (default) = where it is faster than one cell launch + one split-K product per step (B <= 32: every
+ * workgroup reads all of dHW_s, four times the forward's exchange, and above that the step kernels win), 2 = every shape of
+ * key 29, 0 = off.  Same outputs to rounding.
  */
 int hpc_rll_tune_set(int key, int value);
 
@@ -384,7 +389,7 @@ int hpc_rll_lstm_backward_y(const float* dy, const float* dhn, const float* dcn,
  * (large batch), 4 = persistent row-block kernel (large batch, tune key 26), 5 = persistent mid-batch kernel (5 <= B <= 256,
  * tune key 29); -1 = no forward yet. */
 int hpc_rll_lstm_last_forward_path(void);
-int hpc_rll_lstm_last_backward_path(void);   /* the same for the most recent hpc_rll_lstm_backward* call (its last layer) */
+int hpc_rll_lstm_last_backward_path(void);   /* the same for the most recent hpc_rll_lstm_backward* call (its last layer; 5 = mid-batch kernel, key 33) */
 /* Asynchronous status of the persistent small-batch LSTM kernels (B <= 4).  Their workgroups exchange data through
  * memory and must all be resident at once; that is checked against the runtime's occupancy figure at dispatch and
  * launches of one process are serialised per device, but ANOTHER PROCESS holding compute units for seconds can still

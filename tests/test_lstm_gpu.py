@@ -557,6 +557,56 @@ def test_lstm_mid_batch_kernel_against_step_kernels(S, B, I, H, L, p):
         assert not torch.equal(step[0], got[0])              # another summation order: the kernel did run
 
 
+@pytest.mark.parametrize("S,B,I,H,L,p", [(10, 64, 32, 1024, 1, 0.0), (14, 24, 24, 384, 3, 0.2), (5, 200, 16, 512, 2, 0.0), (6, 5, 8, 64, 1, 0.0),
+                                         (4, 128, 16, 1024, 1, 0.0), (7, 70, 12, 208, 1, 0.0)])
+def test_lstm_mid_batch_backward_kernel_against_step_kernels(S, B, I, H, L, p):
+    """tune key 33: the persistent mid-batch BACKWARD (one launch per layer: row sums and dHW exchanged without fences, dh_prev
+    on the 4x4 matrix instruction against rows of Wh in LDS) against one cell launch + one split-K product per step, fed by
+    the SAME forward (mid-batch kernel, same saved tensors): every gradient to rounding -- the k slices of dh_prev and the
+    row sums are added in another order -- and the path that ran is reported.  Ragged batches (5, 24, 70, 200 rows: one to
+    four 64-row groups), H / 4 workgroups with and without a k split (H = 208: 52 workgroups), dropout, no dy / dhn / dcn."""
+    import hpc_torch_utils_network as N
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(S * 3 + B + H)
+    m = LSTM(S, B, I, H, L, dropout=p).to(DEV)
+    with torch.no_grad():
+        m.ln_gamma.add_(0.1 * torch.randn_like(m.ln_gamma))
+        m.ln_beta.add_(0.1 * torch.randn_like(m.ln_beta))
+    x = torch.randn(S, B, I, device=DEV)
+    h0, c0 = torch.randn(L, B, H, device=DEV), torch.randn(L, B, H, device=DEV)
+    gy, gh, gc = torch.randn(S, B, H, device=DEV), torch.randn(L, B, H, device=DEV), torch.randn(L, B, H, device=DEV)
+
+    def run(only_y):
+        for q in m.parameters():
+            q.grad = None
+        xs, hs, cs = (t.clone().requires_grad_(True) for t in (x, h0, c0))
+        torch.manual_seed(7)
+        y, (hn, cn) = m(xs, (hs, cs))
+        assert N.lstm_last_forward_path() == 5
+        ((y * gy).sum() if only_y else (y * gy).sum() + (hn * gh).sum() + (cn * gc).sum()).backward()
+        torch.cuda.synchronize()
+        assert N.async_error() == 0
+        return N.lstm_last_backward_path(), [t.detach().clone() for t in (xs.grad, hs.grad, cs.grad, m.wx.grad, m.wh.grad, m.bias.grad,
+                                                                         m.ln_gamma.grad, m.ln_beta.grad)]
+
+    for only_y in (False, True):
+        try:
+            N.tune_set(33, 0)
+            p0, step = run(only_y)
+            N.tune_set(33, 2)                    # every mid-batch shape (the default, 1, takes it for B <= 32 only: where it pays)
+            p1, mid = run(only_y)
+            N.tune_set(33, 1)
+            p2, _ = run(only_y)
+        finally:
+            N.tune_set(33, 1)
+        assert (p0, p1, p2) == (0, 5, 5 if B <= 32 else 0)
+        for k, a, b in zip("dx dh0 dc0 dwx dwh dbias dgamma dbeta".split(), step, mid):
+            assert torch.isfinite(b).all(), k
+            scale = float(a.abs().max())
+            err = float((a - b).abs().max()) / scale
+            assert err < 2e-5, (k, err, scale, only_y)
+
+
 def test_lstm_row_block_kernel_with_operands_off_a_16_byte_boundary():
     """The large-batch kernels use 16-byte accesses (the C ABI answers HPC_RLL_EALIGN to a pointer off that boundary);
     the extension copies such an operand once instead of failing: x / h0 / c0 / dy that are contiguous views starting

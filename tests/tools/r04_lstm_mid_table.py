@@ -20,6 +20,12 @@ from hpc_rll.torch_utils.network.rnn import LSTM  # noqa: E402
 
 dev = torch.device("cuda:0")
 S = 64
+TAG = ""
+for _kv in os.environ.get("HPC_RLL_TUNE", "").split(","):      # e.g. HPC_RLL_TUNE=33:0 (A/B runs of this tool; tags the output file)
+    if ":" in _kv:
+        import hpc_torch_utils_network as _N
+        _N.tune_set(int(_kv.split(":")[0]), int(_kv.split(":")[1]))
+        TAG += "_" + _kv.replace(":", "-")
 
 
 def timed(fn, n=5, rounds=3):
@@ -101,4 +107,4 @@ for B in (16, 64, 256):
         rows.append(r)
         print(json.dumps(r), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "r04_lstm_mid_table.json"), "w"), indent=1)
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "r04_lstm_mid_table" + TAG + ".json"), "w"), indent=1)
