@@ -946,6 +946,9 @@ extern "C" int hpc_rll_pad1d_packed_forward(const float* flat, const int64_t* ta
     if (max_len >= 32 && max_len <= 16384 && g_pad_wave) {   // wave tiles in output space (round 4)
         const long ntiles = (long)(((unsigned long)n * (unsigned long)max_len + 1023) / 1024);
         long wb = (ntiles + 3) / 4;
+        // (fewer, persistent workgroups -- the shape that makes a pure fill fast, profiles/r04_writebw.txt -- are SLOWER here:
+        // 1 / 2 / 4 / 8 workgroups per CU 612 / 466 / 324 / 315 us against 270 for the API call: a tile is a chain of table
+        // lookups, source loads, LDS and stores that needs many tiles in flight per CU)
         if (wb > 8192) wb = 8192;
         hipLaunchKernelGGL(pad1d_packed_wave_kernel, dim3((unsigned)wb), dim3(256), 0, (hipStream_t)stream, flat, table, new_x, mask,
                            (long)n, (unsigned)max_len, 1.0f / (float)max_len, (float)value, value);

@@ -33,7 +33,7 @@ inline int device_cus() {   // CU count of the current device (cached per device
 // `shift` = 16-byte elements between the 4 KiB boundary below y and y: the loop runs over indices from that boundary, so that
 // every workgroup's 256 x 16 bytes are ONE 4 KiB-aligned block (the same loop on a base 512 bytes off such a boundary:
 // 5.7 instead of 6.5 TB/s).
-__global__ __launch_bounds__(256) void stream_zero_kernel(vfloat4* __restrict__ y, size_t n4, unsigned shift,
+static __global__ __launch_bounds__(256) void stream_zero_kernel(vfloat4* __restrict__ y, size_t n4, unsigned shift,
                                                           float* __restrict__ tail, int ntail) {
     const vfloat4 z = {0.f, 0.f, 0.f, 0.f};
     const size_t nt = (size_t)gridDim.x * 256, end = n4 + shift;
