@@ -1201,7 +1201,7 @@ int lstm_forward_impl(const float* x, const float* h0, const float* c0, const fl
         return HPC_RLL_EALIGN;   // these shapes run 16-byte kernels only
     const bool block = perm && block_fwd_ok(B, H, st);
     // mid-size batches: one persistent kernel per layer with the product on the matrix cores (lstm_mid.hpp)
-    const bool mid = S > 0 && !persist && !perm && cell_al16(ws) && mid_fwd_ok(B, H, st);   // (16-byte accesses to the workspace)
+    const bool mid = S > 0 && !persist && !perm && cell_al16(ws) && cell_al16(h0) && mid_fwd_ok(B, H, st);   // (16-byte accesses to the workspace and h0)
     if (persist) g_lstm_last_path.store(1, std::memory_order_relaxed);
     if (mid) g_lstm_last_path.store(5, std::memory_order_relaxed);
     if (perm) g_lstm_last_path.store(block ? 4 : 3, std::memory_order_relaxed);

@@ -360,7 +360,7 @@ def test_lstm_dropout(B):
                                        # ... and more of the mid-batch kernel's (lstm_mid.hpp): ragged batches (5, 17, 40, 100,
                                        # 129 rows in 1 / 2 / 4 / 8 / 16 row blocks), H / 16 odd (one k slice), H = 64
                                        (7, 5, 20, 64, 2), (5, 40, 24, 400, 1), (3, 100, 16, 208, 2), (4, 17, 8, 1024, 1),
-                                       (3, 129, 8, 256, 1), (9, 33, 12, 768, 1)])
+                                       (3, 129, 8, 256, 1), (9, 33, 12, 768, 1), (1, 12, 8, 128, 2), (2, 30, 8, 64, 1)])   # ... one and two steps
 def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
     """B <= 4 runs the persistent kernels (lstm_persist.hpp / lstm_wave.hpp), 5 <= B <= 256 with H % 16 == 0 the persistent
     mid-batch kernel (lstm_mid.hpp; forward only -- the other B > 4 cases here exercise the step path twice); hpc_rll_tune_set(3, 0) forces the step-kernel
