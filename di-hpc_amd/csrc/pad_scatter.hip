@@ -859,6 +859,74 @@ __global__ __launch_bounds__(1024) void scatter_bwd_lds_kernel(const float* __re
     }
 }
 
+// Round 4 EXPERIMENT (tune key 34 = 1; default off: 1.25 ms against 0.865 at C5 -- 64 KB of loads in flight per CU is all the
+// LDS leaves beside the gathered block, and the memory latency under load wants twice that; bit-identical results): the same
+// backward as a PERSISTENT, software-pipelined kernel.  The kernel above reads all of
+// grad_out once -- at 256 entities on a 64 x 64 map nearly every 64-byte sector holds a wanted element, so the full sequential
+// read is the right traffic -- but as 65536 short-lived workgroups (stage 64 KB, barrier, gather, exit) it streams at 4.9-5.0
+// TB/s where a pure read reaches 6.5-7.  Here one workgroup per CU walks whole batch elements: eight waves keep FOUR planes
+// (LDS-DMA, global_load_lds_dwordx4: no staging registers) in flight into a five-plane ring while four waves gather the plane
+// that has landed; the gathered (M, N) block of a batch element is collected in LDS and written once, 64 KB contiguous
+// (the one-launch-per-tile kernel wrote it as 16-byte pieces from 16 different workgroups).  Needs HW = 2048 or 4096 (eight loader waves x
+// whole-KiB pieces), M <= 256 and ring + block within the CU's LDS.
+template <int NBUF>
+__global__ __launch_bounds__(1024) void scatter_bwd_stream_kernel(const float* __restrict__ grad_out, const int64_t* __restrict__ location,
+                                                                  float* __restrict__ grad_x, int B, int M, int N, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float s_ring[];   // [NBUF][HW] planes, then [M][N + 1] the gathered block
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gl_ptr;
+    const int HW = H * W, ld = N + 1;
+    float* const s_out = s_ring + (size_t)NBUF * HW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool gatherer = wave < 4, loader = wave >= 4 && wave < 12;
+    const int per = HW / 8;                                // floats of a plane per loader wave (a multiple of 256)
+    const long nb = ((long)B - blockIdx.x + gridDim.x - 1) / gridDim.x;   // batch elements of this workgroup
+    const long nplanes = nb * N;                           // its planes, in order: b = blockIdx.x + (i / N) * gridDim.x, n = i % N
+    auto plane_ptr = [&](long i) { return grad_out + (((size_t)blockIdx.x + (size_t)(i / N) * gridDim.x) * N + (size_t)(i % N)) * HW; };
+    auto issue = [&](long i) __attribute__((always_inline)) {   // loader waves: plane i -> ring slot i % NBUF
+        const float* src = plane_ptr(i) + (size_t)(wave - 4) * per + 4 * lane;
+        float* dst = s_ring + (size_t)(i % NBUF) * HW + (size_t)(wave - 4) * per;
+        for (int c = 0; c < per; c += 256) __builtin_amdgcn_global_load_lds((gl_ptr)(src + c), (lds_ptr)(dst + c), 16, 0, 0);
+    };
+    if (loader)
+        for (long i = 0; i < NBUF - 1 && i < nplanes; ++i) issue(i);
+    int cell = -1;
+    for (long i = 0; i < nplanes; ++i) {
+        const long bi = i / N;
+        const int n = (int)(i - bi * N);
+        const long b = blockIdx.x + bi * gridDim.x;
+        if (loader) {
+            // plane i must have landed: at most the NBUF - 2 planes issued after it may still be in flight (per / 256 loads each)
+            const int k = per / 256;
+            if (i + NBUF - 1 <= nplanes) {                  // steady state: NBUF - 2 younger planes outstanding
+                if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF - 2) : "memory");
+                else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NBUF - 2)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: no more planes are being issued
+            }
+        }
+        if (gatherer && n == 0 && tid < M) {               // the entity's cell of this batch element
+            const int64_t* lp = location + ((size_t)b * M + tid) * 2;
+            const long y = lp[0], xx = lp[1];
+            cell = (y >= 0 && y < H && xx >= 0 && xx < W) ? (int)(y * W + xx) : -1;
+        }
+        __syncthreads();                                   // plane i is in LDS; the slot of plane i - 1 is free
+        if (loader && i + NBUF - 1 < nplanes) issue(i + NBUF - 1);
+        if (gatherer && tid < M) s_out[tid * ld + n] = cell >= 0 ? s_ring[(size_t)(i % NBUF) * HW + cell] : 0.f;
+        if (n == N - 1) {                                  // the batch element is complete: its (M, N) block, contiguous
+            __syncthreads();
+            if (!loader) {                                 // (the loaders' vmcnt bookkeeping must not see these stores)
+                float* gx = grad_x + (size_t)b * M * N;
+                const int t8 = wave < 4 ? tid : tid - 512; // 512 threads: waves 0-3 and 12-15
+                for (int e = t8; e < M * N; e += 512) gx[e] = s_out[(e / N) * ld + e % N];
+            }
+            // (the next write to s_out is behind the next iteration's barrier)
+        }
+    }
+}
+
 // fallback for planes too large for LDS: direct gather
 __global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __restrict__ grad_out,
                                                                  const int64_t* __restrict__ location,
@@ -880,6 +948,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __
 
 namespace hpc_rll { int g_pad_wave = 1; }   // hpc_rll_tune_set key 28: packed Pad1D on wave tiles in output space (0 = the round-3 workgroup kernel)
 namespace hpc_rll { int g_scatter_threads = 1024; int g_scatter_bwd_lds_kb = 64; int g_scatter_lds_fwd = 1; int g_scatter_npb = 0; }
+namespace hpc_rll { int g_scatter_bwd_stream = 0; }   // hpc_rll_tune_set key 34: persistent pipelined scatter backward (experiment: slower, see the kernel)
 using namespace hpc_rll;
 
 extern "C" int hpc_rll_pad_forward(const int64_t* table, float* new_x, int32_t* mask, int64_t n, int m0, int m1,
@@ -1269,6 +1338,22 @@ extern "C" int hpc_rll_scatter_connection_backward(const float* grad_out, const 
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
     const long plane_bytes = HW * 4;
+    {   // persistent pipelined kernel: planes that split into eight whole-KiB pieces, ring + gathered block within the LDS
+        constexpr int NBUF = 5;
+        const size_t lds = ((size_t)NBUF * HW + (size_t)M * (N + 1)) * 4;
+        if (g_scatter_bwd_stream && HW % 2048 == 0 && HW / 2048 <= 2 && M <= 256 && M > 0 && lds <= 150 * 1024 &&
+            (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0 && (long)B * N >= 4096) {
+            int cus = 0, dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (cus <= 0) cus = 256;
+            if (hipFuncSetAttribute((const void*)scatter_bwd_stream_kernel<NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+                hipSuccess)
+                return last_error();
+            hipLaunchKernelGGL(scatter_bwd_stream_kernel<NBUF>, dim3((unsigned)std::min<long>(B, cus)), dim3(1024), lds, st, grad_out,
+                               location, grad_x, B, M, N, H, W);
+            return last_error();
+        }
+    }
     if (plane_bytes <= 128 * 1024 && B <= 65535) {
         int NG = (int)std::min<long>(N, std::max<long>(1, (long)g_scatter_bwd_lds_kb * 1024 / plane_bytes));
         if (NG > 32) NG = 32;

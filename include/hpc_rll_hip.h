@@ -181,6 +181,10 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * resident in LDS): 1 (default) = where it is faster than one cell launch + one split-K product per step (B <= 32: every
  * workgroup reads all of dHW_s, four times the forward's exchange, and above that the step kernels win), 2 = every shape of
  * key 29, 0 = off.  Same outputs to rounding.
+ * key 34: scatter-connection backward as ONE persistent software-pipelined kernel (a workgroup per CU walks whole batch elements;
+ * LDS-DMA keeps four planes in flight into a five-plane ring while the landed plane is gathered; a batch element's (M, N) block is
+ * written once, contiguous): 1 = on (planes of 2048 or 4096 elements, M <= 256), 0 (default) = one workgroup per (batch element,
+ * channel group) -- an experiment that lost: 1.25 against 0.865 ms at 4096 x 64 planes of 64 x 64.  Identical results.
  */
 int hpc_rll_tune_set(int key, int value);
 

@@ -367,6 +367,36 @@ def test_scatter_oracle_bit_exact(B, M, N, H, W):
         assert torch.equal(xd.grad.cpu(), xo.grad), st
 
 
+@pytest.mark.parametrize("B,M,N,H,W", [(70, 200, 64, 64, 64), (300, 256, 16, 32, 64), (257, 37, 17, 64, 64), (1100, 1, 4, 64, 32)])
+def test_scatter_backward_stream_kernel_bit_exact(B, M, N, H, W):
+    """tune key 34 (an experiment that is slower and off by default): the persistent software-pipelined backward (a workgroup per CU walks whole batch elements, LDS-DMA ring of
+    five planes, the (M, N) block of a batch element written once) against one workgroup per (batch element, channel group):
+    the same bits, and both equal to the CPU oracle's gather on a slice.  More batch elements than CUs and fewer per
+    workgroup than one (B = 70), planes of 2048 and 4096 elements, odd N, M = 1, out-of-range locations (gradient 0)."""
+    import hpc_torch_utils_network as NW
+    rng = np.random.default_rng(B + N)
+    loc = np.stack([rng.integers(-1, H + 1, (B, M)), rng.integers(-1, W + 1, (B, M))], -1).astype(np.int64)
+    gout = torch.from_numpy(rng.standard_normal((B, N, H, W)).astype(np.float32)).to(DEV)
+    dloc = torch.from_numpy(loc).to(DEV)
+    res = {}
+    try:
+        for key in (0, 1):
+            NW.tune_set(34, key)
+            gx = torch.full((B, M, N), float("nan"), device=DEV)
+            NW.ScatterConnectionBackward([gout, dloc], [gx])
+            res[key] = gx.clone()
+    finally:
+        NW.tune_set(34, 0)
+    assert torch.equal(res[0], res[1])
+    y, xx = loc[..., 0], loc[..., 1]
+    ok = (y >= 0) & (y < H) & (xx >= 0) & (xx < W)
+    gc = gout.cpu().numpy()
+    want = np.zeros((B, M, N), np.float32)
+    bb, mm = np.nonzero(ok)
+    want[bb, mm, :] = gc[bb, :, y[bb, mm], xx[bb, mm]]
+    assert np.array_equal(res[1].cpu().numpy(), want)
+
+
 def test_scatter_deterministic_and_full_write():
     """`cover` is deterministic (the reference kernel is a race) and the output needs no pre-zeroing."""
     import hpc_torch_utils_network as U
