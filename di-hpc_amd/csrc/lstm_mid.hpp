@@ -1,4 +1,4 @@
-// lstm_mid.hpp -- persistent MID-BATCH forward of the LayerNorm-LSTM (included by lstm.hip only).
+// lstm_mid.hpp -- persistent MID-BATCH kernels of the LayerNorm-LSTM: forward, and a backward (below) (included by lstm.hip only).
 //
 // Regime: 5 <= B <= 256, 64 <= H <= 1024, H % 16 == 0 -- the batches RL actors and small learners run (the reference's own
 // test is B = 3: tests/test_lstm.py:10-16; its per-step cost model is src/torch_utils/network/lstm.cu:145-161: one SGEMM,
@@ -14,13 +14,16 @@
 //     16-row block mb and the k slice kq (16 waves = mbp row blocks x ks k slices), reads its A operand straight from
 //     h_{s-1} in global memory (L2: every workgroup reads all of it) and leaves a 16 x 16 partial tile in LDS;
 //   * thread (row, unit) adds the k slices of its four gates (a fixed order: deterministic), keeps c in a register;
-//   * two exchanges per step between ALL workgroups: (1) LayerNorm partials -- every workgroup publishes (mean, M2) of its
-//     16 columns per row, every workgroup combines all of them (fixed order) -- and (2) h_s itself.  A flag word per
-//     workgroup and exchange carries the step number; the waiting wave reads all flags in one poll (no atomics, no
-//     counter); the data moves without cache-wide fences (see "Exchange protocol" below).
+//   * two exchanges per step between ALL workgroups: (1) LayerNorm partials -- every workgroup sends (mean, M2) of its 16
+//     columns per row as {value, tag} words to ONE combiner workgroup per row, which sends (mean, rstd) back the same way
+//     -- and (2) h_s itself: a slot per step, write-through stores, a flag word per workgroup carrying the step number (the
+//     waiting wave reads all flags in one poll: no atomics, no counter), ordinary loads by the readers.  No cache-wide
+//     fences anywhere (see "Exchange protocol" below).
 // Co-residency, bounded waits and the timeout protocol are lstm_persist.hpp's (persist_runtime_ready, persist_resident_t,
 // persist_poll_failed).  The saved-for-backward tensors (hw, gates, c, hseq, stats) are written exactly as the step kernels
-// write them, so the backward is unchanged.
+// write them, so either backward (the step kernels, or lstm_mid_bwd_kernel below) can follow.
+// Measured history of the protocol, phase times and what bounds the step: DESIGN.md 4.6, profiles/r04_lstm_mid_phases.txt,
+// profiles/r04_bcast_micro.txt, profiles/r04_lstm_mid_bwd.txt.
 #pragma once
 
 namespace hpc_rll {
