@@ -389,6 +389,34 @@ def suite_small():
     report("lstm_small", f"S={S} B={B} I={I} H={H} L={L}", t_f, None, t_b, None, fl, 2 * fl)
 
 
+def suite_lstm_mid():
+    """mid-size batches: the persistent mid-batch kernels (csrc/lstm_mid.hpp) at the shapes of the latency
+    table, I = H, L = 1, S = 64; us per step = whole forward (backward) / S, beside the matrix floor of the recurrent product."""
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    import hpc_torch_utils_network as NW
+    S = 64
+    for B, H in ((64, 1024), (16, 384)):
+        torch.manual_seed(0)
+        m = LSTM(S, B, H, H, 1).to(dev)
+        x = torch.randn(S, B, H, device=dev, requires_grad=True)
+        y, _ = m(x, None)
+        fpath = NW.lstm_last_forward_path()
+        t_f = timed(lambda: m(x, None), n=3)
+        g = torch.ones_like(y)
+
+        def bwd():
+            x.grad = None
+            y.backward(g, retain_graph=True)
+
+        t_b = timed(bwd, n=3)
+        fl = 2.0 * S * B * 4 * H * (H + H)
+        report("lstm_mid", f"S={S} B={B} I={H} H={H} L=1", t_f, None, t_b, None, fl, 2 * fl)
+        rows[-1]["op"] = f"lstm_mid_B{B}_H{H}"
+        rows[-1].update(fwd_us_per_step=t_f / S * 1e6, bwd_us_per_step=t_b / S * 1e6, forward_path=fpath,
+                        backward_path=NW.lstm_last_backward_path(),
+                        recurrent_product_matrix_floor_us=2.0 * B * 4 * H * H / (MFMA_F32 * 1e12) * 1e6)
+
+
 if __name__ == "__main__":
     import faulthandler
     faulthandler.enable()
@@ -427,5 +455,6 @@ if __name__ == "__main__":
         suite_c5()
     if which in ("small", "all"):
         suite_small()
+        suite_lstm_mid()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", f"suite_{which}.json"), "w"), indent=1)
