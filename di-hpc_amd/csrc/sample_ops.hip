@@ -10,6 +10,8 @@
 // (wave butterfly -> LDS -> one partial per workgroup -> fixed-order fp64 finalize), no float atomics.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "colscan.hpp"
 #include "hpc_rll_hip.h"
 #include "ppo_op.hpp"
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(256) void onehot_values_kernel(const float* __restr
 
 }  // namespace
 
-int g_onehot_fill_mb = 256;   // hpc_rll_tune_set key 31: outputs of at least this many MiB are written as fill + values (0 = never)
+int g_onehot_fill_mb = 3072;  // hpc_rll_tune_set key 31: outputs of at least this many MiB are written as fill + values (0 = never)
+int g_onehot_qpw = 0;         // hpc_rll_tune_set key 35: 16-byte quads per workgroup of the one-launch one-hot kernel (0 = by size)
 
 // planes > 1: grad is (planes, B, N) and buf is (B, planes) (K must be 1); else grad is (B, N, K), buf (B, K).
 int onehot_scatter(const float* g, const float* buf, const int64_t* action, float* grad, long B, int N, int K,
@@ -193,7 +196,11 @@ int onehot_scatter(const float* g, const float* buf, const int64_t* action, floa
     if (L % 4 == 0 && L / 4 < (1L << 20) && (reinterpret_cast<uintptr_t>(grad) & 15) == 0 && (planes <= 1 || K == 1) &&
         planes <= 65535) {
         const unsigned l4 = (unsigned)(L / 4);
-        const int rb = l4 >= 4096 ? 1 : (int)(4096 / l4);          // ~16 quads per thread
+        // Quads per workgroup (tune key 35; 0 = by size).  Round 4: 4096 (16 per thread, a dependent action / value load chain each)
+        // -> 256 for outputs of 256 MiB and more: ONE quad per thread, the workgroup writes one 4 KiB block and retires (IQN
+        // 0.114 -> 0.091 ms, QR-DQN 0.412 -> 0.358, C51 0.642 -> 0.623); 1024 below that (q-TD at 67 MB: 23.2 -> 16.9 us, 256: 20.0)
+        const long qpw = g_onehot_qpw > 0 ? g_onehot_qpw : (total * 4 >= (256L << 20) ? 256 : 1024);
+        const int rb = (long)l4 >= qpw ? 1 : (int)(qpw / l4);
         const unsigned magic = (unsigned)(((1ull << 32) + l4 - 1) / l4);   // q / l4 == umulhi(q, magic) for q < 2^32 / l4
         const long blocks = (B + rb - 1) / rb;
         hipLaunchKernelGGL(onehot_rows4_kernel, dim3((unsigned)blocks, planes > 1 ? planes : 1), dim3(256), 0, st, g, buf,

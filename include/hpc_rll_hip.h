@@ -169,9 +169,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * key 30: replicas (1 ... 32, default 8) of the words every workgroup of that kernel polls (its flags and final row
  * statistics): 256 pollers on one cache line cost 4.4 us per exchange, a single one sees a store after 0.6 us.
  * key 31: one-hot gradients (the backward of the q / dist / IQN / QR-DQN n-step TD losses: all zeros except K values per
- * sample): outputs of at least this many MiB (default 256; 0 = never) are written as a fill in the store pattern that
- * reaches the part's write rate (one 256-thread workgroup per CU, grid-stride, 16-byte stores: 6.3-6.5 TB/s against
- * 4.5-5.9 for every other shape of the same loop) plus a second launch for the values.  Identical results.
+ * sample): outputs of at least this many MiB (default 3072; 0 = never) with K >= 16 are written as a fill in the store
+ * pattern that reaches the part's write rate (one 256-thread workgroup per CU, grid-stride, 16-byte stores: 6.3-6.5 TB/s
+ * against 4.5-5.9 for every other shape of the same loop) plus a second launch for the values.  Identical results.
  * key 32: PPO forward (hpc_rll_ppo_forward) for rows of up to 512 logits: 1 (default) = ONE launch -- a lane group reads the
  * same row of both policy heads, its last lane applies the per-sample loss, the sums are folded by the last workgroup;
  * 0 = two categorical launches + the sample launch.  Same per-sample coefficients (the backward's inputs), the five sums
@@ -185,6 +185,8 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * LDS-DMA keeps four planes in flight into a five-plane ring while the landed plane is gathered; a batch element's (M, N) block is
  * written once, contiguous): 1 = on (planes of 2048 or 4096 elements, M <= 256), 0 (default) = one workgroup per (batch element,
  * channel group) -- an experiment that lost: 1.25 against 0.865 ms at 4096 x 64 planes of 64 x 64.  Identical results.
+ * key 35: 16-byte quads per workgroup of the one-launch one-hot gradient kernel: 0 (default) = by output size (256 -- one per
+ * thread, a 4 KiB block per workgroup -- from 256 MiB, 1024 below), or 256 ... 8192.  Identical results.
  */
 int hpc_rll_tune_set(int key, int value);
 

@@ -609,8 +609,9 @@ def test_onehot_gradient_as_fill_plus_values_is_bit_identical(op, B, N, K):
     nx = np.abs(f32(rng, B, N, K))
     res = {}
     try:
-        for key in (0, 1):                      # 1 MiB threshold: every shape here takes the fill path
-            U.tune_set(31, key)
+        for key in (0, 1, "q256", "q4096"):     # 31 = 1: a 1 MiB threshold, every shape here takes the fill path; q*: key 35 (quads per workgroup)
+            U.tune_set(31, key if key in (0, 1) else 0)
+            U.tune_set(35, 0 if key in (0, 1) else int(key[1:]))
             xx = G(x, True)
             if op == "c51":
                 loss, _ = DistNStepTD(T, B, N, K)(xx, G(nx), G(a), G(na), G(r), G(done), G(w), 0.97, -5., 5.)
@@ -619,9 +620,11 @@ def test_onehot_gradient_as_fill_plus_values_is_bit_identical(op, B, N, K):
             (loss * 3.0).backward()
             res[key] = xx.grad.clone()
     finally:
-        U.tune_set(31, 256)
+        U.tune_set(31, 3072)
+        U.tune_set(35, 0)
     assert int((res[0] != 0).sum()) > B * K // 2
-    assert torch.equal(res[0], res[1]), (int((res[0] != res[1]).sum()), (res[0] != res[1]).nonzero()[:4].tolist())
+    for k in (1, "q256", "q4096"):
+        assert torch.equal(res[0], res[k]), (k, int((res[0] != res[k]).sum()), (res[0] != res[k]).nonzero()[:4].tolist())
 
 
 def test_losses_are_deterministic():
