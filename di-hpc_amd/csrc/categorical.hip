@@ -741,11 +741,15 @@ __global__ __launch_bounds__(256) void categorical_bwd_long_kernel(const float* 
 }
 
 }  // namespace
-int g_blocks_per_cu = 24;  // tuning knob (hpc_rll_tune_set key 0); in-process sweep at the C3 shape: 24 (fwd 335 us, bwd 724 us; 12: 364 / 736)
+int g_blocks_per_cu = 1024;  // tuning knob (hpc_rll_tune_set key 0): cap of the row kernels' grids, in workgroups per CU.  Rounds 1-3 shipped 24 (resident
+// workgroups looping over ~20 slices of the rows: "12: 364 / 736 us, 24: 335 / 724").  Round 4 (profiles/r04_writebw.txt: a stream of
+// short-lived workgroups that each write one aligned block beats long-lived ones) lifted the cap -- at the C3 shape every workgroup
+// now takes ONE slice of 32 rows and retires: V-trace 0.755 / 0.784 -> 0.72 / 0.68 ms, UPGO 0.366 / 0.736 -> 0.323 / 0.680
+// (24 -> 64 -> 256 -> 1024 workgroups per CU: backward 0.784, 0.714, 0.686, 0.678 ms)
 namespace {  // tuning knob (hpc_rll_tune_set key 0)
 inline unsigned grid_for(long rows, int rows_per_block) {
     long g = (rows + rows_per_block - 1) / rows_per_block;
-    const long cap = 256L * g_blocks_per_cu;  // 256 CUs x resident blocks of 256 threads
+    const long cap = 256L * g_blocks_per_cu;  // 256 CUs x workgroups per CU (above it the workgroups loop)
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (unsigned)g;
@@ -907,7 +911,7 @@ int categorical_backward(const float* logits, const int64_t* action, const float
 
 namespace hpc_rll { extern int g_gemm_bk; extern int g_scatter_threads; extern int g_lstm_persist; extern int g_lstm_xchg_rep; extern int g_lstm_jw; extern int g_gemm_big_target; extern int g_gemm_big_tile128; extern int g_lstm_wave; extern int g_scatter_bwd_lds_kb; extern int g_gemm_xcd; extern int g_lstm_nn_bwd; extern int g_lstm_dh_big; extern int g_gemm_lat_target; extern int g_gemm_thr_ktiles; extern int g_cell_vec4; extern int g_gemm_tile256; extern int g_scatter_lds_fwd; extern int g_scatter_npb; extern int g_scan_wave_target; extern int g_cell_rows_wgs; extern int g_scan_fold; extern int g_split_algo; extern int g_gemm_exp; extern int g_sample_batch; extern int g_gemm_dma; extern int g_lstm_block; extern int g_lstm_block_skew; extern int g_pad_wave; extern int g_lstm_mid; extern int g_lstm_mid_rep; extern int g_onehot_fill_mb; extern int g_ppo_fused; extern int g_lstm_mid_bwd; extern int g_scatter_bwd_stream; extern int g_onehot_qpw; }
 extern "C" int hpc_rll_tune_set(int key, int value) {
-    if (key == 0 && value >= 1 && value <= 64) { hpc_rll::g_blocks_per_cu = value; return HPC_RLL_OK; }
+    if (key == 0 && value >= 1 && value <= 1024) { hpc_rll::g_blocks_per_cu = value; return HPC_RLL_OK; }
     if (key == 1 && (value == 0 || value == 16 || value == 32)) { hpc_rll::g_gemm_bk = value; return HPC_RLL_OK; }
     if (key == 2 && (value == 256 || value == 512 || value == 1024)) { hpc_rll::g_scatter_threads = value; return HPC_RLL_OK; }
     if (key == 3 && (value == 0 || value == 1)) { hpc_rll::g_lstm_persist = value; return HPC_RLL_OK; }

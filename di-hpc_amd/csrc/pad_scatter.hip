@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1018,7 +1019,7 @@ extern "C" int hpc_rll_pad1d_packed_forward(const float* flat, const int64_t* ta
         // (fewer, persistent workgroups -- the shape that makes a pure fill fast, profiles/r04_writebw.txt -- are SLOWER here:
         // 1 / 2 / 4 / 8 workgroups per CU 612 / 466 / 324 / 315 us against 270 for the API call: a tile is a chain of table
         // lookups, source loads, LDS and stores that needs many tiles in flight per CU)
-        if (wb > 8192) wb = 8192;
+        if (wb > (1L << 20)) wb = 1L << 20;   // (every wave ONE tile: the 8192-workgroup cap of the first version, four tiles per wave, was 2.5 % slower)
         hipLaunchKernelGGL(pad1d_packed_wave_kernel, dim3((unsigned)wb), dim3(256), 0, (hipStream_t)stream, flat, table, new_x, mask,
                            (long)n, (unsigned)max_len, 1.0f / (float)max_len, (float)value, value);
         return last_error();

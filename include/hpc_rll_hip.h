@@ -112,8 +112,8 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
 
 /* Tuning knobs for experiments (a measurement / test hook, not a serving API): process-global plain ints, not
  * synchronised -- set them while no other thread is launching work, and never between an LSTM forward and its backward
- * (the workspace layout depends on the split-K knobs).  key 0: resident 256-thread blocks per CU targeted by the categorical row kernels
- * (1..64).  key 1: k-depth of the fp32 GEMM tiles (16, 32, or 0 = chosen by operand layout).  key 2: threads per
+ * (the workspace layout depends on the split-K knobs).  key 0: cap of the categorical row kernels' grids in 256-thread workgroups per CU (1..1024,
+ * default 1024: one slice of rows per short-lived workgroup; 24, the resident-and-looping shape of rounds 1-3, is 4-15 % slower).  key 1: k-depth of the fp32 GEMM tiles (16, 32, or 0 = chosen by operand layout).  key 2: threads per
  * block of the scatter output kernel (256/512/1024).  key 3: persistent small-batch LSTM path on (1) / off (0).
  * key 4: replicas of every exchange word of that path (1..32).  key 5: minimum hidden units per workgroup there.
  * key 6, key 7: split-K target / 128x128 tiles for the weight-gradient GEMMs.  key 8: layer-wavefront LSTM on/off.
