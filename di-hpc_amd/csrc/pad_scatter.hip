@@ -735,6 +735,9 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
     // 64-bit division by the plane size: 1.07 G stores x 40 / 64 lanes x 4 cycles / 1024 SIMDs = 1.1 ms at C5, the time it
     // took).  Now the lane's (channel, cell) position advances incrementally (one division before the loop), and a quad of
     // cells without an owner -- 78 % of them at 256 entities on a 64 x 64 map -- is one LDS read, three ANDs and the store.
+    // (Also tried in round 4, not kept: ONE 4 KiB output block per short-lived 256-thread workgroup with no staging at all --
+    // owner quad from L2, owned cells gathered from x 4 bytes at a time -- the shape that fixed the one-hot gradients: 1.47 ms
+    // cover / 2.37 ms add against 0.90 / 0.89 here; the staged x tile and owner table are what make this kernel.)
     // order 0: every wave streams its own contiguous sixteenth of the span (64 KiB-class pieces).  Round-4 experiments
     // (tests/tools/micro/writebw3.hip: a pure-write stream runs at 6.5 TB/s when the stores a CU has in flight form whole
     // 4 KiB-aligned blocks, 4.5-5.9 otherwise): order 1 = all 16 waves write ONE contiguous 16 KiB per round, order 2 = only
