@@ -64,11 +64,13 @@ def test_graphed_vtrace_three_losses_and_td_lambda():
     assert not fstep.backward and torch.equal(fstep(), td(vv, rr, w, 0.9, 0.8))
 
 
-def test_graphed_lstm_parameters_are_differentiated():
+@pytest.mark.parametrize("S,B,I,H,L", [(6, 16, 24, 32, 2),      # step kernels
+                                       (6, 16, 24, 128, 2),     # persistent mid-batch forward AND backward kernels inside the graph
+                                       (5, 48, 16, 256, 1)])    # mid-batch forward (two streams), step-kernel backward
+def test_graphed_lstm_parameters_are_differentiated(S, B, I, H, L):
     import hpc_rll
     from hpc_rll.torch_utils.network.rnn import LSTM
     torch.manual_seed(0)
-    S, B, I, H, L = 6, 16, 24, 32, 2
     m = LSTM(S, B, I, H, L).to(DEV)
     x = torch.randn(S, B, I, device=DEV, requires_grad=True)
     step = hpc_rll.graphed(m, x, None)
