@@ -247,6 +247,43 @@ def test_fuzz_lstm():
         assert grad_err(ox.grad.numpy(), dx.grad.cpu().numpy()) < tol, (S, B, I, H, L)
 
 
+def test_fuzz_lstm_mid_batch_kernels():
+    """Random shapes in the range of the persistent mid-batch kernels (csrc/lstm_mid.hpp: 5 <= B <= 256, H a multiple of 16
+    from 64; the backward kernel for B <= 32) against the fp64 oracle: ragged batches, one to three layers, H / 16 odd and even
+    (k slices), one or two batch streams.  The path that ran is asserted, so a silent fallback to the step kernels fails."""
+    import hpc_torch_utils_network as NW
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    rng = np.random.default_rng(11)
+    for _ in range(10):
+        S, B, I = int(rng.integers(1, 8)), int(rng.integers(5, 201)), int(rng.integers(2, 41))
+        H, L = int(rng.choice([64, 80, 96, 128, 208, 256, 384, 512])), int(rng.integers(1, 4))
+        torch.manual_seed(S * 1000 + B)
+        m = LSTM(S, B, I, H, L).to(DEV)
+        with torch.no_grad():
+            m.ln_gamma.add_(0.1 * torch.randn_like(m.ln_gamma))
+            m.ln_beta.add_(0.1 * torch.randn_like(m.ln_beta))
+        x, h0, c0 = f32(rng, S, B, I), f32(rng, L, B, H), f32(rng, L, B, H)
+        dx = G(x, True)
+        y, (hn, cn) = m(dx, (G(h0), G(c0)))
+        assert NW.lstm_last_forward_path() == 5, (S, B, I, H, L)
+        (y.sum() + hn.sum() * 0.5 - cn.sum()).backward()
+        assert NW.lstm_last_backward_path() == (5 if B <= 32 else 0), (S, B, I, H, L)
+        G4 = 4 * H
+        off, wx = 0, []
+        for l in range(L):
+            k = (I if l == 0 else H) * G4
+            wx.append(m.wx.detach().cpu().double()[off:off + k].reshape(-1, G4))
+            off += k
+        wh = [m.wh.detach().cpu().double()[l * H * G4:(l + 1) * H * G4].reshape(H, G4) for l in range(L)]
+        ox = D(x, True)
+        oy, oh, oc = R.lstm(ox, D(h0), D(c0), wx, wh, m.bias.detach().cpu().double().reshape(L, G4),
+                            m.ln_gamma.detach().cpu().double(), m.ln_beta.detach().cpu().double())
+        (oy.sum() + oh.sum() * 0.5 - oc.sum()).backward()
+        assert rel_err(oy.detach().numpy(), y.detach().cpu().numpy()) < 2e-5, (S, B, I, H, L)
+        assert rel_err(oc.detach().numpy(), cn.detach().cpu().numpy()) < 2e-5, (S, B, I, H, L)
+        assert grad_err(ox.grad.numpy(), dx.grad.cpu().numpy()) < 3e-5, (S, B, I, H, L)
+
+
 @pytest.mark.parametrize("B,N,K", [(7, 4, 1), (300, 4, 1), (5, 256, 64), (3, 8, 2), (9, 2, 2), (4, 1024, 16), (6, 6, 2)])
 def test_onehot_gradient_row_shapes(B, N, K):
     """The one-hot-shaped gradients (q-TD K = 1, QR-DQN K = tau, IQN tau planes) at the corners of the 16-byte kernel's
