@@ -73,6 +73,21 @@ __device__ __forceinline__ void mid_store2(float* p, float x, float y) {
 __device__ __forceinline__ void mid_store4(float* base, unsigned byte_off, vfloat4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(blk_u32x4, v), blk_rsrc(base), (int)byte_off, 0, 16);
 }
+// One failed poll of the mid-batch kernels: lstm_persist.hpp's bounded wait (abort word, limit, host status) with a shorter nap --
+// there the co-resident waves need the memory queue, here the rest of the workgroup sits at a barrier and a poll round trip is
+// the step's critical path: 64 cycles instead of 512.
+__device__ __forceinline__ void mid_poll_failed(long& spins) {
+    if (__builtin_expect(((++spins) & 1023) == 0, 0)) {
+        if (__hip_atomic_load(&g_persist_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) __builtin_amdgcn_endpgm();
+        if (spins >= g_persist_spin_limit) {
+            __hip_atomic_store(&g_persist_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* hs = g_persist_host_status;
+            if (hs) __hip_atomic_store(hs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_endpgm();
+        }
+    }
+    __builtin_amdgcn_s_sleep(1);
+}
 __device__ __forceinline__ void mid_publish(unsigned* flags, int nrep, unsigned value) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's write-through stores have been acknowledged
     __syncthreads();
@@ -93,7 +108,7 @@ __device__ __forceinline__ void mid_wait(const unsigned* flags, int nwg, unsigne
 #pragma unroll
             for (int i = 0; i < 4; ++i) ok = ok && (l + 64 * i >= nwg || v[i] >= target);
             if (__all(ok)) break;
-            persist_poll_failed(spins);
+            mid_poll_failed(spins);
         }
     }
     __syncthreads();
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(64 * NW, 4) void lstm_mid_fwd_kernel(MidFwd a) {
                 long spins = 0;
                 u64 w;
                 while ((uint32_t)((w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag)
-                    persist_poll_failed(spins);
+                    mid_poll_failed(spins);
                 cmb[tid] = __uint_as_float((uint32_t)w);
             }
             __syncthreads();
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(64 * NW, 4) void lstm_mid_fwd_kernel(MidFwd a) {
             u64 w;
             const u64* src = a.fin_t + (size_t)(wg % a.nrep) * 512 + tid;
             while ((uint32_t)((w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag)
-                persist_poll_failed(spins);
+                mid_poll_failed(spins);
             lnst[tid] = __uint_as_float((uint32_t)w);
         }
         __syncthreads();
@@ -521,7 +536,7 @@ __global__ __launch_bounds__(1024, 4) void lstm_mid_bwd_kernel(MidBwd a) {
                 long spins = 0;
                 u64 w;
                 while ((uint32_t)((w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag)
-                    persist_poll_failed(spins);
+                    mid_poll_failed(spins);
                 cmb[tid] = __uint_as_float((uint32_t)w);
             }
             __syncthreads();
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(1024, 4) void lstm_mid_bwd_kernel(MidBwd a) {
             u64 w;
             const u64* src = a.fin_t + (size_t)(wg % a.nrep) * 1024 + tid;
             while ((uint32_t)((w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag)
-                persist_poll_failed(spins);
+                mid_poll_failed(spins);
             rtot[tid] = __uint_as_float((uint32_t)w);
         }
         __syncthreads();
