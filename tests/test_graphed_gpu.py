@@ -81,6 +81,17 @@ def test_graphed_lstm_parameters_are_differentiated(S, B, I, H, L):
     assert torch.equal(out[0], y.detach())
     for a, b in zip(grads, ref):
         assert torch.equal(a, b)
+    # new data in the captured input, replayed: the persistent kernels' exchange slots are re-read with ordinary loads, and a
+    # graph's kernel nodes must start with clean caches like eager launches do (no value of the first replay may survive)
+    for _ in range(3):
+        with torch.no_grad():
+            x.normal_()
+        out, grads = step()
+        y, (hn, cn) = m(x, None)
+        ref = torch.autograd.grad([y, hn, cn], [x] + list(m.parameters()), [torch.ones_like(y), torch.ones_like(hn), torch.ones_like(cn)])
+        assert torch.equal(out[0], y.detach())
+        for a, b in zip(grads, ref):
+            assert torch.equal(a, b)
 
 
 def test_graphed_ppo_with_device_side_monitors():

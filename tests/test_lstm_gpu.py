@@ -607,6 +607,48 @@ def test_lstm_mid_batch_backward_kernel_against_step_kernels(S, B, I, H, L, p):
             assert err < 2e-5, (k, err, scale, only_y)
 
 
+@pytest.mark.parametrize("S,B,I,H,L", [(8, 64, 16, 1024, 1), (6, 24, 16, 256, 2), (5, 160, 8, 512, 1)])
+def test_lstm_mid_batch_kernels_see_no_stale_exchange_data_across_launches(S, B, I, H, L):
+    """The mid-batch kernels read their exchange slots (h_s, dHW_s) with ORDINARY loads, relying on two things: inside a launch a
+    slot is read only after its writers' write-through stores were acknowledged and flagged, and a NEW launch starts with clean
+    caches.  The other tests re-run a module on the same inputs, where a stale line of the previous launch would hold the right
+    values; here every iteration has new inputs and new weights in the SAME buffers (same workspace block from torch's
+    allocator, same slots), forward and backward, checked against the step kernels each time."""
+    import hpc_torch_utils_network as N
+    from hpc_rll.torch_utils.network.rnn import LSTM
+    torch.manual_seed(3)
+    m = LSTM(S, B, I, H, L).to(DEV)
+    x = torch.empty(S, B, I, device=DEV)
+    h0, c0 = torch.empty(L, B, H, device=DEV), torch.empty(L, B, H, device=DEV)
+    gy = torch.empty(S, B, H, device=DEV)
+    worst = 0.0
+    try:
+        for it in range(12):
+            with torch.no_grad():
+                for t in (x, h0, c0, gy):
+                    t.normal_()
+                m.wh.mul_(0.5).add_(0.05 * torch.randn_like(m.wh))      # new recurrent weights: other h, other dHW every time
+            res = {}
+            for key in (2, 0):                                           # mid-batch kernels first (the launch that could read stale lines)
+                N.tune_set(29, key)
+                N.tune_set(33, 2 if key else 0)
+                for q in m.parameters():
+                    q.grad = None
+                xs = x.clone().requires_grad_(True)
+                y, (hn, cn) = m(xs, (h0, c0))
+                assert N.lstm_last_forward_path() == (5 if key else 0)
+                (y * gy).sum().backward()
+                res[key] = [t.detach().clone() for t in (y, hn, cn, xs.grad, m.wh.grad)]
+            for k, a, b in zip("y hn cn dx dwh".split(), res[0], res[2]):
+                err = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-30)
+                worst = max(worst, err)
+                assert err < (2e-5 if k in ("y", "hn", "cn") else 2e-4), (it, k, err)
+    finally:
+        N.tune_set(29, 2)
+        N.tune_set(33, 1)
+    assert worst > 0.0
+
+
 def test_lstm_row_block_kernel_with_operands_off_a_16_byte_boundary():
     """The large-batch kernels use 16-byte accesses (the C ABI answers HPC_RLL_EALIGN to a pointer off that boundary);
     the extension copies such an operand once instead of failing: x / h0 / c0 / dy that are contiguous views starting
