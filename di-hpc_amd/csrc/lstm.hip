@@ -1230,7 +1230,7 @@ int lstm_forward_impl(const float* x, const float* h0, const float* c0, const fl
         }
         if (block) {
             BlockFwd a{lw.xw, w.whP, bias + (size_t)l * G, ln_gamma + (size_t)l * 2 * G, ln_beta + (size_t)l * 2 * G,
-                       h0 + (size_t)l * BH, c0 + (size_t)l * BH, lw.hw, lw.c, lw.hseq, lw.stats, nullptr, nullptr, S, B, H, 0, 0, 0, nullptr};
+                       h0 + (size_t)l * BH, c0 + (size_t)l * BH, lw.hw, lw.c, lw.hseq, lw.stats, nullptr, nullptr, S, B, H, 0, 0, 0, nullptr, 0};
             const int brc = launch_block_fwd(a, w.blk_part, reinterpret_cast<unsigned*>(w.blk_flags), st);
             if (brc) return brc;
         }

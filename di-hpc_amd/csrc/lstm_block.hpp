@@ -40,20 +40,35 @@ int g_lstm_block_skew = 10;  // hpc_rll_tune_set key 27: microseconds between th
 namespace {
 
 // ---- counter barrier over the workgroups of one row block -----------------------------------------------------------
-__device__ __forceinline__ void block_arrive(unsigned* flag) {
+// nofence (round 4, tune key 26 bit 7; what lstm_mid.hpp measured: an agent-scope release writes back EVERY dirty line of the
+// XCD's L2 -- here the hw / c / h streams of 32 workgroups -- and an acquire invalidates that L2, Wh included): the exchanged data
+// is stored write-through (sc1) and either lives at addresses written once per launch (h_s, dHW_s: read with ordinary loads,
+// nothing stale can be cached) or is read with agent-scope loads (the LayerNorm partials, whose slots are reused); a workgroup's
+// waves wait for their own stores, barrier, one counter increment -- no cache-wide operation on either side.
+__device__ __forceinline__ void block_arrive(unsigned* flag, bool nofence = false) {
+    if (nofence) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's write-through stores are acknowledged
     __syncthreads();   // workgroup-scope release of every thread's stores, then the barrier
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (!nofence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__device__ __forceinline__ void block_wait(unsigned* flag, unsigned target) {
+__device__ __forceinline__ void block_wait(unsigned* flag, unsigned target, bool nofence = false) {
     if (threadIdx.x == 0) {
         long spins = 0;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) persist_poll_failed(spins);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!nofence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+}
+__device__ __forceinline__ void blk_put2(float* p, float x, float y, bool nofence) {
+    if (nofence) __hip_atomic_store(reinterpret_cast<u64*>(p), ((u64)__float_as_uint(y) << 32) | (u64)__float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *reinterpret_cast<vfloat2*>(p) = vfloat2{x, y};
+}
+__device__ __forceinline__ vfloat2 blk_get2(const float* p, bool nofence) {
+    if (!nofence) return *reinterpret_cast<const vfloat2*>(p);
+    const u64 w = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return vfloat2{__uint_as_float((uint32_t)w), __uint_as_float((uint32_t)(w >> 32))};
 }
 
 // x-branch row statistics from the per-row partials the x-branch product's epilogue wrote: rowpart[cb][rows][2] = (mean,
@@ -90,6 +105,7 @@ struct BlockFwd {
     int S, B, H, rb0, nct;
     int skew_ticks;                     // wall-clock ticks (100 MHz) between the starts of consecutive row blocks
     u64* prof;                          // optional (HPC_RLL_LSTM_PROFILE=1): 8 phase accumulators of workgroup gridDim.x / 2
+    int nofence;                        // exchange without cache-wide fences (see block_arrive)
 };
 #define HPC_RLL_BLK_TICK(i)                                   \
     if (prof_on) {                                            \
@@ -147,6 +163,7 @@ __global__ __launch_bounds__(128 * MW, 2) void lstm_block_fwd_kernel(const Block
     unsigned* const flag_p = a.flags + 2 * rbl;
     unsigned* const flag_h = flag_p + 1;
     float* const part = a.part + (size_t)rbl * 2 * 2 * nct * BM * 2;
+    const bool nf = a.nofence != 0;
 
     float gx[4], gh[4], bx[4], bh[4], bb[4];
 #pragma unroll
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(128 * MW, 2) void lstm_block_fwd_kernel(const Block
                     __builtin_nontemporal_store(vfloat4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]},
                                                 reinterpret_cast<vfloat4*>(hw_p + (size_t)R * G + xoff));
                 }
-            block_wait(flag_h, (unsigned)(nct * s));   // h_{s-1} of this row block is complete
+            block_wait(flag_h, (unsigned)(nct * s), nf);   // h_{s-1} of this row block is complete
         }
         HPC_RLL_BLK_TICK(0)   // hw stores issued, wait for h
 
@@ -286,11 +303,11 @@ __global__ __launch_bounds__(128 * MW, 2) void lstm_block_fwd_kernel(const Block
             const int rr = i32 & 15;
             const int row = wm * 64 + (i32 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
             // every wave publishes its own (mean, M2) over 128 columns: 2 nct partials per row
-            *reinterpret_cast<vfloat2*>(pslot + ((size_t)(2 * ct + wn) * BM + row) * 2) = vfloat2{my_m, my_d};
+            blk_put2(pslot + ((size_t)(2 * ct + wn) * BM + row) * 2, my_m, my_d, nf);
         }
-        block_arrive(flag_p);
+        block_arrive(flag_p, nf);
         HPC_RLL_BLK_TICK(2)   // row partials + publish
-        block_wait(flag_p, (unsigned)(nct * (s + 1)));
+        block_wait(flag_p, (unsigned)(nct * (s + 1)), nf);
         HPC_RLL_BLK_TICK(3)   // wait for the row block's partials
         if (tid < BM) {
             // Chan's update, one partial (128 columns) at a time, eight loads in flight: mean and M2 of the whole row
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(128 * MW, 2) void lstm_block_fwd_kernel(const Block
                 vfloat2 p[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    p[k] = *reinterpret_cast<const vfloat2*>(pp + (size_t)(c0 + k < 2 * nct ? c0 + k : 0) * BM * 2);
+                    p[k] = blk_get2(pp + (size_t)(c0 + k < 2 * nct ? c0 + k : 0) * BM * 2, nf);
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (c0 + k < 2 * nct) {
@@ -337,13 +354,15 @@ __global__ __launch_bounds__(128 * MW, 2) void lstm_block_fwd_kernel(const Block
                     const float ig = blk_sigmoid<FAST>(pre[0]), fg = blk_sigmoid<FAST>(pre[1]), og = blk_sigmoid<FAST>(pre[2]);
                     const float ug = blk_tanh<FAST>(pre[3]);
                     const float cn = fg * cp[ci & 1][q] + ig * ug;
-                    (h_s + (size_t)R * H)[uoff] = og * blk_tanh<FAST>(cn);
+                    const float hv = og * blk_tanh<FAST>(cn);
+                    if (nf) __hip_atomic_store((h_s + (size_t)R * H) + uoff, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else (h_s + (size_t)R * H)[uoff] = hv;
                     (c_s + (size_t)R * H)[uoff] = cn;
                 }
             }
         }
         HPC_RLL_BLK_TICK(5)   // gates
-        block_arrive(flag_h);
+        block_arrive(flag_h, nf);
         HPC_RLL_BLK_TICK(6)   // h / c stores drained, release fence, arrival
     }
     {   // the last step's pre-LayerNorm product
@@ -409,6 +428,7 @@ inline int launch_block_fwd_t(BlockFwd a, float* part, unsigned* flags, hipStrea
     a.nct = 4 * a.H / 256;
     a.skew_ticks = g_lstm_block_skew * 100;
     a.prof = persist_prof();
+    a.nofence = (g_lstm_block & 128) ? 1 : 0;
     for (int rb = 0; rb < nrb; rb += per) {
         const int n = nrb - rb < per ? nrb - rb : per;
         a.rb0 = rb;

@@ -153,7 +153,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * (lstm_block.hpp); 0 = one product + one cell launch per step (same layout, same saved tensors).  A bit mask: bit 0 the
  * persistent forward, bit 1 its 128-row variant (two workgroups per CU; measured slower), bit 2 libm instead of hardware
  * exp2 / reciprocal in its gates, bit 3 the persistent BACKWARD (128 rows x 128 hidden units per workgroup, full K, cell
- * adjoint and both LayerNorm adjoints in the product's epilogue; H % 128 == 0), bit 4 its k-depth 16 instead of 32.
+ * adjoint and both LayerNorm adjoints in the product's epilogue; H % 128 == 0), bit 4 its k-depth 16 instead of 32, bit 5 its
+ * k-depth 64, bit 6 its linear workgroup order, bit 7 the forward's exchanges without cache-wide fences (measured: 65.25 -> 65.14 ms
+ * at the default start skew, 68.2 -> 65.5 without one -- the skew already hides what the fences cost).
  * Default 9 = forward + backward.  Forward and backward paths can be mixed freely (same saved tensors).
  * key 27: start skew of that kernel's row blocks in microseconds (0 ... 200, default 0): row block r waits r x this
  * before its first step, which spreads the HBM-bound epilogues of the row blocks over the step.
