@@ -623,7 +623,7 @@ def run_suite(dev):
     t0 = time.perf_counter()
     out = {}
     for name, fn in (("c3", S.suite_c3), ("ppo", S.suite_ppo), ("td", S.suite_td), ("c4", S.suite_c4),
-                     ("c5", lambda: S.suite_c5(quick=True)), ("lstm_mid", S.suite_lstm_mid)):
+                     ("c5", lambda: S.suite_c5(quick=True)), ("lstm_mid", S.suite_lstm_mid), ("small", S.suite_small)):
         S.rows.clear()
         try:
             fn()
