@@ -189,6 +189,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * channel group) -- an experiment that lost: 1.25 against 0.865 ms at 4096 x 64 planes of 64 x 64.  Identical results.
  * key 35: 16-byte quads per workgroup of the one-launch one-hot gradient kernel: 0 (default) = by output size (256 -- one per
  * thread, a 4 KiB block per workgroup -- from 256 MiB, 1024 below), or 256 ... 8192.  Identical results.
+ * key 36: the nap between failed polls of every persistent LSTM kernel, in 64-cycle units: 1 (default) ... 8 (shipped until round
+ * 4; 1.5-5 % slower forward, 1-2.4 % slower backward at small batch, profiles/r04_persist_nap.txt).  The value reaches the device
+ * with the next persistent launch outside stream capture (one blocking 4-byte copy).  Identical results.
  */
 int hpc_rll_tune_set(int key, int value);
 
