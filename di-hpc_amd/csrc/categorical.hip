@@ -932,7 +932,7 @@ extern "C" int hpc_rll_tune_set(int key, int value) {
     if (key == 18 && (value == 0 || (value >= 4 && value <= 64 && value % 4 == 0))) { hpc_rll::g_scatter_npb = value; return HPC_RLL_OK; }
     if (key == 19 && value >= 256 && value <= 16384) { hpc_rll::g_scan_wave_target = value; return HPC_RLL_OK; }
     if (key == 20 && (value == 0 || (value >= 64 && value <= 1024))) { hpc_rll::g_cell_rows_wgs = value; return HPC_RLL_OK; }
-    if (key == 21 && (value == 0 || value == 1)) { hpc_rll::g_scan_fold = value; return HPC_RLL_OK; }
+    if (key == 21 && value >= 0 && value <= 2) { hpc_rll::g_scan_fold = value; return HPC_RLL_OK; }
     if (key == 22 && (value == 0 || value == 1)) { hpc_rll::g_split_algo = value; return HPC_RLL_OK; }
     if (key == 23 && value >= 0 && value <= 3) { hpc_rll::g_gemm_exp = value; return HPC_RLL_OK; }
     if (key == 25 && value >= 0 && value <= 2) { hpc_rll::g_gemm_dma = value; return HPC_RLL_OK; }

@@ -21,8 +21,18 @@ __global__ __launch_bounds__(256) void finalize_sums_kernel(const float* __restr
     __shared__ double red[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int k = 0; k < nacc; ++k) {
+        // thread t adds partials t, t + 256, ... in that order; 16 of them are requested at a time (round 4: one memory round
+        // trip per partial made this launch 10 us behind IQN's 8192 workgroups)
         double s = 0.0;
-        for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partials[(size_t)k * nblocks + i];
+        constexpr int CH = 16;
+        for (int i0 = threadIdx.x; i0 < nblocks; i0 += CH * 256) {
+            float v[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) v[j] = i0 + j * 256 < nblocks ? partials[(size_t)k * nblocks + i0 + j * 256] : 0.f;
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (i0 + j * 256 < nblocks) s += (double)v[j];
+        }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
         if (lane == 0) red[w] = s;

@@ -129,9 +129,11 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * x tile fits 52 KB of LDS, or a multiple of 4 in 4..64).  key 19: waves a column-scan launch (TD-lambda, V-trace,
  * UPGO) aims for when it picks its waves per workgroup (256..16384, default 4096).  key 20: workgroups of the large-batch
  * LSTM backward cell (768 <= H <= 1024) that walks >= 8 batch rows per workgroup and keeps the bias / gamma / beta column sums (64..1024,
- * default 512 = two per CU; 0 = always one row per workgroup + a separate column-reduction pass).  key 21: 1 (default) =
- * every scalar-loss forward (TD-lambda, V-trace, UPGO, PPO, q / dist / IQN / QR-DQN n-step TD) finalises its loss sums in
- * the last workgroup of its last launch; 0 = a separate finalize launch (the same partials, summed in fp64 either way).
+ * default 512 = two per CU; 0 = always one row per workgroup + a separate column-reduction pass).  key 21: every
+ * scalar-loss forward (TD-lambda, V-trace, UPGO, PPO, q / dist / IQN / QR-DQN n-step TD) finalises its loss sums in the last
+ * workgroup of its last launch: 1 (default) = grids up to 512 workgroups, 2 = grids up to 32768 (above 512 through 16 arrival
+ * counters, round 4: measured neutral against the finalize launch at 1024 ... 8192 workgroups, profiles/r04_fold_tree.txt),
+ * 0 = always a separate finalize launch (the same partials, summed in fp64 in the same order either way).
  * key 22: group-split algorithm of hpc_rll_oracle_split_group for key-sorted lists: 0 (default) = DP over the runs of
  * equal keys, 1 = the round-2 element-level paths (cross-check; identical results).
  * key 23: fp32 GEMM experiments on the 256x256 tile, a bit mask (default 0): bit 0 = s_setprio(1) around the MFMA

@@ -438,3 +438,35 @@ def test_scatter_many_entities_and_both_forward_kernels(B, M, N, H, W):
     finally:
         NW.tune_set(17, 1)
         NW.tune_set(18, 0)
+
+
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 70001, 2048 * 1024 + 5])
+@pytest.mark.parametrize("misalign", [0, 1])
+def test_packed_table_rows_through_the_c_abi(n, misalign):
+    """hpc_rll_packed_table writes {base + stride * (exclusive prefix of the lengths), 1, 1, length} per row (round 4: rows staged
+    through LDS, a wave's stores contiguous; 16-byte stores when the table is 16-byte aligned, 8-byte ones otherwise).  Against
+    numpy's cumsum, bit for bit: one chunk, ragged last chunks, more than 1024 chunks (the separate scan launch), zero and large
+    lengths, a table at 8 mod 16."""
+    import cabi as N
+    rng = np.random.default_rng(n)
+    lens = rng.integers(0, 200, size=n).astype(np.int64)
+    if n > 3:
+        lens[n // 2] = 0
+        lens[n // 3] = 1 << 33
+    base, stride = 1 << 40, 4
+    d_lens = torch.from_numpy(lens).to(DEV)
+    buf = torch.full((4 * n + 2,), -7, dtype=torch.int64, device=DEV)
+    table = buf[misalign:misalign + 4 * n]
+    assert table.data_ptr() % 16 == 8 * misalign
+    scratch = torch.empty(int(N.lib.hpc_rll_packed_table_scratch_int64(n)), dtype=torch.int64, device=DEV)
+    rc = N.lib.hpc_rll_packed_table(d_lens.data_ptr(), n, base, stride, table.data_ptr(), scratch.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    got = buf.cpu().numpy()
+    want = np.empty((n, 4), dtype=np.int64)
+    want[:, 0] = base + stride * (np.cumsum(lens) - lens)
+    want[:, 1] = 1
+    want[:, 2] = 1
+    want[:, 3] = lens
+    assert np.array_equal(got[misalign:misalign + 4 * n].reshape(n, 4), want)
+    assert got[:misalign].tolist() == [-7] * misalign and got[misalign + 4 * n:].tolist() == [-7] * (2 - misalign)
