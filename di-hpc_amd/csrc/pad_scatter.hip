@@ -574,15 +574,22 @@ __global__ __launch_bounds__(256) void packed_table_kernel(const int64_t* __rest
 // whatever M is (M ~ 1e4 entities per map).
 __global__ __launch_bounds__(256) void scatter_index_kernel(const int64_t* __restrict__ location,
                                                             int32_t* __restrict__ idx, int M, int H, int W) {
-    __shared__ int32_t s_cell[256];
+    typedef int vint4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) int32_t s_cell[256];
     const int b = blockIdx.x;
     const int HW = H * W;
     const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
     int32_t* head = idx + (size_t)b * (2 * HW + M);
     int32_t* last = head + HW;
     int32_t* next = last + HW;
-    for (int c = threadIdx.x; c < HW; c += 256) { head[c] = -1; last[c] = -1; }
-    for (int m = threadIdx.x; m < M; m += 256) next[m] = -1;
+    // the whole block of this b (head, last, next) starts at -1: 16-byte stores when every block is 16-byte aligned
+    const int words = 2 * HW + M;
+    if ((words & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 15) == 0) {
+        const vint4 m1 = {-1, -1, -1, -1};
+        for (int i = threadIdx.x; i < words / 4; i += 256) reinterpret_cast<vint4*>(head)[i] = m1;
+    } else {
+        for (int i = threadIdx.x; i < words; i += 256) head[i] = -1;
+    }
     __syncthreads();
     for (int m0 = 0; m0 < M; m0 += 256) {
         const int m = m0 + threadIdx.x;
@@ -595,10 +602,20 @@ __global__ __launch_bounds__(256) void scatter_index_kernel(const int64_t* __res
         s_cell[threadIdx.x] = c;
         const int32_t before = c >= 0 ? last[c] : -1;   // largest m of the EARLIER chunks at this cell
         __syncthreads();
+        // the latest EARLIER lane of the chunk at the same cell.  Round 4: every lane of a wave reads the same four cells per step
+        // (a broadcast read) and keeps the last match below its own index -- no data-dependent branch.  The first version walked
+        // backwards from its own lane with a break: up to 255 DEPENDENT LDS round trips per thread, ~10 us per workgroup and most
+        // of this kernel's 94 us at B = 4096, M = 256.
+        int pk = -1;
+        const int kend = (((int)threadIdx.x >> 6) + 1) * 16;     // wave-uniform: quads up to the end of this wave's lanes
+        for (int k4 = 0; k4 < kend; ++k4) {
+            const vint4 v = reinterpret_cast<const vint4*>(s_cell)[k4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (v[j] == c && 4 * k4 + j < (int)threadIdx.x) pk = 4 * k4 + j;
+        }
         if (c >= 0) {
-            int32_t prev = -1;
-            for (int k = (int)threadIdx.x - 1; k >= 0; --k)
-                if (s_cell[k] == c) { prev = m0 + k; break; }
+            int32_t prev = pk >= 0 ? m0 + pk : -1;
             if (prev < 0) prev = before;
             if (prev >= 0) next[prev] = m;   // exactly one writer per slot
             else head[c] = m;                // exactly one writer per cell
