@@ -723,11 +723,17 @@ __global__ __launch_bounds__(1024) void scatter_out4_kernel(const float* __restr
 // scatter_out4_kernel issues).  Per float4 of output: one 16-byte LDS read of the four owners, four 4-byte LDS gathers
 // from the padded x tile (row stride NPB+1: conflict-free for distinct m), `add` walks the chain in ascending m.
 // Needs HW % 4 == 0, 16-byte aligned x/out, HW ints + M*(NPB+1) floats of LDS.
-template <bool ADD>
+// BUILD (round 4, tune key 37): the owner table and the chain links are built HERE, in LDS, from `location` -- no index
+// launch, no index in memory.  cover: the largest m at a cell = an LDS atomic max per entity; add: the head = an LDS atomic
+// min (empty = -1 = the largest unsigned), next[m] = the smallest later entity at the same cell, found with broadcast reads of
+// the cell list (M <= 1024; 1024 / M threads share an entity's walk over the M / 4 quads).  The same table scatter_index_kernel leaves in memory, so the
+// same output bits.  At C5 the index launch took 64 of the forward's 880 us; a workgroup spends ~1 us here.
+template <bool ADD, bool BUILD>
 __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __restrict__ x,
                                                               const int32_t* __restrict__ idx,
                                                               float* __restrict__ out, int M, int N, int HW, int npb,
-                                                              int order) {
+                                                              int order, const int64_t* __restrict__ location, int W) {
+    typedef int vint4 __attribute__((ext_vector_type(4)));
     extern __shared__ float s_dyn[];
     const int b = blockIdx.y;
     const int n0 = blockIdx.x * npb;
@@ -736,27 +742,79 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
     float* xs = s_dyn;                                     // [M][ld]
     int32_t* s_first = reinterpret_cast<int32_t*>(s_dyn + (((size_t)M * ld + 3) & ~(size_t)3));   // [HW] head (add) / last (cover), 16-byte aligned
     int32_t* s_next = s_first + HW;                        // [M]   (add only)
-    const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
-    const int32_t* __restrict__ first_g = ADD ? head : head + HW;
-    const int32_t* __restrict__ next_g = head + 2 * HW;
     const float* __restrict__ xb = x + (size_t)b * M * N + n0;
-    // ---- stage: owner table (16-byte loads), chain links, the x tile (float4 along the channels when aligned)
-    for (int c = threadIdx.x; c < HW; c += 1024) s_first[c] = first_g[c];
-    if (ADD)
-        for (int m = threadIdx.x; m < M; m += 1024) s_next[m] = next_g[m];
-    if ((nn & 3) == 0 && (N & 3) == 0 && (n0 & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-        const int q = nn >> 2;                             // float4 per row
-        for (int e = threadIdx.x; e < M * q; e += 1024) {
-            const int m = e / q, j = e - m * q;
-            const vfloat4 t = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(xb + (size_t)m * N) + j);
-            float* d = xs + m * ld + 4 * j;
-            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    // the x tile (float4 along the channels when aligned)
+    auto stage_x = [&]() {
+        if ((nn & 3) == 0 && (N & 3) == 0 && (n0 & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+            const int q = nn >> 2;                             // float4 per row
+            for (int e = threadIdx.x; e < M * q; e += 1024) {
+                const int m = e / q, j = e - m * q;
+                const vfloat4 t = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(xb + (size_t)m * N) + j);
+                float* d = xs + m * ld + 4 * j;
+                d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+            }
+        } else {
+            for (int e = threadIdx.x; e < M * nn; e += 1024) {
+                const int m = e / nn, j = e - m * nn;
+                xs[m * ld + j] = xb[(size_t)m * N + j];
+            }
+        }
+    };
+    if (BUILD) {
+        int32_t* s_cell = s_next + ((M + 3) & ~3);         // [M rounded to 4]   (add only)
+        const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
+        const int H = HW / W;
+        const int m4 = (M + 3) & ~3;
+        // the first entity of every thread is requested before the x tile: one memory round trip for both
+        long y0 = -1, x0 = -1;
+        if ((int)threadIdx.x < M) { y0 = loc[2 * threadIdx.x]; x0 = loc[2 * threadIdx.x + 1]; }
+        const vint4 m1 = {-1, -1, -1, -1};
+        for (int c4 = threadIdx.x; c4 < (HW >> 2); c4 += 1024) reinterpret_cast<vint4*>(s_first)[c4] = m1;
+        if (ADD)
+            for (int m = threadIdx.x; m < M; m += 1024) s_next[m] = -1;
+        stage_x();
+        __syncthreads();
+        for (int m = threadIdx.x; m < m4; m += 1024) {
+            int32_t c = -2;                                // the padding of the cell list matches nothing
+            if (m < M) {
+                const long y = m == (int)threadIdx.x ? y0 : loc[2 * m], xx = m == (int)threadIdx.x ? x0 : loc[2 * m + 1];
+                c = (y >= 0 && y < H && xx >= 0 && xx < W) ? (int32_t)(y * W + xx) : -1;   // out of range: dropped, as in scatter_index_kernel
+                if (c >= 0) {
+                    if (ADD) atomicMin(reinterpret_cast<unsigned*>(s_first) + c, (unsigned)m);
+                    else atomicMax(s_first + c, m);
+                }
+            }
+            if (ADD) s_cell[m] = c;
+        }
+        if (ADD) {
+            __syncthreads();
+            // M <= 1024: the 1024 threads are P = 1024 / mr groups of mr (M rounded to whole waves) -- thread (p, m) walks the p-th
+            // part of the cell list for entity m and files the smallest later entity it finds with an LDS atomic min (-1 = none
+            // = the largest unsigned)
+            const int mr = (M + 63) & ~63, P = 1024 / mr;
+            const int p = threadIdx.x / mr, m = threadIdx.x - p * mr;
+            if (p < P) {
+                const int quads = m4 >> 2, q0 = (int)((long)quads * p / P), q1 = (int)((long)quads * (p + 1) / P);
+                const int32_t c = m < M ? s_cell[m] : -1;
+                int nk = -1;
+                for (int q = q1 - 1; q >= q0; --q) {       // descending: the last hit kept is the smallest later entity
+                    const vint4 v = reinterpret_cast<const vint4*>(s_cell)[q];
+#pragma unroll
+                    for (int j = 3; j >= 0; --j)
+                        if (v[j] == c && 4 * q + j > m) nk = 4 * q + j;
+                }
+                if (c >= 0 && nk >= 0) atomicMin(reinterpret_cast<unsigned*>(s_next) + m, (unsigned)nk);
+            }
         }
     } else {
-        for (int e = threadIdx.x; e < M * nn; e += 1024) {
-            const int m = e / nn, j = e - m * nn;
-            xs[m * ld + j] = xb[(size_t)m * N + j];
-        }
+        const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
+        const int32_t* __restrict__ first_g = ADD ? head : head + HW;
+        const int32_t* __restrict__ next_g = head + 2 * HW;
+        // ---- stage: owner table, chain links
+        for (int c = threadIdx.x; c < HW; c += 1024) s_first[c] = first_g[c];
+        if (ADD)
+            for (int m = threadIdx.x; m < M; m += 1024) s_next[m] = next_g[m];
+        stage_x();
     }
     __syncthreads();
     // ---- stream the span: wave w writes float4 units [w*per, (w+1)*per) of the nn*HW/4 units of this workgroup
@@ -986,7 +1044,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __
 }  // namespace hpc_rll
 
 namespace hpc_rll { int g_pad_wave = 1; }   // hpc_rll_tune_set key 28: packed Pad1D on wave tiles in output space (0 = the round-3 workgroup kernel)
-namespace hpc_rll { int g_scatter_threads = 1024; int g_scatter_bwd_lds_kb = 64; int g_scatter_lds_fwd = 1; int g_scatter_npb = 0; }
+namespace hpc_rll { int g_scatter_threads = 1024; int g_scatter_bwd_lds_kb = 64; int g_scatter_lds_fwd = 1; int g_scatter_npb = 0; int g_scatter_build = 1; }
 namespace hpc_rll { int g_scatter_bwd_stream = 0; }   // hpc_rll_tune_set key 34: persistent pipelined scatter backward (experiment: slower, see the kernel)
 using namespace hpc_rll;
 
@@ -1309,9 +1367,14 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     if (!out || !ws || (M > 0 && (!x || !location))) return HPC_RLL_EINVAL;
     if (HW >= (1L << 31) || B > 65535) return HPC_RLL_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(scatter_index_kernel, dim3(B), dim3(256), 0, st, location, ws, M, H, W);
-    int rc = last_error();
-    if (rc) return rc;
+    int rc = HPC_RLL_OK;
+    bool indexed = false;
+    auto build_index = [&]() {   // the paths that read the index from memory
+        if (indexed) return;
+        hipLaunchKernelGGL(scatter_index_kernel, dim3(B), dim3(256), 0, st, location, ws, M, H, W);
+        rc = last_error();
+        indexed = true;
+    };
     const bool v4 = (HW % 4) == 0 && (N % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     // LDS-staged streaming kernel: the owner table (HW ints) and an M x NPB tile of x must fit in LDS with room for
@@ -1320,6 +1383,8 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     // 4.99 TB/s), reference test shape (16x16 maps) cover 51 -> 46 us, add 68 -> 53 us; `add` on large maps is a tie at
     // 64 channels per workgroup (0.893 ms, 5.13 TB/s) and a loss at 32, so it keeps the cells-per-thread kernel there.
     if (g_scatter_lds_fwd == 2 && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0) {   // wave tiles (experiment)
+        build_index();
+        if (rc) return rc;
         const int tpp = (int)((HW + 1023) / 1024), groups = (N + 15) / 16;
         const long nwaves = (long)B * tpp * groups;
         const unsigned blocks = (unsigned)((nwaves + 3) / 4);
@@ -1327,31 +1392,47 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
         else hipLaunchKernelGGL(scatter_out_wave_kernel<false>, dim3(blocks), dim3(256), 0, st, x, ws, out, M, N, (int)HW, tpp, groups, nwaves);
         return last_error();
     }
-    const bool lds_pays = !add || HW * 4 <= 8 * 1024 || g_scatter_npb != 0;
+    // in-kernel index build (round 4, key 37): cover for every M (an LDS atomic per entity); add where the LDS kernel is taken
+    // anyway (maps up to 8 KB) and the quadratic chain search is small against the workgroup's output
+    // (add: measured -13 % at 32 x 32 maps with 128 entities, +15 % at the reference's 16 x 16 test shape with 256, where four
+    // workgroups per batch element each repeat a build that outweighs their 64 KB of output)
+    const bool build = g_scatter_build && W > 0 && (!add || (M <= 1024 && (g_scatter_build >= 2 || (M <= 256 && HW >= 1024))));
+    // (`add` on large maps: the LDS kernel + build at 32 / 64 channels per workgroup = key 37 = 2 / 3, measured against the
+    // cells-per-thread kernel behind the index launch -- see DESIGN.md 4.5)
+    const bool lds_pays = !add || HW * 4 <= 8 * 1024 || g_scatter_npb != 0 || (build && g_scatter_build >= 2);
     if (g_scatter_lds_fwd && lds_pays && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0 && B <= 65535 &&
         (size_t)HW * 4 <= 32 * 1024) {
-        const size_t fixed = (size_t)HW * 4 + (add ? (size_t)M * 4 : 0);
+        const size_t fixed = (size_t)HW * 4 + (add ? (size_t)M * 4 : 0) + (add && build ? (size_t)((M + 3) & ~3) * 4 + 16 : 0);
+        const bool big = g_scatter_npb != 0 || (add && build && g_scatter_build == 3 && HW * 4 > 8 * 1024);
+        const size_t cap = (size_t)(big ? 100 : 52) * 1024;
         int npb = 0;
         static const int kNpb[5] = {64, 32, 16, 8, 4};
         for (int i = 0; i < 5 && !npb; ++i) {
             const int c = g_scatter_npb ? g_scatter_npb : kNpb[i];
-            if (c <= 64 && c >= 1 && (size_t)M * (c + 1) * 4 + 16 + fixed <= (g_scatter_npb ? 100 : 52) * 1024) npb = c;
+            if (c <= 64 && c >= 1 && (size_t)M * (c + 1) * 4 + 16 + fixed <= cap) npb = c;
             if (g_scatter_npb) break;
         }
         if (npb > N) npb = (N + 3) / 4 * 4;
-        if (npb >= 1 && (size_t)M * (npb + 1) * 4 + 16 + fixed <= (g_scatter_npb ? 100 : 52) * 1024) {
+        if (npb >= 1 && (size_t)M * (npb + 1) * 4 + 16 + fixed <= cap) {
             const size_t lds = (((size_t)M * (npb + 1) + 3) & ~(size_t)3) * 4 + fixed;
-            if (lds > 64 * 1024) {
-                const void* k = add ? (const void*)scatter_out_lds_kernel<true> : (const void*)scatter_out_lds_kernel<false>;
-                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return last_error();
+            const void* k = add ? (build ? (const void*)scatter_out_lds_kernel<true, true> : (const void*)scatter_out_lds_kernel<true, false>)
+                                : (build ? (const void*)scatter_out_lds_kernel<false, true> : (const void*)scatter_out_lds_kernel<false, false>);
+            if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return last_error();
+            if (!build) {
+                build_index();
+                if (rc) return rc;
             }
             const dim3 grid((N + npb - 1) / npb, B);
             const int order = g_scatter_lds_fwd >= 3 ? g_scatter_lds_fwd - 2 : 0;
-            if (add) hipLaunchKernelGGL(scatter_out_lds_kernel<true>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order);
-            else hipLaunchKernelGGL(scatter_out_lds_kernel<false>, grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order);
+            if (add && build) hipLaunchKernelGGL((scatter_out_lds_kernel<true, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order, location, W);
+            else if (add) hipLaunchKernelGGL((scatter_out_lds_kernel<true, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order, location, W);
+            else if (build) hipLaunchKernelGGL((scatter_out_lds_kernel<false, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order, location, W);
+            else hipLaunchKernelGGL((scatter_out_lds_kernel<false, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order, location, W);
             return last_error();
         }
     }
+    build_index();
+    if (rc) return rc;
     const int tpb = (v4 && HW >= 4096) ? g_scatter_threads : 256;   // threads per block of the 4-wide kernel
     const int cell_blocks = (int)((HW + (v4 ? 4 * tpb - 1 : 255)) / (v4 ? 4 * tpb : 256));
     // enough workgroups to cover the chip: split the channel axis when B * cell_blocks is small

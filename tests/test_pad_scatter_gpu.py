@@ -470,3 +470,43 @@ def test_packed_table_rows_through_the_c_abi(n, misalign):
     want[:, 3] = lens
     assert np.array_equal(got[misalign:misalign + 4 * n].reshape(n, 4), want)
     assert got[:misalign].tolist() == [-7] * misalign and got[misalign + 4 * n:].tolist() == [-7] * (2 - misalign)
+
+
+@pytest.mark.parametrize("B,M,N,H,W", [(3, 256, 64, 64, 64), (2, 500, 12, 32, 32), (2, 512, 8, 16, 16), (2, 513, 8, 16, 16),
+                                       (1, 3000, 8, 32, 32), (4, 1, 4, 8, 8), (3, 37, 17, 16, 12), (2, 255, 70, 4, 4), (2, 1024, 8, 32, 32),
+                                       (2, 1025, 8, 32, 32), (3, 700, 5, 16, 16)])
+def test_scatter_in_kernel_index_build(B, M, N, H, W):
+    """Round 4 (tune key 37): the LDS-staged forward kernel builds the owner table (cover: LDS atomic max; add: LDS atomic min for the
+    head + a broadcast search for the next entity of the chain, M <= 512) itself instead of reading the index launch's tables.
+    Against the CPU oracle and against key 37 = 0, bit for bit: heavy collisions (4 x 4 maps), M = 1, M % 4 != 0, the add
+    fallback above 512 entities, cover with several entities per thread, and -- on / off only, the oracle has no such case --
+    out-of-range locations (dropped)."""
+    import hpc_torch_utils_network as NW
+    from oracle import ref_torch as R
+    rng = np.random.default_rng(M * 7 + N)
+    x = rng.standard_normal((B, M, N)).astype(np.float32)
+    loc = np.stack([rng.integers(0, H, (B, M)), rng.integers(0, W, (B, M))], -1).astype(np.int64)
+    bad = loc.copy()
+    bad[:, ::5, 0] = -1
+    bad[:, 1::7, 1] = W
+    bad[:, 2::11, 0] = H + 3
+    dx = torch.from_numpy(x).to(DEV)
+    try:
+        for typ in ("cover", "add"):
+            ref = R.scatter_connection(torch.from_numpy(x), torch.from_numpy(loc), H, W, typ).numpy()
+            for l, want in ((loc, ref), (bad, None)):
+                dloc = torch.from_numpy(l).to(DEV)
+                outs = []
+                for key in (0, 1, 2, 3):      # 2 / 3: `add` builds in the kernel wherever it can (M <= 1024), 32 / 64 channels per workgroup
+                    NW.tune_set(37, key)
+                    out = torch.full((B, N, H, W), float("nan"), device=DEV)
+                    NW.ScatterConnectionForward([dx, dloc], [out], typ)
+                    outs.append(out.cpu().numpy())
+                for o in outs[1:]:
+                    assert np.array_equal(outs[0], o), typ
+                if want is not None:
+                    assert np.array_equal(outs[1], want), typ
+                else:
+                    assert not np.isnan(outs[1]).any()
+    finally:
+        NW.tune_set(37, 1)

@@ -28,12 +28,15 @@ def timed(fn, n=10, rounds=5):
 
 
 g = torch.Generator(device=dev).manual_seed(0)
-for B, M, N, H, W in ((4096, 256, 64, 64, 64), (1024, 1024, 64, 64, 64), (256, 4096, 32, 64, 64)):
+for B, M, N, H, W in ((4096, 256, 64, 64, 64), (4096, 128, 64, 32, 32), (256, 256, 256, 16, 16), (1024, 1024, 64, 64, 64), (256, 4096, 32, 64, 64)):
     x = torch.randn(B, M, N, device=dev, generator=g)
     loc = torch.stack([torch.randint(0, H, (B, M), device=dev, generator=g), torch.randint(0, W, (B, M), device=dev, generator=g)], -1)
     for kind in ("cover", "add"):
         m = ScatterConnection(B, M, N, H, W, kind)
-        with torch.no_grad():
-            t = timed(lambda: m(x, loc))
         by = 4 * x.numel() + 4 * B * N * H * W
-        print(f"B={B} M={M} N={N} {kind:5s}: forward {t:8.1f} us  {by / t / 1e3:6.0f} GB/s", flush=True)
+        import hpc_torch_utils_network as NW
+        for key in ((0, 1, 0, 1) if kind == 'cover' else (0, 1, 0, 1)):
+            NW.tune_set(37, key)
+            with torch.no_grad():
+                t = timed(lambda: m(x, loc))
+            print(f"B={B} M={M} N={N} {kind:5s} in-kernel index (key 37) = {key}: forward {t:8.1f} us  {by / t / 1e3:6.0f} GB/s", flush=True)
