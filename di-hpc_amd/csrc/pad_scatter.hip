@@ -573,23 +573,33 @@ __global__ __launch_bounds__(256) void packed_table_kernel(const int64_t* __rest
 // (integer atomicMax: deterministic).  O(M * 256) instead of the first version's O(M^2) pair scan, 1 KB of LDS
 // whatever M is (M ~ 1e4 entities per map).
 __global__ __launch_bounds__(256) void scatter_index_kernel(const int64_t* __restrict__ location,
-                                                            int32_t* __restrict__ idx, int M, int H, int W) {
+                                                            int32_t* __restrict__ idx, int M, int H, int W, int parts) {
+    // parts (round 4): bit 0 = head + next are wanted (add), bit 1 = last is wanted (cover, or add with more than one chunk, which
+    // links its chains across chunks through last).  The tables that are not wanted are neither initialised nor written: add at
+    // M <= 256 leaves out half of the block's bytes and every atomic.
     typedef int vint4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) int32_t s_cell[256];
     const int b = blockIdx.x;
     const int HW = H * W;
+    const bool want_chain = parts & 1, want_last = parts & 2;
     const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
     int32_t* head = idx + (size_t)b * (2 * HW + M);
     int32_t* last = head + HW;
     int32_t* next = last + HW;
-    // the whole block of this b (head, last, next) starts at -1: 16-byte stores when every block is 16-byte aligned
+    // the tables of this b start at -1: 16-byte stores when every block is 16-byte aligned
     const int words = 2 * HW + M;
-    if ((words & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 15) == 0) {
-        const vint4 m1 = {-1, -1, -1, -1};
-        for (int i = threadIdx.x; i < words / 4; i += 256) reinterpret_cast<vint4*>(head)[i] = m1;
-    } else {
-        for (int i = threadIdx.x; i < words; i += 256) head[i] = -1;
-    }
+    const bool al = (words & 3) == 0 && (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 15) == 0;
+    auto fill = [&](int32_t* p, int n) {
+        if (al && (n & 3) == 0) {
+            const vint4 m1 = {-1, -1, -1, -1};
+            for (int i = threadIdx.x; i < n / 4; i += 256) reinterpret_cast<vint4*>(p)[i] = m1;
+        } else {
+            for (int i = threadIdx.x; i < n; i += 256) p[i] = -1;
+        }
+    };
+    if (want_chain && want_last) fill(head, words);
+    else if (want_chain) { fill(head, HW); fill(next, M); }
+    else fill(last, HW);
     __syncthreads();
     for (int m0 = 0; m0 < M; m0 += 256) {
         const int m = m0 + threadIdx.x;
@@ -599,8 +609,12 @@ __global__ __launch_bounds__(256) void scatter_index_kernel(const int64_t* __res
             // out-of-range locations are dropped (the reference would write out of bounds)
             if (y >= 0 && y < H && x >= 0 && x < W) c = (int32_t)(y * W + x);
         }
+        if (!want_chain) {                                   // cover: the largest m of a cell, nothing else
+            if (c >= 0) atomicMax(&last[c], m);
+            continue;
+        }
         s_cell[threadIdx.x] = c;
-        const int32_t before = c >= 0 ? last[c] : -1;   // largest m of the EARLIER chunks at this cell
+        const int32_t before = (c >= 0 && want_last) ? last[c] : -1;   // largest m of the EARLIER chunks at this cell
         __syncthreads();
         // the latest EARLIER lane of the chunk at the same cell.  Round 4: every lane of a wave reads the same four cells per step
         // (a broadcast read) and keeps the last match below its own index -- no data-dependent branch.  The first version walked
@@ -619,7 +633,7 @@ __global__ __launch_bounds__(256) void scatter_index_kernel(const int64_t* __res
             if (prev < 0) prev = before;
             if (prev >= 0) next[prev] = m;   // exactly one writer per slot
             else head[c] = m;                // exactly one writer per cell
-            atomicMax(&last[c], m);
+            if (want_last) atomicMax(&last[c], m);
         }
         __syncthreads();   // the next chunk reads last[] (global memory written by this workgroup: barrier + L1 write-through)
     }
@@ -1371,7 +1385,8 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     bool indexed = false;
     auto build_index = [&]() {   // the paths that read the index from memory
         if (indexed) return;
-        hipLaunchKernelGGL(scatter_index_kernel, dim3(B), dim3(256), 0, st, location, ws, M, H, W);
+        const int parts = add ? (M > 256 ? 3 : 1) : 2;
+        hipLaunchKernelGGL(scatter_index_kernel, dim3(B), dim3(256), 0, st, location, ws, M, H, W, parts);
         rc = last_error();
         indexed = true;
     };
