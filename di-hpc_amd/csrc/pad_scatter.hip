@@ -677,24 +677,77 @@ __global__ __launch_bounds__(256) void scatter_out_kernel(const float* __restric
 
 // 4 consecutive cells x 4 channels per thread step: four float4 gathers, a 4x4 register transpose, four float4
 // nontemporal stores (1 KiB per wave-store instead of 256 B).  Needs HW % 4 == 0, N % 4 == 0, 16-byte aligned x/out.
-template <bool ADD>
+// BUILD (round 4, tune key 37): the owners of the workgroup's 4 * blockDim.x cells and (add, M <= blockDim.x) the chain links are
+// built in LDS from `location`, as in scatter_out_lds_kernel below -- no index launch, no index in memory.
+template <bool ADD, bool BUILD>
 __global__ __launch_bounds__(1024) void scatter_out4_kernel(const float* __restrict__ x,
                                                            const int32_t* __restrict__ idx,
                                                            float* __restrict__ out, int M, int N, int HW,
-                                                           int n_per_block) {
+                                                           int n_per_block, const int64_t* __restrict__ location, int W) {
+    typedef int vint4 __attribute__((ext_vector_type(4)));
+    extern __shared__ int32_t s_tab[];                              // BUILD: [4 * blockDim.x] first | [M4] next | [M4] cell
     const int b = blockIdx.z;
     const int cell = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // blockDim.x = 256 or 1024 (16 KiB runs per plane)
-    if (cell >= HW) return;
     const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
     const int32_t* __restrict__ last = head + HW;
-    const int32_t* __restrict__ next = last + HW;
+    const int32_t* __restrict__ next = BUILD ? nullptr : last + HW;
+    int32_t* const s_next = s_tab + 4 * blockDim.x;
+    int32_t first[4] = {-1, -1, -1, -1};
+    if (BUILD) {
+        const int NT = blockDim.x, m4 = (M + 3) & ~3, cell0 = blockIdx.x * NT * 4, H = HW / W;
+        int32_t* const s_cell = s_next + m4;
+        const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
+        long y0 = -1, x0 = -1;
+        if ((int)threadIdx.x < M) { y0 = loc[2 * threadIdx.x]; x0 = loc[2 * threadIdx.x + 1]; }
+        const vint4 m1 = {-1, -1, -1, -1};
+        reinterpret_cast<vint4*>(s_tab)[threadIdx.x] = m1;
+        if (ADD)
+            for (int m = threadIdx.x; m < M; m += NT) s_next[m] = -1;
+        __syncthreads();
+        for (int m = threadIdx.x; m < m4; m += NT) {
+            int32_t c = -2;                                // the padding of the cell list matches nothing
+            if (m < M) {
+                const long y = m == (int)threadIdx.x ? y0 : loc[2 * m], xx = m == (int)threadIdx.x ? x0 : loc[2 * m + 1];
+                c = (y >= 0 && y < H && xx >= 0 && xx < W) ? (int32_t)(y * W + xx) : -1;
+                const int rel = c - cell0;
+                if (c >= 0 && rel >= 0 && rel < 4 * NT) {
+                    if (ADD) atomicMin(reinterpret_cast<unsigned*>(s_tab) + rel, (unsigned)m);
+                    else atomicMax(s_tab + rel, m);
+                }
+            }
+            if (ADD) s_cell[m] = c;
+        }
+        if (ADD) {
+            __syncthreads();
+            const int mr = (M + 63) & ~63, P = NT / mr;     // M <= blockDim.x
+            const int p = threadIdx.x / mr, m = threadIdx.x - p * mr;
+            if (p < P) {
+                const int quads = m4 >> 2, q0 = (int)((long)quads * p / P), q1 = (int)((long)quads * (p + 1) / P);
+                const int32_t c = m < M ? s_cell[m] : -1;
+                int nk = -1;
+                for (int q = q1 - 1; q >= q0; --q) {
+                    const vint4 v = reinterpret_cast<const vint4*>(s_cell)[q];
+#pragma unroll
+                    for (int j = 3; j >= 0; --j)
+                        if (v[j] == c && 4 * q + j > m) nk = 4 * q + j;
+                }
+                if (c >= 0 && nk >= 0) atomicMin(reinterpret_cast<unsigned*>(s_next) + m, (unsigned)nk);
+            }
+        }
+        __syncthreads();
+        if (cell >= HW) return;
+        const vint4 f = reinterpret_cast<const vint4*>(s_tab)[threadIdx.x];
+        first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
+    } else {
+        if (cell >= HW) return;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) first[c] = ADD ? head[cell + c] : last[cell + c];
+    }
     const float* __restrict__ xb = x + (size_t)b * M * N;
     float* __restrict__ ob = out + (size_t)b * N * HW + cell;
     const int n0 = blockIdx.y * n_per_block;
     const int n1 = min(N, n0 + n_per_block);
-    int32_t first[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) first[c] = ADD ? head[cell + c] : last[cell + c];
+    auto nxt = [&](int32_t m) -> int32_t { return BUILD ? s_next[m] : next[m]; };
     // 16 channels per iteration: all 16 gathers of an iteration are independent and issued together (a dependent
     // gather costs ~2 us under streaming load; serialising them made the first version latency bound)
     constexpr int U = 4;
@@ -712,7 +765,7 @@ __global__ __launch_bounds__(1024) void scatter_out4_kernel(const float* __restr
         if (ADD) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                for (int32_t m = first[c] >= 0 ? next[first[c]] : -1; m >= 0; m = next[m])
+                for (int32_t m = first[c] >= 0 ? nxt(first[c]) : -1; m >= 0; m = nxt(m))
 #pragma unroll
                     for (int u = 0; u < U; ++u)
                         if (n + 4 * u < n1) acc[u][c] += *reinterpret_cast<const vfloat4*>(xb + (size_t)m * N + n + 4 * u);
@@ -1446,8 +1499,6 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
             return last_error();
         }
     }
-    build_index();
-    if (rc) return rc;
     const int tpb = (v4 && HW >= 4096) ? g_scatter_threads : 256;   // threads per block of the 4-wide kernel
     const int cell_blocks = (int)((HW + (v4 ? 4 * tpb - 1 : 255)) / (v4 ? 4 * tpb : 256));
     // enough workgroups to cover the chip: split the channel axis when B * cell_blocks is small
@@ -1455,10 +1506,23 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     while (n_per_block > 4 && (long)B * cell_blocks * ((N + n_per_block - 1) / n_per_block) < 2048) n_per_block = (n_per_block / 2 + 3) / 4 * 4;
     const dim3 grid(cell_blocks, (N + n_per_block - 1) / n_per_block, B);
     if (v4) {
-        if (add) hipLaunchKernelGGL(scatter_out4_kernel<true>, grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
-        else hipLaunchKernelGGL(scatter_out4_kernel<false>, grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
+        // in-kernel tables here only on request (key 37 >= 2): at C5 `add` 859 -> 875 us -- this kernel has no staging phase the
+        // build's round trip and barriers could hide behind, eight rounds of workgroups pay ~5 us each, more than the index launch
+        const bool b4 = g_scatter_build >= 2 && W > 0 && M > 0 && (!add || (M <= 256 && M <= tpb));
+        if (b4) {
+            const size_t lds = ((size_t)4 * tpb + (add ? 2 * (size_t)((M + 3) & ~3) : 0)) * 4;
+            if (add) hipLaunchKernelGGL((scatter_out4_kernel<true, true>), grid, dim3(tpb), lds, st, x, ws, out, M, N, (int)HW, n_per_block, location, W);
+            else hipLaunchKernelGGL((scatter_out4_kernel<false, true>), grid, dim3(tpb), lds, st, x, ws, out, M, N, (int)HW, n_per_block, location, W);
+            return last_error();
+        }
+        build_index();
+        if (rc) return rc;
+        if (add) hipLaunchKernelGGL((scatter_out4_kernel<true, false>), grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block, location, W);
+        else hipLaunchKernelGGL((scatter_out4_kernel<false, false>), grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block, location, W);
         return last_error();
     }
+    build_index();
+    if (rc) return rc;
     const bool vec = (N % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     if (add) hipLaunchKernelGGL(scatter_out_kernel<true>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block, vec);
     else hipLaunchKernelGGL(scatter_out_kernel<false>, grid, dim3(256), 0, st, x, ws, out, M, N, (int)HW, n_per_block, vec);

@@ -196,8 +196,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * with the next persistent launch outside stream capture (one blocking 4-byte copy).  Identical results.
  * key 37: scatter-connection forward builds its owner table / chain links in LDS inside the LDS-staged output kernel: 1 (default)
  * = cover for every M, add for M <= 256 on maps of 1024 ... 2048 cells (no index launch, no index in memory: cover at C5 874 ->
- * 812 us); 2 / 3 = add wherever M <= 1024, on large maps through the LDS kernel at 32 / 64 channels per workgroup (measured
- * slower there); 0 = the index launch of rounds 1-3 for every path.  Identical results.
+ * 812 us); 2 / 3 = add wherever M <= 1024, on large maps through the LDS kernel at 32 / 64 channels per workgroup, and in the
+ * cells-per-thread kernels (all measured slower: C5 add 859 -> 922 / 901 / 875 us); 0 = the index launch of rounds 1-3 for every
+ * path.  Identical results.
  */
 int hpc_rll_tune_set(int key, int value);
 

@@ -474,7 +474,7 @@ def test_packed_table_rows_through_the_c_abi(n, misalign):
 
 @pytest.mark.parametrize("B,M,N,H,W", [(3, 256, 64, 64, 64), (2, 500, 12, 32, 32), (2, 512, 8, 16, 16), (2, 513, 8, 16, 16),
                                        (1, 3000, 8, 32, 32), (4, 1, 4, 8, 8), (3, 37, 17, 16, 12), (2, 255, 70, 4, 4), (2, 1024, 8, 32, 32),
-                                       (2, 1025, 8, 32, 32), (3, 700, 5, 16, 16)])
+                                       (2, 1025, 8, 32, 32), (3, 700, 5, 16, 16), (2, 200, 64, 128, 128), (2, 300, 8, 100, 100)])
 def test_scatter_in_kernel_index_build(B, M, N, H, W):
     """Round 4 (tune key 37): the LDS-staged forward kernel builds the owner table (cover: LDS atomic max; add: LDS atomic min for the
     head + a broadcast search for the next entity of the chain, M <= 512) itself instead of reading the index launch's tables.
@@ -497,8 +497,11 @@ def test_scatter_in_kernel_index_build(B, M, N, H, W):
             for l, want in ((loc, ref), (bad, None)):
                 dloc = torch.from_numpy(l).to(DEV)
                 outs = []
-                for key in (0, 1, 2, 3):      # 2 / 3: `add` builds in the kernel wherever it can (M <= 1024), 32 / 64 channels per workgroup
+                # 2 / 3: `add` builds in the kernel wherever it can (M <= 1024), 32 / 64 channels per workgroup;
+                # key 17 = 0 with key 37 = 2: the cells-per-thread kernels build their tables the same way (off by default: slower)
+                for key, lds in ((0, 1), (1, 1), (2, 1), (3, 1), (1, 0), (2, 0), (0, 0)):
                     NW.tune_set(37, key)
+                    NW.tune_set(17, lds)
                     out = torch.full((B, N, H, W), float("nan"), device=DEV)
                     NW.ScatterConnectionForward([dx, dloc], [out], typ)
                     outs.append(out.cpu().numpy())
@@ -510,3 +513,4 @@ def test_scatter_in_kernel_index_build(B, M, N, H, W):
                     assert not np.isnan(outs[1]).any()
     finally:
         NW.tune_set(37, 1)
+        NW.tune_set(17, 1)
