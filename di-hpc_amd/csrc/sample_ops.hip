@@ -14,6 +14,7 @@
 
 #include "colscan.hpp"
 #include "hpc_rll_hip.h"
+#include "nstep.hpp"
 #include "ppo_op.hpp"
 #include "stream_write.hpp"
 
@@ -77,14 +78,18 @@ struct QNStepOp {
     float *td_err, *grad_buf;
     int nstep, B, N; float gamma, gamma_n, scale; int rescale;
     __device__ void operator()(long b, float (&acc)[NACC]) const {
-        const float qsa = q[b * N + action[b]];
-        float tq = next_q[b * N + next_action[b]];
-        if (rescale) tq = h_inverse(tq, 1e-2f);
-        float R = 0.f, f = 1.f;
-        for (int t = 0; t < nstep; ++t) { R = fmaf(f, reward[(size_t)t * B + b], R); f *= gamma; }
-        float tgt = R + gamma_n * tq * (1.f - done[b]);
-        if (rescale) tgt = h_transform(tgt, 1e-2f);
+        // Round 4: every scalar of the sample is requested before the first use, the rewards eight steps at a time (nstep.hpp).
+        // The plain loop `R = fmaf(f, reward[t, b], R)` with its run-time trip count made the compiler wait for each reward before
+        // the next was requested: nstep dependent memory round trips in front of a two-load kernel.  Same operations, same order.
+        const long a = action[b], na = next_action[b];
+        const float dn = done[b];
         const float w = weight ? weight[b] : 1.f;
+        const float R = nstep_return1(reward, B, nstep, gamma, b);
+        const float qsa = q[b * N + a];
+        float tq = next_q[b * N + na];
+        if (rescale) tq = h_inverse(tq, 1e-2f);
+        float tgt = R + gamma_n * tq * (1.f - dn);
+        if (rescale) tgt = h_transform(tgt, 1e-2f);
         const float d = qsa - tgt;
         td_err[b] = d * d;
         acc[0] = fmaf(d * d, w, acc[0]);
