@@ -996,10 +996,22 @@ __global__ __launch_bounds__(256) void scatter_out_wave_kernel(const float* __re
 __global__ __launch_bounds__(1024) void scatter_bwd_lds_kernel(const float* __restrict__ grad_out,
                                                                const int64_t* __restrict__ location,
                                                                float* __restrict__ grad_x, int M, int N, int H,
-                                                               int W, int NG) {
+                                                               int W, int NG, int xcd_order) {
     extern __shared__ __attribute__((aligned(16))) float s_plane[];  // NG * HW
-    const int b = blockIdx.y;
-    const int n0 = blockIdx.x * NG;
+    // xcd_order (round 4, tune key 38): the workgroups of ONE batch element write 16-byte pieces of the same 128-byte lines of
+    // grad_x (an entity's row is N floats; a workgroup owns NG of them).  Dispatched in launch order they land on eight different
+    // XCDs -- eight L2s each holding a partial line, each written back masked.  Workgroup i runs on XCD i % 8: with
+    // L = (i % 8) * (total / 8) + i / 8 as the logical index, the channel groups of a batch element take consecutive slots of one
+    // XCD and their pieces meet in ONE L2 before the line leaves it.
+    unsigned bi = blockIdx.y, ci = blockIdx.x;
+    if (xcd_order) {
+        const unsigned nx = gridDim.x, total = nx * gridDim.y, id = blockIdx.x + nx * blockIdx.y;
+        const unsigned L = (id & 7u) * (total >> 3) + (id >> 3);
+        bi = L / nx;
+        ci = L - bi * nx;
+    }
+    const int b = (int)bi;
+    const int n0 = (int)ci * NG;
     const int ng = min(NG, N - n0);
     const int HW = H * W;
     const float* __restrict__ g = grad_out + ((size_t)b * N + n0) * HW;
@@ -1111,7 +1123,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __
 }  // namespace hpc_rll
 
 namespace hpc_rll { int g_pad_wave = 1; }   // hpc_rll_tune_set key 28: packed Pad1D on wave tiles in output space (0 = the round-3 workgroup kernel)
-namespace hpc_rll { int g_scatter_threads = 1024; int g_scatter_bwd_lds_kb = 64; int g_scatter_lds_fwd = 1; int g_scatter_npb = 0; int g_scatter_build = 1; }
+namespace hpc_rll { int g_scatter_threads = 1024; int g_scatter_bwd_lds_kb = 64; int g_scatter_lds_fwd = 1; int g_scatter_npb = 0; int g_scatter_build = 1; int g_scatter_bwd_xcd = 1; }
 namespace hpc_rll { int g_scatter_bwd_stream = 0; }   // hpc_rll_tune_set key 34: persistent pipelined scatter backward (experiment: slower, see the kernel)
 using namespace hpc_rll;
 
@@ -1562,7 +1574,11 @@ extern "C" int hpc_rll_scatter_connection_backward(const float* grad_out, const 
             hipFuncSetAttribute((const void*)scatter_bwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
                 hipSuccess)
             return last_error();
-        hipLaunchKernelGGL(scatter_bwd_lds_kernel, grid, dim3(1024), lds, st, grad_out, location, grad_x, M, N, H, W, NG);
+        // measured (profiles/r04_scatter_bwd_xcd.txt): 16-byte pieces (64 x 64 maps, NG = 4) -8 % at C5 and -31 % at M = 1024, N = 128;
+        // 64-byte pieces (32 x 32 maps) +6 %, whole lines (16 x 16) +4 % -- only pieces below a 64-byte sector pair profit
+        const int xcd_order = (g_scatter_bwd_xcd == 2 || (g_scatter_bwd_xcd == 1 && NG * 4 <= 32)) &&
+                              ((long)grid.x * grid.y) % 8 == 0 && grid.x > 1;
+        hipLaunchKernelGGL(scatter_bwd_lds_kernel, grid, dim3(1024), lds, st, grad_out, location, grad_x, M, N, H, W, NG, xcd_order);
     } else {
         const long total = (long)B * M * N;
         long blocks = (total + 255) / 256;

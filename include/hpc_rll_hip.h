@@ -199,6 +199,10 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * 812 us); 2 / 3 = add wherever M <= 1024, on large maps through the LDS kernel at 32 / 64 channels per workgroup, and in the
  * cells-per-thread kernels (all measured slower: C5 add 859 -> 922 / 901 / 875 us); 0 = the index launch of rounds 1-3 for every
  * path.  Identical results.
+ * key 38: scatter-connection backward runs the channel groups of one batch element on ONE XCD (their pieces of the same grad_x
+ * lines then meet in one L2 instead of being written back masked from eight): 1 (default) = where a workgroup's piece of an entity row
+ * is at most 32 bytes (C5: 860 -> 792 us; M = 1024, N = 128 on 64 x 64 maps: 406 -> 280 us), 2 = always (64-byte pieces +6 %, whole
+ * lines +4 %), 0 = launch order.  Identical results.
  */
 int hpc_rll_tune_set(int key, int value);
 

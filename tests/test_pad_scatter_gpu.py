@@ -514,3 +514,30 @@ def test_scatter_in_kernel_index_build(B, M, N, H, W):
     finally:
         NW.tune_set(37, 1)
         NW.tune_set(17, 1)
+
+
+@pytest.mark.parametrize("B,M,N,H,W", [(16, 256, 64, 64, 64), (24, 100, 16, 64, 64), (8, 37, 12, 64, 32), (40, 64, 64, 32, 32), (3, 50, 8, 64, 64)])
+def test_scatter_backward_xcd_order_bit_exact(B, M, N, H, W):
+    """Tune key 38 (round 4): the channel groups of a batch element take consecutive slots of ONE XCD (logical index
+    (i % 8) * (total / 8) + i / 8) so that their pieces of the same grad_x lines meet in one L2.  A pure re-labelling of which
+    workgroup does what: launch order (0), the default rule (1) and always (2) give the same bits, also where the grid is no
+    multiple of 8 (no re-labelling) and with out-of-range locations (zero gradient)."""
+    import cabi as C
+    import hpc_torch_utils_network as NW
+    g = torch.Generator(device=DEV).manual_seed(B * 131 + M)
+    go = torch.randn(B, N, H, W, device=DEV, generator=g)
+    loc = torch.stack([torch.randint(-1, H + 1, (B, M), device=DEV, generator=g), torch.randint(0, W, (B, M), device=DEV, generator=g)], -1)
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    try:
+        for key in (0, 1, 2):
+            NW.tune_set(38, key)
+            gx = torch.full((B, M, N), float("nan"), device=DEV)
+            assert C.lib.hpc_rll_scatter_connection_backward(go.data_ptr(), loc.data_ptr(), gx.data_ptr(), B, M, N, H, W, s) == 0
+            outs.append(gx.cpu())
+    finally:
+        NW.tune_set(38, 1)
+    ok = (loc[..., 0] >= 0) & (loc[..., 0] < H)
+    want = go.permute(0, 2, 3, 1)[torch.arange(B, device=DEV)[:, None], loc[..., 0].clamp(0, H - 1), loc[..., 1]] * ok[..., None]
+    assert torch.equal(outs[0], want.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
