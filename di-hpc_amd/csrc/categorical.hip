@@ -909,7 +909,7 @@ int categorical_backward(const float* logits, const int64_t* action, const float
 
 }  // namespace hpc_rll
 
-namespace hpc_rll { extern int g_gemm_bk; extern int g_scatter_threads; extern int g_lstm_persist; extern int g_lstm_xchg_rep; extern int g_lstm_jw; extern int g_gemm_big_target; extern int g_gemm_big_tile128; extern int g_lstm_wave; extern int g_scatter_bwd_lds_kb; extern int g_gemm_xcd; extern int g_lstm_nn_bwd; extern int g_lstm_dh_big; extern int g_gemm_lat_target; extern int g_gemm_thr_ktiles; extern int g_cell_vec4; extern int g_gemm_tile256; extern int g_scatter_lds_fwd; extern int g_scatter_npb; extern int g_scan_wave_target; extern int g_cell_rows_wgs; extern int g_scan_fold; extern int g_split_algo; extern int g_gemm_exp; extern int g_sample_batch; extern int g_gemm_dma; extern int g_lstm_block; extern int g_lstm_block_skew; extern int g_pad_wave; extern int g_lstm_mid; extern int g_lstm_mid_rep; extern int g_onehot_fill_mb; extern int g_ppo_fused; extern int g_lstm_mid_bwd; extern int g_scatter_bwd_stream; extern int g_onehot_qpw; extern int g_lstm_poll_nap; extern int g_scatter_build; extern int g_scatter_bwd_xcd; }
+namespace hpc_rll { extern int g_gemm_bk; extern int g_scatter_threads; extern int g_lstm_persist; extern int g_lstm_xchg_rep; extern int g_lstm_jw; extern int g_gemm_big_target; extern int g_gemm_big_tile128; extern int g_lstm_wave; extern int g_scatter_bwd_lds_kb; extern int g_gemm_xcd; extern int g_lstm_nn_bwd; extern int g_lstm_dh_big; extern int g_gemm_lat_target; extern int g_gemm_thr_ktiles; extern int g_cell_vec4; extern int g_gemm_tile256; extern int g_scatter_lds_fwd; extern int g_scatter_npb; extern int g_scan_wave_target; extern int g_cell_rows_wgs; extern int g_scan_fold; extern int g_split_algo; extern int g_gemm_exp; extern int g_sample_batch; extern int g_gemm_dma; extern int g_lstm_block; extern int g_lstm_block_skew; extern int g_pad_wave; extern int g_lstm_mid; extern int g_lstm_mid_rep; extern int g_onehot_fill_mb; extern int g_ppo_fused; extern int g_lstm_mid_bwd; extern int g_scatter_bwd_stream; extern int g_onehot_qpw; extern int g_lstm_poll_nap; extern int g_scatter_build; extern int g_scatter_bwd_xcd; extern int g_lstm_mid_xcd; }
 extern "C" int hpc_rll_tune_set(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { hpc_rll::g_blocks_per_cu = value; return HPC_RLL_OK; }
     if (key == 1 && (value == 0 || value == 16 || value == 32)) { hpc_rll::g_gemm_bk = value; return HPC_RLL_OK; }
@@ -949,6 +949,7 @@ extern "C" int hpc_rll_tune_set(int key, int value) {
     if (key == 36 && value >= 1 && value <= 8) { hpc_rll::g_lstm_poll_nap = value; return HPC_RLL_OK; }
     if (key == 37 && value >= 0 && value <= 3) { hpc_rll::g_scatter_build = value; return HPC_RLL_OK; }
     if (key == 38 && value >= 0 && value <= 2) { hpc_rll::g_scatter_bwd_xcd = value; return HPC_RLL_OK; }
+    if (key == 39 && (value == 0 || value == 1)) { hpc_rll::g_lstm_mid_xcd = value; return HPC_RLL_OK; }
     if (key == 24 && (value == 0 || value == 1 || value == 8 || value == 16 || value == 32 || value == 64)) { hpc_rll::g_sample_batch = value; return HPC_RLL_OK; }
     return HPC_RLL_EINVAL;
 }

@@ -203,6 +203,9 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * lines then meet in one L2 instead of being written back masked from eight): 1 (default) = where a workgroup's piece of an entity row
  * is at most 32 bytes (C5: 860 -> 792 us; M = 1024, N = 128 on 64 x 64 maps: 406 -> 280 us), 2 = always (64-byte pieces +6 %, whole
  * lines +4 %), 0 = launch order.  Identical results.
+ * key 39: mid-batch LSTM forward kernel with neighbouring workgroups (the two halves of the same 128-byte lines of the saved
+ * tensors) on one XCD: 0 (default) = launch order, 1 = on (an experiment: -6 % at B = 128, H = 512, +1.5 ... 4.5 % at three other
+ * shapes, profiles/r04_lstm_mid_xcd.txt).  Identical results.
  */
 int hpc_rll_tune_set(int key, int value);
 

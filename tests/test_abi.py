@@ -91,7 +91,7 @@ def test_tuning_knobs_documented_and_guarded():
     keys = sorted({int(k) for k in re.findall(r"key (\d+)", doc)})
     assert keys == list(range(len(keys))) and len(keys) >= 26, keys
     defaults = {0: 1024, 1: 0, 2: 1024, 3: 1, 4: 4, 5: 0, 6: 768, 7: 1, 8: 1, 9: 64, 10: 1, 11: 1, 12: 1, 13: 256, 14: 8,
-                15: 3, 16: 1, 17: 1, 18: 0, 19: 4096, 20: 512, 21: 1, 22: 0, 23: 0, 24: 0, 25: 1, 26: 9, 27: 10, 28: 1, 29: 2, 30: 8, 31: 3072, 32: 1, 33: 1, 34: 0, 35: 0, 36: 1, 37: 1, 38: 1}
+                15: 3, 16: 1, 17: 1, 18: 0, 19: 4096, 20: 512, 21: 1, 22: 0, 23: 0, 24: 0, 25: 1, 26: 9, 27: 10, 28: 1, 29: 2, 30: 8, 31: 3072, 32: 1, 33: 1, 34: 0, 35: 0, 36: 1, 37: 1, 38: 1, 39: 0}
     for k in keys:
         assert N.lib.hpc_rll_tune_set(k, defaults[k]) == 0, k
         assert N.lib.hpc_rll_tune_set(k, -7) != 0, k
