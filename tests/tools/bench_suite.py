@@ -278,6 +278,11 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
                                  weight[:Bi].contiguous())[0], [qi])
     report("iqn_nstep_td", f"tau=tau'={tau} B={Bi} N={N}", t_f, Bi * (2 * tau * 128 + 8 * tau + per_sample), t_b,
            Bi * (4 * tau * N + 4 * tau), valu_f=vc.get("iqn_nstep_td_fwd", 0) * Bi)
+    # the forward is a 128-byte-line gather (every other line of q / next_n_q): what that pattern reaches with the loss arithmetic
+    # left out is measured (tests/tools/micro/gather.hip, profiles/r04_gather_micro.txt: 5.3-5.9 TB/s of lines in four lane -> row
+    # maps, a contiguous read 6.3) -- reported beside the fraction of the 8 TB/s peak
+    rows[-1].update(fwd_line_gather_ceiling_gbs=5800.0, fwd_frac_of_gather_ceiling=rows[-1]["fwd_gbs"] / 5800.0,
+                    fwd_bound_note="line-granular gather: a bare gather of the same lines runs at 5.3-5.9 TB/s (profiles/r04_gather_micro.txt)")
     ri, di, wi = reward[:, :Bi].contiguous(), done[:Bi].contiguous(), weight[:Bi].contiguous()
     add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(qi, nqi, ai, nai, ri, di, rq, 0.99, 1.0, wi)[0], [qi]),
                                          (Bi * (2 * tau * 128 + 8 * tau + per_sample), Bi * (4 * tau * N + 4 * tau))) for x in pair])
