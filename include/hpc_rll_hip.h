@@ -361,7 +361,8 @@ int hpc_rll_pad1d_group_forward(const int64_t* table, const int64_t* order, cons
 /* ScatterConnection -- replaces ScatterConnectionForward/Backward (torch_utils/network/entry.h:21-29,
  * src/torch_utils/network/scatter_connection.cu:8-73).  x (B,M,N) fp32, location (B,M,2) int64 (y,x),
  * out (B,N,H,W) fp32 (fully written: no pre-zeroing needed); add=0: "cover" (the largest m at a cell wins,
- * like the CPU oracle), add=1: sum in ascending m.  ws: hpc_rll_scatter_workspace_ints(B,M,H,W) int32.
+ * like the CPU oracle), add=1: sum in ascending m.  ws: hpc_rll_scatter_workspace_ints(B,M,H,W) int32 of scratch
+ * (contents unspecified afterwards; untouched where the output kernel builds its tables in LDS, tune key 37).
  * backward: grad_x[b,m,:] = grad_out[b,:,y,x] for every entity (also the covered ones). */
 int64_t hpc_rll_scatter_workspace_ints(int B, int M, int H, int W);
 int hpc_rll_scatter_connection_forward(const float* x, const int64_t* location, float* out, int32_t* ws, int B,
