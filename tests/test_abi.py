@@ -118,3 +118,31 @@ def test_c_program_links_and_runs(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "abi 4 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_xcd_relabelling_is_a_permutation():
+    """csrc/pad_scatter.hip (scatter backward, tune key 38) and csrc/lstm_block.hpp (row-block backward) re-label workgroups so that
+    the ones that share cache lines run on one XCD (workgroup i runs on XCD i % 8).  The formulas, restated: every workgroup keeps
+    exactly one logical index, and the workgroups of one group share i % 8."""
+    for nx, ny in ((16, 4096), (8, 24), (4, 6), (16, 1)):          # scatter backward: nx channel groups x ny batch elements
+        total = nx * ny
+        if total % 8:
+            continue
+        seen = {}
+        for i in range(total):
+            L = (i % 8) * (total // 8) + i // 8
+            b, cg = divmod(L, nx)
+            assert (b, cg) not in seen and b < ny
+            seen[(b, cg)] = i % 8
+        assert len(seen) == total
+        if (total // 8) % nx == 0:                                  # a batch element's groups never straddle two XCDs
+            for b in range(ny):
+                assert len({seen[(b, cg)] for cg in range(nx)}) == 1
+    for nnt, nrb in ((8, 32), (8, 8), (4, 16)):                     # row-block backward: nnt tiles x nrb row blocks (nrb % 8 == 0)
+        seen = {}
+        for i in range(nnt * nrb):
+            grp = 8 * nnt
+            rbl, nt = (i // grp) * 8 + (i & 7), (i % grp) >> 3
+            assert (rbl, nt) not in seen and rbl < nrb and nt < nnt
+            seen[(rbl, nt)] = i % 8
+        assert all(len({seen[(r, t)] for t in range(nnt)}) == 1 for r in range(nrb))
