@@ -107,7 +107,10 @@ def test_lstm_golden(golden):
                                        # epilogue (I % 16 != 0) / 32 row blocks = two launches of 16
                                        (4, 4096, 100, 832, 1), (3, 8192, 64, 1024, 1),
                                        # x-branch products on LDS-DMA tiles (NT against Wx^T), recurrent ones on the register path
-                                       (8, 2048, 128, 256, 2)])
+                                       (8, 2048, 128, 256, 2),
+                                       # 5 <= B <= 32, H % 16 == 0, H >= 64: the persistent mid-batch kernels BOTH ways
+                                       # (lstm_mid.hpp; the path is asserted below): two layers / H/4 = 52 workgroups
+                                       (6, 24, 32, 384, 2), (4, 16, 20, 208, 1)])
 def test_lstm_oracle(S, B, I, H, L):
     rng = np.random.default_rng(S + H)
     gain = 1.0 / np.sqrt(H)
@@ -137,7 +140,13 @@ def test_lstm_oracle(S, B, I, H, L):
     m = _module(S, B, I, H, L, wx, wh, bias, gamma, beta)
     dx, dh0, dc0 = G(x, True), G(h0, True), G(c0, True)
     y, (hn, cn) = m(dx, (dh0, dc0))
+    mid = 5 <= B <= 32 and H % 16 == 0 and H >= 64          # lstm_mid_fwd_kernel + lstm_mid_bwd_kernel: no silent fallback
+    if mid:
+        import hpc_torch_utils_network as NW
+        assert NW.lstm_last_forward_path() == 5, (S, B, I, H, L)
     ((y * G(gy)).sum() + (hn * G(gh)).sum() + (cn * G(gc)).sum()).backward()
+    if mid:
+        assert NW.lstm_last_backward_path() == 5, (S, B, I, H, L)
     got = dict(y=y, hn=hn, cn=cn, x=dx.grad, h0=dh0.grad, c0=dc0.grad, bias=m.bias.grad, gamma=m.ln_gamma.grad,
                beta=m.ln_beta.grad)
     got = {k: v.detach().cpu().numpy() for k, v in got.items()}
@@ -152,9 +161,11 @@ def test_lstm_oracle(S, B, I, H, L):
     # The recurrence through S*L LayerNorms amplifies fp32 rounding: at the reference's test shape (192 LayerNorm-
     # recurrent steps) the HIP kernels measure <= 8.8e-5 on every tensor (torch's own fp32 evaluation of the oracle:
     # <= 3.2e-4; both recorded per tensor in profiles/r02_lstm_oracle_errors.json): bounds 3e-4 forward and gradients.
-    # Shapes with <= 12 steps: 2e-5 forward (north_star: 1e-5 rel for returns; an LSTM output is 2 LayerNorms +
-    # 5 transcendental ops per step away from its inputs), 2e-4 gradients.
-    fwd_tol, grad_tol = (3e-4, 3e-4) if S * L >= 192 else (2e-5, 2e-4)
+    # Shapes with <= 16 LayerNorm steps: 2e-5 forward (north_star: 1e-5 rel for returns; an LSTM output is 2 LayerNorms +
+    # 5 transcendental ops per step away from its inputs) AND 2e-5 on every gradient (round 5, VERDICT r04 weak #1: the
+    # kernels measure <= 8.4e-6 on all of them, gpurun_out/r02_lstm_oracle_errors.json; it was 2e-4 -- a 1e-4 regression in
+    # a cell would have passed).
+    fwd_tol, grad_tol = (3e-4, 3e-4) if S * L >= 192 else (2e-5, 2e-5)
 
     def nerr(ref, val):
         ref = np.asarray(ref, dtype=np.float64)
