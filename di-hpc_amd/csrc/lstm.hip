@@ -1124,6 +1124,29 @@ extern "C" int64_t hpc_rll_lstm_workspace_y_offset(int S, int B, int I, int H, i
 namespace hpc_rll { namespace {
 std::atomic<int> g_lstm_last_path{-1};   // hpc_rll_lstm_last_forward_path (diagnostic)
 std::atomic<int> g_lstm_last_bwd_path{-1};   // hpc_rll_lstm_last_backward_path
+// ... and of THIS host thread (a binding that reads the path right after its own call must not see another
+// thread's forward): hpc_rll_lstm_last_forward_path() answers with it once the calling thread has run a forward.
+thread_local int t_lstm_last_path = -1;
+struct LastPath {
+    void store(int v, std::memory_order) { g_lstm_last_path.store(v, std::memory_order_relaxed); t_lstm_last_path = v; }
+} g_lstm_path_both;
+
+// hpc_rll_lstm_forward_y leaves the workspace's own last-layer h-sequence slot UNWRITTEN (y is that sequence) on every path
+// but the layer wavefront: a later hpc_rll_lstm_backward WITHOUT y on that workspace would read uninitialised memory
+// (ADVICE r04).  Host-side record, keyed by the workspace address, of what the most recent forward on it was: no device
+// work, no synchronisation.  (Addresses are recycled by the caller's allocator: every forward overwrites its entry.)
+std::mutex g_ws_pair_mu;
+std::map<const void*, bool> g_ws_y_external;
+void ws_pair_record(const void* ws, bool y_external) {
+    std::lock_guard<std::mutex> lk(g_ws_pair_mu);
+    if (!y_external) { g_ws_y_external.erase(ws); return; }
+    if (g_ws_y_external.size() >= 4096) g_ws_y_external.clear();   // bounded: forgetting only loses the diagnosis
+    g_ws_y_external[ws] = true;
+}
+bool ws_pair_needs_y(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_ws_pair_mu);
+    return g_ws_y_external.count(ws) != 0;
+}
 // y_hseq: y doubles as the last layer's h sequence (the caller hands the SAME y to the backward, which reads it there):
 // the cells write y directly, the workspace's own slot for it stays unused, no (S,B,H) copy.
 int lstm_forward_impl(const float* x, const float* h0, const float* c0, const float* wx,
@@ -1148,7 +1171,8 @@ int lstm_forward_impl(const float* x, const float* h0, const float* c0, const fl
     size_t wx_off = 0;
     WaveCfg wc{};
     const bool wave = S > 0 && wave_fwd_ok(S, B, H, L, &wc, st);
-    g_lstm_last_path.store(wave ? 2 : 0, std::memory_order_relaxed);
+    g_lstm_path_both.store(wave ? 2 : 0, std::memory_order_relaxed);
+    ws_pair_record(ws, y_hseq && !wave && S > 0 && y != w.layer[L - 1].hseq);
     // (the layer wavefront addresses every layer's buffers with one stride: it keeps its h sequences in the workspace and
     // y is filled by the copy at the end -- a few KB at B <= 4)
     if (y_hseq && !wave && S > 0) w.layer[L - 1].hseq = y;
@@ -1202,9 +1226,9 @@ int lstm_forward_impl(const float* x, const float* h0, const float* c0, const fl
     const bool block = perm && block_fwd_ok(B, H, st);
     // mid-size batches: one persistent kernel per layer with the product on the matrix cores (lstm_mid.hpp)
     const bool mid = S > 0 && !persist && !perm && cell_al16(ws) && cell_al16(h0) && mid_fwd_ok(B, H, st);   // (16-byte accesses to the workspace and h0)
-    if (persist) g_lstm_last_path.store(1, std::memory_order_relaxed);
-    if (mid) g_lstm_last_path.store(5, std::memory_order_relaxed);
-    if (perm) g_lstm_last_path.store(block ? 4 : 3, std::memory_order_relaxed);
+    if (persist) g_lstm_path_both.store(1, std::memory_order_relaxed);
+    if (mid) g_lstm_path_both.store(5, std::memory_order_relaxed);
+    if (perm) g_lstm_path_both.store(block ? 4 : 3, std::memory_order_relaxed);
     for (int l = 0; l < L && perm; ++l) {
         const int in_l = l == 0 ? I : H;
         const float* xin = l == 0 ? x : w.layer[l - 1].xin_next;
@@ -1356,6 +1380,7 @@ int lstm_backward_impl(const float* dy, const float* dhn, const float* dcn, cons
     hipStream_t st = (hipStream_t)stream;
     const size_t SB = (size_t)S * B, G = 4 * (size_t)H, BH = (size_t)B * H;
     Ws w = carve(ws, S, B, I, H, L, dropout_p > 0.f);
+    if (!y_ext && ws_pair_needs_y(ws)) return HPC_RLL_EINVAL;    // forward_y on this workspace pairs with backward_y only
     if (y_ext) w.layer[L - 1].hseq = const_cast<float*>(y_ext);   // read only on this side
     size_t wx_offs[16];
     {
@@ -1592,8 +1617,11 @@ extern "C" int hpc_rll_lstm_backward(const float* dy, const float* dhn, const fl
 // Which kernels the most recent hpc_rll_lstm_forward* call of this process ran its recurrence on (a diagnostic, like
 // hpc_rll_gae_last_config): 0 = one product + one cell launch per step, 1 = per-layer persistent kernels (B <= 4),
 // 2 = layer wavefront (B <= 4, L >= 2), 3 = step kernels on gate-interleaved pre-activations (large batch), 4 = persistent
-// row-block kernel (large batch, lstm_block.hpp); -1 = no forward yet.
-extern "C" int hpc_rll_lstm_last_forward_path(void) { return g_lstm_last_path.load(std::memory_order_relaxed); }
+// row-block kernel (large batch, lstm_block.hpp), 5 = persistent mid-batch kernel (lstm_mid.hpp); -1 = no forward yet.  The
+// calling thread's own most recent forward if it ran one, else the process's.
+extern "C" int hpc_rll_lstm_last_forward_path(void) {
+    return t_lstm_last_path >= 0 ? t_lstm_last_path : g_lstm_last_path.load(std::memory_order_relaxed);
+}
 // ... and the most recent hpc_rll_lstm_backward* call (last layer processed): same codes.
 extern "C" int hpc_rll_lstm_last_backward_path(void) { return g_lstm_last_bwd_path.load(std::memory_order_relaxed); }
 

@@ -821,7 +821,12 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
     }
 }
 
-inline bool lstm_block_bwd_shape(int B, int H) { return lstm_perm_shape(B, H) && H % 128 == 0 && B % 128 == 0; }
+// One column-sum row of 3 * 4H floats per 128-row block goes to the workspace's `colpart` (launch_block_bwd_t), which carve()
+// sizes for kBlockBwdMaxRowBlocks (= kCellRowsMaxWgs) rows: larger batches (B > 131072) keep the step kernels.
+constexpr int kBlockBwdMaxRowBlocks = kCellRowsMaxWgs;   // (lstm.hip, above this include: the rows carve() gives colpart)
+inline bool lstm_block_bwd_shape(int B, int H) {
+    return lstm_perm_shape(B, H) && H % 128 == 0 && B % 128 == 0 && B / 128 <= kBlockBwdMaxRowBlocks;
+}
 inline int block_bwd_rows_per_launch(int H) {
     const int nnt = H / 128;
     return nnt > 0 ? persist_cu_count() / nnt : 0;

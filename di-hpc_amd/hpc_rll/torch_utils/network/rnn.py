@@ -11,12 +11,14 @@ buffers are dropped), a checkpoint saved here holds the five parameters only; th
 > 0, also under ``eval()``).
 The autograd node is ``hpc_torch_utils_network.lstm`` (compiled torch::autograd::Function).
 
-Small batches (B <= 4) run persistent kernels whose workgroups exchange data and must be co-resident on the GPU.  If
-ANOTHER PROCESS holds the compute units for seconds, such a kernel gives up and reports it asynchronously: the next
-LSTM call of this process warns, re-runs itself on the step kernels and keeps using them; results produced in between
-are invalid.  On GPUs shared between processes (several actors per GPU) either construct the module with
-``check_persistent=True`` (synchronises after every small-batch forward, checks, and recomputes on the spot -- an
-actor reads its outputs right away anyhow) or export ``HPC_RLL_LSTM_PERSIST=0`` (step kernels from the start).
+Three batch regimes run PERSISTENT kernels whose workgroups exchange data and must be co-resident on the GPU: B <= 4
+(per-layer kernels / layer wavefront), 5 <= B <= 256 (mid-batch kernels, ``csrc/lstm_mid.hpp``) and B >= 4096 (row-block
+kernels, ``csrc/lstm_block.hpp``).  If ANOTHER PROCESS holds the compute units for seconds, such a kernel gives up and
+reports it asynchronously: the next LSTM call of this process warns, re-runs itself on the step kernels and keeps using
+them; results produced in between are invalid.  On GPUs shared between processes (several actors per GPU) either
+construct the module with ``check_persistent=True`` (synchronises after every forward that RAN a persistent kernel --
+whatever the batch size --, checks, and recomputes on the spot: an actor reads its outputs right away anyhow) or export
+``HPC_RLL_LSTM_PERSIST=0`` (step kernels from the start).
 """
 import math
 import os
@@ -80,12 +82,13 @@ class LSTM(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
         args = (inputs, self.wx, self.wh, self.bias, self.ln_gamma, self.ln_beta, h0, c0, p, seed)
         y, h, c = hpc_torch_utils_network.lstm(*args)
-        if self.check_persistent and inputs.shape[1] <= 4:
+        # paths 1, 2, 4, 5 of hpc_rll_lstm_last_forward_path (this thread's own call): kernels that need co-residency
+        if self.check_persistent and hpc_torch_utils_network.lstm_last_forward_path() in (1, 2, 4, 5):
             # the persistent kernels report a co-residency timeout asynchronously: wait for THIS call and look
             torch.cuda.current_stream(inputs.device).synchronize()
             if hpc_torch_utils_network.async_error():
                 hpc_torch_utils_network.clear_async_error()
-                warnings.warn("hpc_rll LSTM: a persistent small-batch kernel timed out waiting for co-residency (another process "
+                warnings.warn("hpc_rll LSTM: a persistent kernel timed out waiting for co-residency (another process "
                               "holds the GPU); this forward is recomputed on the step kernels, which are used from now on",
                               RuntimeWarning)
                 y, h, c = hpc_torch_utils_network.lstm(*args)

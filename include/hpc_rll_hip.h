@@ -159,7 +159,7 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  * k-depth 64, bit 6 its linear workgroup order, bit 7 the forward's exchanges without cache-wide fences (measured: 65.25 -> 65.14 ms
  * at the default start skew, 68.2 -> 65.5 without one -- the skew already hides what the fences cost).
  * Default 9 = forward + backward.  Forward and backward paths can be mixed freely (same saved tensors).
- * key 27: start skew of that kernel's row blocks in microseconds (0 ... 200, default 0): row block r waits r x this
+ * key 27: start skew of that kernel's row blocks in microseconds (0 ... 200, default 10): row block r waits r x this
  * before its first step, which spreads the HBM-bound epilogues of the row blocks over the step.
  * key 28: packed Pad1D (hpc_rll_pad1d_packed_forward, 32 <= max_len <= 16384): 1 (default) = wave-synchronous tiles of 1024
  * consecutive OUTPUT elements (their packed source is one contiguous span, staged through the wave's own LDS slice);

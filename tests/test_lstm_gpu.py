@@ -934,6 +934,25 @@ with torch.no_grad():
     chk, _ = m2(x, None)
 torch.cuda.synchronize()
 assert ((chk - ref).abs().max() / ref.abs().max()).item() < 1e-5
+# ... at EVERY batch size that runs a persistent kernel (the check used to cover B <= 4 only): the mid-batch
+# kernel (path 5), starved the same way, inside a check_persistent module -> detected and recomputed before the call returns
+S3, B3, I3, H3 = 8, 16, 32, 256
+m3 = LSTM(S3, B3, I3, H3, 1, check_persistent=True).to(dev)
+x3 = torch.randn(S3, B3, I3, device=dev)
+with torch.no_grad():
+    ref3, _ = m3(x3, None)
+torch.cuda.synchronize()
+assert NW.lstm_last_forward_path() == 5 and NW.async_error() == 0
+with torch.cuda.stream(side):
+    NW._test_occupy_device(1500, dev, 480)
+import warnings
+with warnings.catch_warnings(record=True) as caught, torch.no_grad():
+    warnings.simplefilter("always")
+    chk3, _ = m3(x3, None)
+torch.cuda.synchronize()
+assert NW.async_error() == 0
+assert ((chk3 - ref3).abs().max() / ref3.abs().max()).item() < 1e-5
+print("mid-batch check_persistent:", "recomputed" if any("timed out" in str(c.message) for c in caught) else "not starved")
 print("starved-ok", err)
 """
 
