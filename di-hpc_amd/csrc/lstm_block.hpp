@@ -506,23 +506,39 @@ struct BlockBwd {
     int xcd_map;                        // the 8-row-block groups of the launch are laid out XCD-major (see the kernel)
 };
 
-template <int BK> struct BlkBwdCfg {
-    static constexpr int BM = 128, BN = 128, NTH = 512;
-    static constexpr int tile_floats = 2 * BK * BM + 2 * BK * BN < 32 * NTH ? 32 * NTH : 2 * BK * BM + 2 * BK * BN;   // operand tiles; also
-                                                                                    // the accumulator dump [32][NTH] of the epilogue
+// NBUF = 3 (round 5): the product's LDS-DMA runs TWO k-tiles ahead.  With two buffers the request for tile kt+1 is issued when
+// tile kt starts (one tile = 4096 matrix-pipe cycles = 1.7 us) and waited for with vmcnt(0) at its end; a 128 x 128 tile pulls
+// twice the operand bytes per flop of the forward's 256 x 256 tile and its row block's Wh stream is shared with no other
+// row block of the XCD (they drift tens of microseconds apart: the L2 does not hold a tile that long), so every B chunk is an
+// L2 miss served by the Infinity Cache under ~2 TB/s of such traffic: a 1.7 us lead is not enough.  Three buffers + a
+// COUNTED wait (vmcnt(4): the newest tile's four pieces per thread may stay in flight) + a bare s_barrier (the fence
+// of __syncthreads would drain the DMA) give the stream 3.4 us.
+template <int NBUF> struct BlkBwdCfg {
+    static constexpr int BK = 32, BM = 128, BN = 128, NTH = 512;
+    static constexpr int tile_floats = NBUF * BK * (BM + BN);   // operand tiles; their first 32 * NTH floats are also the
+                                                                // accumulator dump [32][NTH] of the epilogue
+    static_assert(tile_floats >= 32 * NTH, "accumulator dump");
     static constexpr int lds_floats = tile_floats + BM * 4 + BM * 4 + 3 * 4 * BN;   // + stats, sums, column sums
-    static constexpr size_t lds_bytes = BK == 64 ? 144 * 1024 : 96 * 1024;   // one workgroup per CU
+    static constexpr size_t lds_bytes = NBUF == 3 ? 112 * 1024 : 96 * 1024;   // more than half of the 160 KB: one workgroup per CU
     static_assert(lds_floats * sizeof(float) <= lds_bytes, "row-block backward LDS");
 };
 
-constexpr int kRCB = 2;   // rows per load chunk of the backward epilogue (the 32 gate adjoints hold 128 registers)
-template <int BK, bool FAST>
+// NF: the two exchanges of a step without cache-wide fences (what the forward's bit 7 does): the exchanged data -- the
+// row-sum partials and dHW_s -- are stored write-through (sc1); dHW_s lives at addresses written once per launch (ordinary
+// loads / LDS-DMA cannot find a stale copy), the partials' slots are reused every other step and are read with sc1 loads.
+// RC: rows per load chunk of the two epilogue passes; the passes keep 32 / RC chunks in NS = 8 / RC statically indexed
+// register sets, NS - 1 chunks of loads in flight ahead of the arithmetic (RC = 4: one chunk of four rows ahead, the round-4
+// form; RC = 2: three chunks of two rows ahead -- 6 rows in flight instead of 4 in the same registers).
+template <int NBUF, bool NF, int RC>
 __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a) {
-    typedef BlkBwdCfg<BK> C;
-    constexpr int BM = C::BM, BN = C::BN, NTH = C::NTH, NQ = BK / 8;
+    typedef BlkBwdCfg<NBUF> C;
+    constexpr int BK = C::BK, BM = C::BM, BN = C::BN, NTH = C::NTH, NQ = BK / 8, NS = 8 / RC, NCH = 32 / RC;
+    constexpr bool FAST = true;
+    constexpr int SC = NF ? 16 : 0;   // sc1 on the exchanged stores / loads
+    static_assert(RC == 2 || RC == 4, "rows per chunk");
     extern __shared__ __attribute__((aligned(16))) float blk_lds[];
-    float* const As = blk_lds;                    // [2][BM rows][BK]
-    float* const Bs = As + 2 * BK * BM;           // [2][BN rows (units)][BK]
+    float* const As = blk_lds;                    // [NBUF][BM rows][BK]
+    float* const Bs = As + NBUF * BK * BM;        // [NBUF][BN rows (units)][BK]
     float* const sl = blk_lds + C::tile_floats;   // [BM][4] mean_x, rstd_x, mean_h, rstd_h of this step's rows
     float* const sa = sl + BM * 4;                // [BM][4] the four LayerNorm-adjoint row sums / 4H
     float* const cl = sa + BM * 4;                // [3][4 BN] column sums of the workgroup (final reduction only)
@@ -581,15 +597,29 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         DmaStage<BM, BK, NTH> da;
         DmaStage<BN, BK, NTH> db;
+        static_assert(NBUF == 2 || (DmaStage<BM, BK, NTH>::NP + DmaStage<BN, BK, NTH>::NP == 4), "vmcnt(4) below = one tile's pieces per thread");
         da.init(arows, G, 0, 0);
         db.init(a.whp + (size_t)(nt * BN) * G, G, 0, 0);
         da.issue(As);
         db.issue(Bs);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (NBUF == 3) {
+            da.issue(As + BK * BM);     // (ktiles = 4H / 32 >= 96: there always is a second tile)
+            db.issue(Bs + BK * BN);
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        int buf = 0;
         for (int kt = 0; kt < ktiles; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < ktiles) {
+            if (NBUF == 3) {
+                // tile kt + 2 goes where tile kt - 1 was: every wave has passed the barrier that ended tile kt - 1
+                const int nb = buf == 0 ? 2 : buf - 1;
+                if (kt + 2 < ktiles) {
+                    da.issue(As + nb * BK * BM);
+                    db.issue(Bs + nb * BK * BN);
+                }
+            } else if (kt + 1 < ktiles) {
                 da.issue(As + (buf ^ 1) * BK * BM);
                 db.issue(Bs + (buf ^ 1) * BK * BN);
             }
@@ -606,16 +636,28 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
 #pragma unroll
                     for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (NBUF == 3) {
+                // this wave's operand reads of tile kt are done (lgkmcnt), its pieces of tile kt + 1 have landed (all but
+                // the newest four requests), then the workgroup meets: no fence, the DMA of tile kt + 2 stays in flight
+                if (kt + 2 < ktiles) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                buf = buf == 2 ? 0 : buf + 1;
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                buf ^= 1;
+            }
         }
     };
+
+    // pair k (0 .. 31) of a lane = accumulator register (k >> 4, k & 15): its row inside the wave's 64 (without the lane's 4 h)
+    auto pair_row = [&](int k) __attribute__((always_inline)) { return (k >> 4) * 32 + 8 * ((k & 15) >> 2) + (k & 3); };
 
     for (int s = a.S - 1; s >= 0; --s) {
         const size_t srow = (size_t)s * a.B + row0;
         const bool last = s == a.S - 1;
         if (!last) {
-            block_wait(flag_h, (unsigned)(nnt * (a.S - 1 - s)));   // dHW_{s+1} of this row block is complete
+            block_wait(flag_h, (unsigned)(nnt * (a.S - 1 - s)), NF);   // dHW_{s+1} of this row block is complete
             HPC_RLL_BLK_TICK(0)
             product(a.dhw + (srow + a.B) * G);
         } else {
@@ -630,9 +672,9 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
 
         // ---- pass A: gate adjoints of the lane's 32 (row, unit) pairs, LayerNorm-adjoint row sums, column sums.
         // The product's accumulators go through LDS (the operand tiles are dead now): pair k = 16 i + r of every lane at
-        // accl[k][tid].  That turns the epilogue into ROLLED loops over chunks of four consecutive rows -- fully unrolled
+        // accl[k][tid].  That turns the epilogue into ROLLED loops over chunks of consecutive pairs -- fully unrolled
         // (the accumulator registers can only be indexed statically) it was 10 k instructions and spilled 500 registers.
-        float* const accl = blk_lds;   // [32][NTH] floats = the 64 KB of the operand tiles (BK = 32)
+        float* const accl = blk_lds;   // [32][NTH] floats = the first 64 KB of the operand tiles
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -648,16 +690,14 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
         const __amdgpu_buffer_rsrc_t r_dco = blk_rsrc((s == 0 ? a.dc0 : a.dc) + (size_t)row0 * H);
         const unsigned xob = 4u * xoff, uob = 4u * uoff;             // the lane's byte offsets
         const unsigned gb = 4u * (unsigned)G, hb = 4u * (unsigned)H;   // bytes per row
-        // chunk c = rows Rc .. Rc + 3 of the wave (pairs k = 4 c .. 4 c + 3): Rc = 64 wm + 32 (c >> 2) + 8 (c & 3)
-        auto chunk_row = [&](int c) __attribute__((always_inline)) { return (unsigned)(wm * 64 + (c >> 2) * 32 + 8 * (c & 3)); };
+        const unsigned wrow = (unsigned)(wm * 64);
         vfloat4 my = {0.f, 0.f, 0.f, 0.f};
         {
-            struct In { vfloat4 x[4], hh[4]; float cn[4], cp[4], dci[4], dy[4]; };
+            struct In { vfloat4 x[RC], hh[RC]; float cn[RC], cp[RC], dci[RC], dy[RC]; };
             auto load_chunk = [&](int c, In& v) __attribute__((always_inline)) {
-                const unsigned Rc = chunk_row(c);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned R = Rc + q;
+                for (int q = 0; q < RC; ++q) {
+                    const unsigned R = wrow + (unsigned)pair_row(RC * c + q);
                     v.x[q] = blk_ld4<0>(r_xw, xob, R * gb);   // (read again in pass B: no streaming hint)
                     v.hh[q] = blk_ld4<0>(r_hw, xob, R * gb);
                     v.cn[q] = blk_ld1<0>(r_cn, uob, R * hb);
@@ -669,13 +709,11 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
                 }
             };
             auto do_chunk = [&](int c, const In& v) __attribute__((always_inline)) {
-                const unsigned Rc = chunk_row(c);
-                const float* stp = slp + ((c >> 2) * 32 + 8 * (c & 3)) * 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned R = Rc + q;
-                    const int k = 4 * c + q;
-                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(stp + 4 * q);
+                for (int q = 0; q < RC; ++q) {
+                    const int k = RC * c + q;
+                    const unsigned R = wrow + (unsigned)pair_row(k);
+                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(slp + pair_row(k) * 4);
                     const vfloat4 x4 = v.x[q], h4 = v.hh[q];
                     float pre[4];
 #pragma unroll
@@ -706,34 +744,36 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
                     if (i32 == k) my = vfloat4{p0, p1, p2, p3};   // lane i32 = 16 i + r = k keeps row k of its half
                 }
             };
-            In va, vb;
-            load_chunk(0, va);
+            In v[NS];
+#pragma unroll
+            for (int j = 0; j < NS - 1; ++j) load_chunk(j, v[j]);
 #pragma unroll 1
-            for (int c = 0; c < 8; c += 2) {   // two chunks per trip: the two input sets alternate statically
-                load_chunk(c + 1, vb);
-                do_chunk(c, va);
-                if (c + 2 < 8) load_chunk(c + 2, va);
-                do_chunk(c + 1, vb);
+            for (int c = 0; c < NCH; c += NS) {   // NS chunks per trip: the input sets rotate statically
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    if (c + j + NS - 1 < NCH) load_chunk(c + j + NS - 1, v[(j + NS - 1) % NS]);
+                    do_chunk(c + j, v[j]);
+                }
             }
         }
         float* const pslot = part + (size_t)(s & 1) * 4 * nnt * BM * 4;
+        const __amdgpu_buffer_rsrc_t r_ps = blk_rsrc(pslot);
         {
             const int rr = i32 & 15;
             const int row = wm * 64 + (i32 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-            *reinterpret_cast<vfloat4*>(pslot + ((size_t)(4 * nt + wn) * BM + row) * 4) = my;
+            blk_st4<SC>(my, r_ps, (unsigned)(((4 * nt + wn) * BM + row) * 16), 0u);
         }
-        block_arrive(flag_s);
+        block_arrive(flag_s, NF);
         HPC_RLL_BLK_TICK(2)
-        block_wait(flag_s, (unsigned)(nnt * (a.S - s)));
+        block_wait(flag_s, (unsigned)(nnt * (a.S - s)), NF);
         HPC_RLL_BLK_TICK(3)
         if (tid < BM) {
             vfloat4 t = {0.f, 0.f, 0.f, 0.f};
-            const float* pp = pslot + (size_t)tid * 4;
             for (int c0 = 0; c0 < 4 * nnt; c0 += 8) {
                 vfloat4 p[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    p[k] = *reinterpret_cast<const vfloat4*>(pp + (size_t)(c0 + k < 4 * nnt ? c0 + k : 0) * BM * 4);
+                    p[k] = blk_ld4<SC>(r_ps, (unsigned)(tid * 16), (unsigned)((c0 + k < 4 * nnt ? c0 + k : 0) * BM * 16));
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (c0 + k < 4 * nnt) t += p[k];
@@ -746,23 +786,23 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
         // ---- pass B: dXW_s, dHW_s of the lane's pairs (gate adjoints, xw, hw read back: this lane's own lines, from L2)
         {
             const __amdgpu_buffer_rsrc_t r_dxw = blk_rsrc(a.dxw + srow * G), r_dhw = blk_rsrc(a.dhw + srow * G);
-            struct In { vfloat4 x[4], hh[4], d[4]; };
+            struct In { vfloat4 x[RC], hh[RC], d[RC]; };
             auto load_chunk = [&](int c, In& v) __attribute__((always_inline)) {
-                const unsigned Rc = chunk_row(c);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v.x[q] = blk_ld4<2>(r_xw, xob, (Rc + q) * gb);
-                    v.hh[q] = blk_ld4<2>(r_hw, xob, (Rc + q) * gb);
-                    v.d[q] = blk_ld4<2>(r_dg, xob, (Rc + q) * gb);
+                for (int q = 0; q < RC; ++q) {
+                    const unsigned R = wrow + (unsigned)pair_row(RC * c + q);
+                    v.x[q] = blk_ld4<2>(r_xw, xob, R * gb);
+                    v.hh[q] = blk_ld4<2>(r_hw, xob, R * gb);
+                    v.d[q] = blk_ld4<2>(r_dg, xob, R * gb);
                 }
             };
             auto do_chunk = [&](int c, const In& v) __attribute__((always_inline)) {
-                const unsigned Rc = chunk_row(c);
-                const int lo = ((c >> 2) * 32 + 8 * (c & 3)) * 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(slp + lo + 4 * q);
-                    const vfloat4 av = *reinterpret_cast<const vfloat4*>(sap + lo + 4 * q);
+                for (int q = 0; q < RC; ++q) {
+                    const int pr = pair_row(RC * c + q);
+                    const unsigned R = wrow + (unsigned)pr;
+                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(slp + pr * 4);
+                    const vfloat4 av = *reinterpret_cast<const vfloat4*>(sap + pr * 4);
                     vfloat4 ox, oh;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -770,26 +810,28 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
                         ox[g] = st.y * (dyx - av.x - (v.x[q][g] - st.x) * st.y * av.y);
                         oh[g] = st.w * (dyh - av.z - (v.hh[q][g] - st.z) * st.w * av.w);
                     }
-                    blk_st4<2>(ox, r_dxw, xob, (Rc + q) * gb);
-                    blk_st4<0>(oh, r_dhw, xob, (Rc + q) * gb);   // the next product's operand
+                    blk_st4<2>(ox, r_dxw, xob, R * gb);
+                    blk_st4<SC>(oh, r_dhw, xob, R * gb);   // the next product's operand
                 }
             };
-            In va, vb;
-            load_chunk(0, va);
+            In v[NS];
+#pragma unroll
+            for (int j = 0; j < NS - 1; ++j) load_chunk(j, v[j]);
 #pragma unroll 1
-            for (int c = 0; c < 8; c += 2) {
-                load_chunk(c + 1, vb);
-                do_chunk(c, va);
-                if (c + 2 < 8) load_chunk(c + 2, va);
-                do_chunk(c + 1, vb);
+            for (int c = 0; c < NCH; c += NS) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    if (c + j + NS - 1 < NCH) load_chunk(c + j + NS - 1, v[(j + NS - 1) % NS]);
+                    do_chunk(c + j, v[j]);
+                }
             }
         }
         HPC_RLL_BLK_TICK(5)
-        block_arrive(flag_h);
+        block_arrive(flag_h, NF);
         HPC_RLL_BLK_TICK(6)
     }
     // ---- dh0 = dHW_0 @ Wh^T, dc0 is already in place
-    block_wait(flag_h, (unsigned)(nnt * a.S));
+    block_wait(flag_h, (unsigned)(nnt * a.S), NF);
     product(a.dhw + (size_t)row0 * G);
     {
         float* const dh0 = a.dh0 + (size_t)row0 * H;
@@ -832,23 +874,41 @@ inline int block_bwd_rows_per_launch(int H) {
     return nnt > 0 ? persist_cu_count() / nnt : 0;
 }
 inline size_t block_bwd_part_floats(int B, int H) { return (size_t)(B / 128) * 2 * 4 * (H / 128) * 128 * 4; }
-inline int block_bwd_bk() { return (g_lstm_block & 16) ? 16 : (g_lstm_block & 32) ? 64 : 32; }
+// hpc_rll_tune_set key 26, bits 8-10 (round 5 experiments on the backward kernel): bit 8 = two operand buffers instead of
+// three, bit 9 = exchanges WITH cache-wide fences, bit 10 = four-row chunks in the epilogue passes
+inline int block_bwd_var() { return (g_lstm_block >> 8) & 7; }
 
-template <int BK> inline bool block_bwd_resident(int H) {
+template <int NBUF, bool NF, int RC> inline bool block_bwd_resident(int H) {
     const int per = block_bwd_rows_per_launch(H);
-    return per >= 1 && persist_resident_t(lstm_block_bwd_kernel<BK, true>, 512, (H / 128) * per, BlkBwdCfg<BK>::lds_bytes);
+    return per >= 1 && persist_resident_t(lstm_block_bwd_kernel<NBUF, NF, RC>, 512, (H / 128) * per, BlkBwdCfg<NBUF>::lds_bytes);
+}
+#define HPC_RLL_BLK_BWD_VARIANTS(F)                                                                                  \
+    switch (block_bwd_var()) {                                                                                     \
+        case 0: return F(3, true, 2);                                                                              \
+        case 1: return F(2, true, 2);                                                                              \
+        case 2: return F(3, false, 2);                                                                             \
+        case 3: return F(2, false, 2);                                                                             \
+        case 4: return F(3, true, 4);                                                                              \
+        case 5: return F(2, true, 4);                                                                              \
+        case 6: return F(3, false, 4);                                                                             \
+        default: return F(2, false, 4);                                                                            \
+    }
+inline bool block_bwd_resident_any(int H) {
+#define HPC_RLL_F(NB, NF, RC) block_bwd_resident<NB, NF, RC>(H)
+    HPC_RLL_BLK_BWD_VARIANTS(HPC_RLL_F)
+#undef HPC_RLL_F
 }
 inline bool block_bwd_ok(int B, int H, hipStream_t st) {
     if (!(g_lstm_block & 8) || !g_lstm_persist || !lstm_block_bwd_shape(B, H) || !persist_runtime_ready(st)) return false;
     if (!block_launches_fill(B / 128, block_bwd_rows_per_launch(H), H / 128)) return false;
-    return block_bwd_bk() == 16 ? block_bwd_resident<16>(H) : block_bwd_bk() == 64 ? block_bwd_resident<64>(H) : block_bwd_resident<32>(H);
+    return block_bwd_resident_any(H);
 }
-template <int BK>
+template <int NBUF, bool NF, int RC>
 inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
-    typedef BlkBwdCfg<BK> C;
+    typedef BlkBwdCfg<NBUF> C;
     const int nrb = a.B / 128, per = block_bwd_rows_per_launch(a.H);
     if (hipMemsetAsync(flags, 0, block_flag_words(a.B) * sizeof(unsigned), st) != hipSuccess) return last_error();
-    const hipError_t e = hipFuncSetAttribute((const void*)lstm_block_bwd_kernel<BK, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    const hipError_t e = hipFuncSetAttribute((const void*)lstm_block_bwd_kernel<NBUF, NF, RC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)C::lds_bytes);
     if (e != hipSuccess) return (int)e;
     a.nnt = a.H / 128;
@@ -862,15 +922,16 @@ inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* c
         a.colacc = colacc + (size_t)rb * 3 * 4 * a.H;
         a.xcd_map = (n % 8 == 0 && !(g_lstm_block & 64)) ? 1 : 0;
         persist_chain_before(st);
-        hipLaunchKernelGGL((lstm_block_bwd_kernel<BK, true>), dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
+        hipLaunchKernelGGL((lstm_block_bwd_kernel<NBUF, NF, RC>), dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
         persist_chain_after(st);
     }
     persist_prof_report("row-block bwd: wait_h product passA+publish wait_s combine passB arrive_h", 0, a.S, st);
     return last_error();
 }
 inline int launch_block_bwd(const BlockBwd& a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
-    return block_bwd_bk() == 16 ? launch_block_bwd_t<16>(a, part, flags, colacc, st)
-           : block_bwd_bk() == 64 ? launch_block_bwd_t<64>(a, part, flags, colacc, st) : launch_block_bwd_t<32>(a, part, flags, colacc, st);
+#define HPC_RLL_F(NB, NF, RC) launch_block_bwd_t<NB, NF, RC>(a, part, flags, colacc, st)
+    HPC_RLL_BLK_BWD_VARIANTS(HPC_RLL_F)
+#undef HPC_RLL_F
 }
 
 }  // namespace

@@ -12,3 +12,9 @@ def graphed(module, *example_inputs, **kwargs):
     reference's surface for the launch-latency regime (small per-GPU batches under strong scaling)."""
     from .graph import graphed as _graphed
     return _graphed(module, *example_inputs, **kwargs)
+
+
+def graphed_steps(module, step_inputs, **kwargs):
+    """n consecutive steps (micro-batches with their own static buffers) in ONE hipGraph (see ``hpc_rll/graph.py``)."""
+    from .graph import graphed_steps as _graphed_steps
+    return _graphed_steps(module, step_inputs, **kwargs)

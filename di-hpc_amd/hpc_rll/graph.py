@@ -101,3 +101,73 @@ def graphed(module, *example_inputs, grad_outputs: Optional[Sequence[torch.Tenso
         with torch.cuda.graph(g, pool=pool):
             out, grads = fwd_bwd()
     return GraphedStep(g, example_inputs, out, tuple(wrt), tuple(grads), backward)
+
+
+class GraphedSteps:
+    """n forward(+backward) steps -- n micro-batches, each on its OWN static input / upstream-gradient buffers -- captured
+    into ONE hipGraph (:func:`graphed_steps`).  ``outputs[i]`` / ``grads[i]`` are step i's (as in :class:`GraphedStep`);
+    ``wrt[i]`` the tensors its gradients are taken with respect to.  Calling the object replays all n steps with one
+    ``hipGraphLaunch`` and returns ``(outputs, grads)``."""
+
+    def __init__(self, graph, inputs, outputs, wrt, grads):
+        self.graph, self.inputs, self.outputs, self.wrt, self.grads = graph, inputs, outputs, wrt, grads
+        self.steps = len(inputs)
+
+    def replay(self) -> None:
+        self.graph.replay()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.outputs, self.grads
+
+
+def graphed_steps(module, step_inputs: Sequence[Sequence[Any]], grad_outputs: Optional[Sequence[Any]] = None, warmup: int = 3,
+                  pool=None) -> GraphedSteps:
+    """Capture ``len(step_inputs)`` consecutive training steps of ``module`` into ONE hipGraph: step i is
+    ``out_i = module(*step_inputs[i])`` followed by ``autograd.grad(out_i, wrt_i, grad_outputs[i])``, in order, exactly the
+    kernels of i eager steps.  For the launch-latency regime with gradient accumulation over micro-batches (or several
+    rollout shards per optimiser step): the host pays one ``hipGraphLaunch`` per n steps and the GPU-side boundary between
+    two graph launches (a few microseconds, tests/tools/r05_gae_gap_probe.py) once per n steps instead of once per step.
+    Every step has its own static buffers (refill them between replays); ``grad_outputs[i]`` is a tensor or a sequence per
+    differentiable output of step i (default ones)."""
+    n = len(step_inputs)
+    assert n >= 1
+    params = [p for p in module.parameters() if p.requires_grad] if isinstance(module, torch.nn.Module) else []
+    wrts, flat = [], []
+    for args in step_inputs:
+        tens: List[torch.Tensor] = []
+        _tensors_of(args, tens)
+        assert tens and all(t.is_cuda for t in tens), "graphed_steps(): the step inputs must be GPU tensors"
+        wrts.append([t for t in tens if t.requires_grad] + params)
+        flat += tens
+    assert all(wrts), "graphed_steps(): every step needs something that requires grad"
+
+    def all_steps():
+        outs_all, grads_all = [], []
+        for i, args in enumerate(step_inputs):
+            out = module(*args)
+            outs: List[torch.Tensor] = []
+            _tensors_of(out, outs)
+            outs = [o for o in outs if o.requires_grad]
+            assert outs, "graphed_steps(): no output depends on a tensor that requires grad"
+            go = None if grad_outputs is None else grad_outputs[i]
+            if isinstance(go, torch.Tensor):
+                go = [go]
+            gos = list(go) if go is not None else [torch.ones_like(o) for o in outs]
+            assert len(gos) == len(outs)
+            outs_all.append(out)
+            grads_all.append(torch.autograd.grad(outs, wrts[i], gos, allow_unused=True))
+        return outs_all, grads_all
+
+    dev = flat[0].device
+    with torch.cuda.device(dev):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):
+                all_steps()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool):
+            outs_all, grads_all = all_steps()
+    return GraphedSteps(g, list(step_inputs), outs_all, [tuple(w) for w in wrts], [tuple(x) for x in grads_all])
