@@ -504,6 +504,7 @@ struct BlockBwd {
     int skew_ticks;
     u64* prof;
     int xcd_map;                        // the 8-row-block groups of the launch are laid out XCD-major (see the kernel)
+    int abl;                            // TEMPORARY (round-5 ablation, env HPC_RLL_BLK_ABL): bit 0 / 1 = no A / B operand DMA after the first tile (wrong results)
 };
 
 // NBUF = 3 (round 5): the product's LDS-DMA runs TWO k-tiles ahead.  With two buffers the request for tile kt+1 is issued when
@@ -620,8 +621,8 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
                     db.issue(Bs + nb * BK * BN);
                 }
             } else if (kt + 1 < ktiles) {
-                da.issue(As + (buf ^ 1) * BK * BM);
-                db.issue(Bs + (buf ^ 1) * BK * BN);
+                if (!(a.abl & 1)) da.issue(As + (buf ^ 1) * BK * BM);
+                if (!(a.abl & 2)) db.issue(Bs + (buf ^ 1) * BK * BN);
             }
             const float* __restrict__ as = As + buf * BK * BM;
             const float* __restrict__ bs = Bs + buf * BK * BN;
@@ -914,6 +915,7 @@ inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* c
     a.nnt = a.H / 128;
     a.skew_ticks = g_lstm_block_skew * 100;
     a.prof = persist_prof();
+    { const char* e = getenv("HPC_RLL_BLK_ABL"); a.abl = e ? atoi(e) : 0; }
     for (int rb = 0; rb < nrb; rb += per) {
         const int n = nrb - rb < per ? nrb - rb : per;
         a.rb0 = rb;

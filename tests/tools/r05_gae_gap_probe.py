@@ -18,29 +18,43 @@ MODE = os.environ.get("MODE", "time")
 
 
 def gaps(db):
+    import re
     import sqlite3
+    import statistics as st
     con = sqlite3.connect(db)
     tabs = [r[0] for r in con.execute("select name from sqlite_master where type='table' or type='view'")]
     ktab = [t for t in tabs if t == "kernels"] or [t for t in tabs if t.startswith("kernels")]
     rows = con.execute(f"select name, start, end from {ktab[0]} order by start").fetchall()
-    gae = [(n.split("(")[0].split("<")[0].split("::")[-1], s, e) for n, s, e in rows if "gae_" in n and "coef" not in n]
-    print(f"# {len(gae)} GAE kernel launches in {db}")
-    import statistics as st
-    dur = {}
-    gap = {"fwd->bwd": [], "bwd->fwd": []}
-    for i, (n, s, e) in enumerate(gae):
-        dur.setdefault(n, []).append((e - s) / 1e3)
-        if i:
-            pn, ps, pe = gae[i - 1]
-            key = "fwd->bwd" if ("fwd" in pn and "bwd" in n) else "bwd->fwd" if ("bwd" in pn and "fwd" in n) else None
-            if key and (s - pe) < 200e3:
-                gap[key].append((s - pe) / 1e3)
-    for n, d in dur.items():
-        print(f"kernel {n:28s} n={len(d):5d} median {st.median(d):7.2f} us  mean {st.mean(d):7.2f}  min {min(d):7.2f}")
-    for k, g in gap.items():
-        if g:
+
+    def short(n):
+        m = re.search(r"(gae_\w+|\w+_kernel\w*|__amd_rocclr_\w+)", n)
+        return m.group(1) if m else n[:40]
+    ks = [(short(n), s, e) for n, s, e in rows]
+    print(f"# {len(ks)} kernel launches in the trace; by name:", {n: sum(1 for k in ks if k[0] == n) for n in sorted({k[0] for k in ks})})
+    # the three timed loops are separated by synchronisations (idle > 200 us): segment, then per segment durations and gaps
+    seg, segs = [], []
+    for i, k in enumerate(ks):
+        if seg and k[1] - seg[-1][2] > 200e3:
+            segs.append(seg)
+            seg = []
+        seg.append(k)
+    segs.append(seg)
+    for sg in segs:
+        if len(sg) < 100:
+            continue
+        dur, gap = {}, {}
+        for i, (n, s, e) in enumerate(sg):
+            dur.setdefault(n, []).append((e - s) / 1e3)
+            if i:
+                gap.setdefault(sg[i - 1][0][:11] + " -> " + n[:11], []).append((s - sg[i - 1][2]) / 1e3)
+        span = (sg[-1][2] - sg[0][1]) / 1e3
+        nf = sum(1 for k in sg if "fwd" in k[0])
+        print(f"## segment of {len(sg)} launches, {span / max(nf, 1):.2f} us per forward launch (first start .. last end)")
+        for n, d in dur.items():
+            print(f"   kernel {n:26s} n={len(d):5d} median {st.median(d):6.2f} us  mean {st.mean(d):6.2f}  min {min(d):6.2f}")
+        for k, g in gap.items():
             g2 = sorted(g)
-            print(f"gap {k}: n={len(g)} median {st.median(g):6.2f} us  p10 {g2[len(g2) // 10]:6.2f}  p90 {g2[9 * len(g2) // 10]:6.2f}  mean {st.mean(g):6.2f}")
+            print(f"   gap {k:26s} n={len(g):5d} median {st.median(g):6.2f} us  p10 {g2[len(g2) // 10]:6.2f}  p90 {g2[9 * len(g2) // 10]:6.2f}  mean {st.mean(g):6.2f}")
 
 
 if MODE == "gaps":
@@ -98,21 +112,19 @@ def eager():
 
 
 g1 = hpc_rll.graphed(gae, v, r, gamma, lam, grad_outputs=ga)
-multi = {}
+multi, same = {}, {}
 for n in (2, 4, 8):
     sets = [bufs(100 + i) for i in range(n)]
     multi[n] = (hpc_rll.graphed_steps(gae, [(s[0], s[1], gamma, lam) for s in sets], grad_outputs=[s[2] for s in sets]), sets)
+    # the SAME buffers n times (what the eager loops above do as well: every step re-reads the one synthetic batch)
+    same[n] = hpc_rll.graphed_steps(gae, [(v, r, gamma, lam)] * n, grad_outputs=[ga] * n)
 
 if MODE == "trace":
-    for _ in range(300):
-        g1.replay()
-    torch.cuda.synchronize()
-    for _ in range(80):
-        multi[4][0].replay()
-    torch.cuda.synchronize()
-    for _ in range(300):
-        direct()
-    torch.cuda.synchronize()
+    for fn, cnt in ((g1.replay, 300), (same[4].replay, 80), (direct, 300), (eager, 300)):
+        for _ in range(cnt):
+            fn()
+        torch.cuda.synchronize()
+        time.sleep(0.01)
     sys.exit(0)
 
 print(f"# GAE fwd+bwd, T={T} B={B}: microseconds per step (sorted rounds of 300 steps)")
@@ -120,7 +132,9 @@ print("direct C-ABI ops, eager      ", ["%.2f" % t for t in timed(direct, 300)])
 print("module + autograd, eager     ", ["%.2f" % t for t in timed(eager, 300)])
 print("hpc_rll.graphed, 1 step/graph", ["%.2f" % t for t in timed(g1.replay, 300)])
 for n, (gs, _) in multi.items():
-    print(f"graphed_steps, {n} steps/graph  ", ["%.2f" % t for t in timed(gs.replay, 300 // n, per=n)])
+    print(f"graphed_steps, {n} steps/graph, n buffer sets ", ["%.2f" % t for t in timed(gs.replay, 300 // n, per=n)])
+for n, gs in same.items():
+    print(f"graphed_steps, {n} steps/graph, same buffers  ", ["%.2f" % t for t in timed(gs.replay, 300 // n, per=n)])
 # bit-identity of the multi-step graph with the single-step one on the same inputs
 gs, sets = multi[4]
 gs.replay()
