@@ -936,7 +936,7 @@ extern "C" int hpc_rll_tune_set(int key, int value) {
     if (key == 22 && (value == 0 || value == 1)) { hpc_rll::g_split_algo = value; return HPC_RLL_OK; }
     if (key == 23 && value >= 0 && value <= 3) { hpc_rll::g_gemm_exp = value; return HPC_RLL_OK; }
     if (key == 25 && value >= 0 && value <= 2) { hpc_rll::g_gemm_dma = value; return HPC_RLL_OK; }
-    if (key == 26 && value >= 0 && value <= 2047) { hpc_rll::g_lstm_block = value; return HPC_RLL_OK; }
+    if (key == 26 && value >= 0 && value <= 255) { hpc_rll::g_lstm_block = value; return HPC_RLL_OK; }
     if (key == 27 && value >= 0 && value <= 200) { hpc_rll::g_lstm_block_skew = value; return HPC_RLL_OK; }
     if (key == 28 && (value == 0 || value == 1)) { hpc_rll::g_pad_wave = value; return HPC_RLL_OK; }
     if (key == 29 && value >= 0 && value <= 2) { hpc_rll::g_lstm_mid = value; return HPC_RLL_OK; }

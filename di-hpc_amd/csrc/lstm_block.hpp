@@ -504,39 +504,38 @@ struct BlockBwd {
     int skew_ticks;
     u64* prof;
     int xcd_map;                        // the 8-row-block groups of the launch are laid out XCD-major (see the kernel)
-    int abl;                            // TEMPORARY (round-5 ablation, env HPC_RLL_BLK_ABL): bit 0 / 1 = no A / B operand DMA after the first tile (wrong results)
 };
 
-// NBUF = 3 (round 5): the product's LDS-DMA runs TWO k-tiles ahead.  With two buffers the request for tile kt+1 is issued when
-// tile kt starts (one tile = 4096 matrix-pipe cycles = 1.7 us) and waited for with vmcnt(0) at its end; a 128 x 128 tile pulls
-// twice the operand bytes per flop of the forward's 256 x 256 tile and its row block's Wh stream is shared with no other
-// row block of the XCD (they drift tens of microseconds apart: the L2 does not hold a tile that long), so every B chunk is an
-// L2 miss served by the Infinity Cache under ~2 TB/s of such traffic: a 1.7 us lead is not enough.  Three buffers + a
-// COUNTED wait (vmcnt(4): the newest tile's four pieces per thread may stay in flight) + a bare s_barrier (the fence
-// of __syncthreads would drain the DMA) give the stream 3.4 us.
-template <int NBUF> struct BlkBwdCfg {
-    static constexpr int BK = 32, BM = 128, BN = 128, NTH = 512;
+// Round 5 on this kernel (profiles/r05_lstm_block_bwd_ab.json, _phases.txt, _abl.txt; C4, one process, interleaved):
+//   * exchanges WITHOUT cache-wide fences (what the forward's bit 7 does; shipped): the row-sum partials and dHW_s are stored
+//     write-through (sc1); dHW_s lives at addresses written once per launch (ordinary loads / LDS-DMA cannot find a stale copy),
+//     the partials' slots are reused every other step and are read with sc1 loads: wait + arrive phases 17 -> 11 us per step,
+//     backward 135.1 -> 133.9 ms;
+//   * THREE operand buffers with a counted vmcnt and a bare s_barrier (the DMA two k-tiles ahead): product 265 -> 265 us, total
+//     +0.5 ms -- the stream's latency is already covered; what the operand stream costs is its VOLUME: with the A / the B / both
+//     requests removed after the first tile (wrong results) the product phase reads 250 / 246 / 237 us against 259, the whole
+//     backward 133.5 / 131.7 / 130.5 ms -- 237 us is the bare matrix loop of this tile shape (0.94 of the pipe), 22 us per step
+//     are the 4 MB of operands a 128 x 128 tile pulls through L2 per step (twice the forward tile's bytes per flop);
+//   * two-row epilogue chunks in four register sets (three chunks of loads in flight instead of one): 157 spill instructions
+//     inside pass A, pass A 33 -> 96 us; start skew by XCD instead of by row block (the four row blocks of an XCD in step, Wh
+//     tiles shared through its L2): 133.6 against 133.2 ms.  Neither shipped.
+struct BlkBwdCfg {
+    static constexpr int NBUF = 2, BK = 32, BM = 128, BN = 128, NTH = 512;
     static constexpr int tile_floats = NBUF * BK * (BM + BN);   // operand tiles; their first 32 * NTH floats are also the
                                                                 // accumulator dump [32][NTH] of the epilogue
     static_assert(tile_floats >= 32 * NTH, "accumulator dump");
     static constexpr int lds_floats = tile_floats + BM * 4 + BM * 4 + 3 * 4 * BN;   // + stats, sums, column sums
-    static constexpr size_t lds_bytes = NBUF == 3 ? 112 * 1024 : 96 * 1024;   // more than half of the 160 KB: one workgroup per CU
+    static constexpr size_t lds_bytes = 96 * 1024;   // more than half of the 160 KB: one workgroup per CU
     static_assert(lds_floats * sizeof(float) <= lds_bytes, "row-block backward LDS");
 };
 
-// NF: the two exchanges of a step without cache-wide fences (what the forward's bit 7 does): the exchanged data -- the
-// row-sum partials and dHW_s -- are stored write-through (sc1); dHW_s lives at addresses written once per launch (ordinary
-// loads / LDS-DMA cannot find a stale copy), the partials' slots are reused every other step and are read with sc1 loads.
-// RC: rows per load chunk of the two epilogue passes; the passes keep 32 / RC chunks in NS = 8 / RC statically indexed
-// register sets, NS - 1 chunks of loads in flight ahead of the arithmetic (RC = 4: one chunk of four rows ahead, the round-4
-// form; RC = 2: three chunks of two rows ahead -- 6 rows in flight instead of 4 in the same registers).
-template <int NBUF, bool NF, int RC>
+// RC rows per load chunk of the two epilogue passes: 32 / RC chunks in NS = 8 / RC statically indexed register sets, NS - 1
+// chunks of loads in flight ahead of the arithmetic.
 __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a) {
-    typedef BlkBwdCfg<NBUF> C;
-    constexpr int BK = C::BK, BM = C::BM, BN = C::BN, NTH = C::NTH, NQ = BK / 8, NS = 8 / RC, NCH = 32 / RC;
-    constexpr bool FAST = true;
-    constexpr int SC = NF ? 16 : 0;   // sc1 on the exchanged stores / loads
-    static_assert(RC == 2 || RC == 4, "rows per chunk");
+    typedef BlkBwdCfg C;
+    constexpr int NBUF = C::NBUF, RC = 4, BK = C::BK, BM = C::BM, BN = C::BN, NTH = C::NTH, NQ = BK / 8, NS = 8 / RC, NCH = 32 / RC;
+    constexpr bool FAST = true, NF = true;
+    constexpr int SC = 16;   // sc1 (write-through / L1-bypassing) on the exchanged stores and loads
     extern __shared__ __attribute__((aligned(16))) float blk_lds[];
     float* const As = blk_lds;                    // [NBUF][BM rows][BK]
     float* const Bs = As + NBUF * BK * BM;        // [NBUF][BN rows (units)][BK]
@@ -598,31 +597,17 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         DmaStage<BM, BK, NTH> da;
         DmaStage<BN, BK, NTH> db;
-        static_assert(NBUF == 2 || (DmaStage<BM, BK, NTH>::NP + DmaStage<BN, BK, NTH>::NP == 4), "vmcnt(4) below = one tile's pieces per thread");
         da.init(arows, G, 0, 0);
         db.init(a.whp + (size_t)(nt * BN) * G, G, 0, 0);
         da.issue(As);
         db.issue(Bs);
-        if (NBUF == 3) {
-            da.issue(As + BK * BM);     // (ktiles = 4H / 32 >= 96: there always is a second tile)
-            db.issue(Bs + BK * BN);
-            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        int buf = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         for (int kt = 0; kt < ktiles; ++kt) {
-            if (NBUF == 3) {
-                // tile kt + 2 goes where tile kt - 1 was: every wave has passed the barrier that ended tile kt - 1
-                const int nb = buf == 0 ? 2 : buf - 1;
-                if (kt + 2 < ktiles) {
-                    da.issue(As + nb * BK * BM);
-                    db.issue(Bs + nb * BK * BN);
-                }
-            } else if (kt + 1 < ktiles) {
-                if (!(a.abl & 1)) da.issue(As + (buf ^ 1) * BK * BM);
-                if (!(a.abl & 2)) db.issue(Bs + (buf ^ 1) * BK * BN);
+            const int buf = kt & 1;
+            if (kt + 1 < ktiles) {
+                da.issue(As + (buf ^ 1) * BK * BM);
+                db.issue(Bs + (buf ^ 1) * BK * BN);
             }
             const float* __restrict__ as = As + buf * BK * BM;
             const float* __restrict__ bs = Bs + buf * BK * BN;
@@ -637,17 +622,8 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
 #pragma unroll
                     for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
             }
-            if (NBUF == 3) {
-                // this wave's operand reads of tile kt are done (lgkmcnt), its pieces of tile kt + 1 have landed (all but
-                // the newest four requests), then the workgroup meets: no fence, the DMA of tile kt + 2 stays in flight
-                if (kt + 2 < ktiles) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                buf = buf == 2 ? 0 : buf + 1;
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                buf ^= 1;
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
     };
 
@@ -875,47 +851,24 @@ inline int block_bwd_rows_per_launch(int H) {
     return nnt > 0 ? persist_cu_count() / nnt : 0;
 }
 inline size_t block_bwd_part_floats(int B, int H) { return (size_t)(B / 128) * 2 * 4 * (H / 128) * 128 * 4; }
-// hpc_rll_tune_set key 26, bits 8-10 (round 5 experiments on the backward kernel): bit 8 = two operand buffers instead of
-// three, bit 9 = exchanges WITH cache-wide fences, bit 10 = four-row chunks in the epilogue passes
-inline int block_bwd_var() { return (g_lstm_block >> 8) & 7; }
-
-template <int NBUF, bool NF, int RC> inline bool block_bwd_resident(int H) {
+inline bool block_bwd_resident(int H) {
     const int per = block_bwd_rows_per_launch(H);
-    return per >= 1 && persist_resident_t(lstm_block_bwd_kernel<NBUF, NF, RC>, 512, (H / 128) * per, BlkBwdCfg<NBUF>::lds_bytes);
-}
-#define HPC_RLL_BLK_BWD_VARIANTS(F)                                                                                  \
-    switch (block_bwd_var()) {                                                                                     \
-        case 0: return F(3, true, 2);                                                                              \
-        case 1: return F(2, true, 2);                                                                              \
-        case 2: return F(3, false, 2);                                                                             \
-        case 3: return F(2, false, 2);                                                                             \
-        case 4: return F(3, true, 4);                                                                              \
-        case 5: return F(2, true, 4);                                                                              \
-        case 6: return F(3, false, 4);                                                                             \
-        default: return F(2, false, 4);                                                                            \
-    }
-inline bool block_bwd_resident_any(int H) {
-#define HPC_RLL_F(NB, NF, RC) block_bwd_resident<NB, NF, RC>(H)
-    HPC_RLL_BLK_BWD_VARIANTS(HPC_RLL_F)
-#undef HPC_RLL_F
+    return per >= 1 && persist_resident_t(lstm_block_bwd_kernel, 512, (H / 128) * per, BlkBwdCfg::lds_bytes);
 }
 inline bool block_bwd_ok(int B, int H, hipStream_t st) {
     if (!(g_lstm_block & 8) || !g_lstm_persist || !lstm_block_bwd_shape(B, H) || !persist_runtime_ready(st)) return false;
     if (!block_launches_fill(B / 128, block_bwd_rows_per_launch(H), H / 128)) return false;
-    return block_bwd_resident_any(H);
+    return block_bwd_resident(H);
 }
-template <int NBUF, bool NF, int RC>
-inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
-    typedef BlkBwdCfg<NBUF> C;
+inline int launch_block_bwd(BlockBwd a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
+    typedef BlkBwdCfg C;
     const int nrb = a.B / 128, per = block_bwd_rows_per_launch(a.H);
     if (hipMemsetAsync(flags, 0, block_flag_words(a.B) * sizeof(unsigned), st) != hipSuccess) return last_error();
-    const hipError_t e = hipFuncSetAttribute((const void*)lstm_block_bwd_kernel<NBUF, NF, RC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)C::lds_bytes);
+    const hipError_t e = hipFuncSetAttribute((const void*)lstm_block_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
     if (e != hipSuccess) return (int)e;
     a.nnt = a.H / 128;
     a.skew_ticks = g_lstm_block_skew * 100;
     a.prof = persist_prof();
-    { const char* e = getenv("HPC_RLL_BLK_ABL"); a.abl = e ? atoi(e) : 0; }
     for (int rb = 0; rb < nrb; rb += per) {
         const int n = nrb - rb < per ? nrb - rb : per;
         a.rb0 = rb;
@@ -924,16 +877,11 @@ inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* c
         a.colacc = colacc + (size_t)rb * 3 * 4 * a.H;
         a.xcd_map = (n % 8 == 0 && !(g_lstm_block & 64)) ? 1 : 0;
         persist_chain_before(st);
-        hipLaunchKernelGGL((lstm_block_bwd_kernel<NBUF, NF, RC>), dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
+        hipLaunchKernelGGL(lstm_block_bwd_kernel, dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
         persist_chain_after(st);
     }
     persist_prof_report("row-block bwd: wait_h product passA+publish wait_s combine passB arrive_h", 0, a.S, st);
     return last_error();
-}
-inline int launch_block_bwd(const BlockBwd& a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
-#define HPC_RLL_F(NB, NF, RC) launch_block_bwd_t<NB, NF, RC>(a, part, flags, colacc, st)
-    HPC_RLL_BLK_BWD_VARIANTS(HPC_RLL_F)
-#undef HPC_RLL_F
 }
 
 }  // namespace

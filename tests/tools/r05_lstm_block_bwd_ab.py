@@ -3,7 +3,8 @@
 (tune key 26 bits 8-10: two instead of three operand buffers / exchanges with cache-wide fences / four-row epilogue chunks),
 in ONE process, interleaved over rounds.  Backward ms (HIP events), fraction of the fp32 matrix peak, gradient checksums (the
 variants differ in nothing but scheduling: same bits expected).  HPC_RLL_LSTM_PROFILE=1 prints one workgroup's phase times.
-Writes gpurun_out/r05_lstm_block_bwd_ab.json."""
+Writes gpurun_out/r05_lstm_block_bwd_ab.json.
+(the variants were compiled in at commit 9b6d159; only variant 5 = two buffers, fence-free exchanges, four-row chunks is left in the library)"""
 import json
 import os
 import statistics
