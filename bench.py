@@ -20,8 +20,9 @@ What the headline ``value`` is (BASELINE.json metric: "T=1024, B=64k; 1/2/4/8 GP
     launch-latency regime, where the host-side launch path decides -- and which one wins differs from box to box (r03: 35 us
     eager vs 40 us graphed on one, 48 vs 40 on another).  So BOTH are timed in the run (W warmup + K steps each): eager
     ``module(...)`` + ``.backward()``, and ``hpc_rll.graphed`` (forward + backward captured once into a hipGraph, one
-    hipGraphLaunch per step; same kernels, same order, same results); the headline is the faster, named in
-    ``config.launch``, both listed in ``config.launch_modes``.  ``--scaling weak`` / ``--launch eager|graph`` pin a reading.
+    hipGraphLaunch per step; same kernels, same order, same results), and ``hpc_rll.graphed_steps`` (4 steps per hipGraphLaunch:
+    two consecutive graph launches leave the GPU idle for 8.5 us, profiles/r05_gae_gaps.txt); the headline is the fastest,
+    named in ``config.launch``, all listed in ``config.launch_modes``.  ``--scaling weak`` / ``--launch eager|graph|graph4`` pin a reading.
     ``scaling_detail.loss_ops`` times what the GAE headline has none of -- the collective: batch-sharded V-trace + TD-lambda
     at the C3 global shape, each forward ending in its ONE all-reduce (RCCL over xGMI), with the all-reduce's share.
 Whatever the headline is, the same JSON line carries ``scaling_detail`` with BOTH readings, measured in this run after
@@ -45,7 +46,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
                   test_qrdqn_nstep_td_error.py:77, test_ppo.py:79); LSTM S=128,B=4096,H=1024; ScatterConnection (cover, add)
                   B=4096,M=256,N=64,64x64 and the packed Pad1D over 2^20 ragged rows: forward / backward ms and roofline
                   fraction each, with `bound` = "hbm", "mfma" or -- for the instruction-bound quantile / C51 forwards --
-                  "valu" (tests/tools/bench_suite.py holds the byte / flop / instruction models).
+                  "valu" (bench_suite.py, next to this file, holds the byte / flop / instruction models).
 """
 import argparse
 import ctypes
@@ -220,7 +221,7 @@ def main():
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
                     help="headline reading; auto = strong for N > 1 (global B fixed, SURVEY.md 8d), N = 1 is both")
-    ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
+    ap.add_argument("--launch", choices=["auto", "eager", "graph", "graph4"], default="auto",
                     help="headline launch mode; auto = eager for N = 1, hpc_rll.graphed (hipGraph replay) for N > 1")
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--no-scaling-detail", action="store_true", help="skip the extra weak/strong legs (profiler runs)")
@@ -292,8 +293,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    GRAPH_STEPS = 4   # steps per hipGraphLaunch of the "graph4" launch mode (see make_step)
+
     def make_step(Bk, graph):
-        """(step callable, tensors) for one fwd+bwd pass at batch Bk on this rank; graph=True: hpc_rll.graphed."""
+        """(step callable, tensors) for one fwd+bwd pass at batch Bk on this rank; graph=True: hpc_rll.graphed (one
+        hipGraphLaunch per step); graph="graph4": hpc_rll.graphed_steps, GRAPH_STEPS steps -- the same kernels, in the same
+        order, on the same synthetic batch as every other mode -- per hipGraphLaunch.  Why: the kernel trace of the replay loop
+        (profiles/r05_gae_gaps.txt) shows 0.0 us between the two kernels INSIDE a graph launch and 8.5 us of idle GPU between
+        two consecutive graph launches (direct launches: 0.0 us both ways, but the module + autograd host path then costs
+        ~87 us per step); at B = 8192 per rank that gap is a fifth of the 35 us step.  Several steps per launch pay it once.
+        The returned callable runs `n` steps: n // GRAPH_STEPS replays of the multi-step graph, the rest on the one-step one."""
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         value = torch.randn(T + 1, Bk, device=dev, generator=g).requires_grad_(True)
         reward = torch.randn(T, Bk, device=dev, generator=g).requires_grad_(True)
@@ -310,17 +319,34 @@ def main():
             return step, (value, reward, grad_adv)
         # same kernels, same order; only the host-side launch path changes (one hipGraphLaunch per step)
         gs = hpc_rll.graphed(gae, value, reward, gamma, lam, grad_outputs=grad_adv)
-        return gs.replay, (value, reward, grad_adv, gs)
+        if graph != "graph4":
+            return gs.replay, (value, reward, grad_adv, gs)
+        gm = hpc_rll.graphed_steps(gae, [(value, reward, gamma, lam)] * GRAPH_STEPS, grad_outputs=[grad_adv] * GRAPH_STEPS)
+
+        def run_n(n):
+            for _ in range(n // GRAPH_STEPS):
+                gm.replay()
+            for _ in range(n % GRAPH_STEPS):
+                gs.replay()
+        run_n.multi = True          # timed() hands it the step count instead of calling it once per step
+        return run_n, (value, reward, grad_adv, gs, gm)
 
     def timed(step, steps, warmup):
         """W untimed steps, barrier + synchronize, EXACTLY `steps` timed steps, barrier + synchronize.
         Returns (max over ranks, per-rank list) of the elapsed seconds."""
-        for _ in range(warmup):
-            step()
+        multi = getattr(step, "multi", False)
+        if multi:
+            step(warmup)
+        else:
+            for _ in range(warmup):
+                step()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        if multi:
+            step(steps)
+        else:
+            for _ in range(steps):
+                step()
         # closing bracket: this rank's own completion (synchronize), THEN the barrier -- the reported time is the max
         # over ranks of completion times measured from a common start, so a straggler still counts in full, but the
         # latency of the barrier collective itself (tens of us, against K x 40 us at 8 ranks) is not billed to the steps
@@ -346,10 +372,13 @@ def main():
         # item 2a).  Every rank takes the same decision (the times are the max over ranks, gathered).
         launch_modes = {}
         best = None
-        for mode in ("eager", "graph"):
-            st_m, keep_m = make_step(B, mode == "graph")
-            for _ in range(n_pre):
-                st_m()
+        for mode in ("eager", "graph", "graph4"):
+            st_m, keep_m = make_step(B, {"eager": False, "graph": True}.get(mode, mode))
+            if getattr(st_m, "multi", False):
+                st_m(n_pre)
+            else:
+                for _ in range(n_pre):
+                    st_m()
             el_m, per_m = timed(st_m, args.steps, args.warmup)
             launch_modes[mode] = {"ms_per_step": el_m / args.steps * 1e3,
                                   "per_rank_ms_per_step": [p_ / args.steps * 1e3 for p_ in per_m]}
@@ -360,10 +389,13 @@ def main():
         del best
         value, reward, grad_adv = keep[:3]
     else:
-        step, keep = make_step(B, launch == "graph")
+        step, keep = make_step(B, {"eager": False, "graph": True}.get(launch, launch))
         value, reward, grad_adv = keep[:3]
-        for _ in range(n_pre):
-            step()
+        if getattr(step, "multi", False):
+            step(n_pre)
+        else:
+            for _ in range(n_pre):
+                step()
         elapsed, per_rank_s = timed(step, args.steps, args.warmup)
 
     # ---- per-kernel durations, measured IMMEDIATELY after the timed region (same clocks / thermal state), in the same
@@ -419,7 +451,9 @@ def main():
         del keep_alive
         order = sorted(range(rounds), key=lambda i: rs[i][0])
         mx, per = rs[order[rounds // 2]]
-        return {"B_per_gpu": Bk, "global_B": Bk * world, "launch": "hpc_rll.graphed (hipGraph replay)" if graph else "eager",
+        names = {False: "eager", True: "hpc_rll.graphed (hipGraph replay)",
+                 "graph4": f"hpc_rll.graphed_steps (hipGraph replay, {GRAPH_STEPS} steps per launch)"}
+        return {"B_per_gpu": Bk, "global_B": Bk * world, "launch": names[graph],
                 "ms_per_step": mx / steps * 1e3, "value": T * Bk * world * steps / mx,
                 "rounds_ms_per_step": [r[0] / steps * 1e3 for r in rs],
                 "per_rank_ms_per_step": [p / steps * 1e3 for p in per]}
@@ -431,10 +465,21 @@ def main():
                   "weak": {"eager": leg(B_DEFAULT, False), "graph": leg(B_DEFAULT, True)},
                   "strong": None, "strong_per_rank_probe": None}
         if GB % world == 0:
-            detail["strong"] = {"eager": leg(GB // world, False), "graph": leg(GB // world, True)}
+            detail["strong"] = {"eager": leg(GB // world, False), "graph": leg(GB // world, True), "graph4": leg(GB // world, "graph4")}
         if world == 1:   # what one rank of an N-GPU strong-scaling run of global B = 65536 holds, timed on this GPU
-            detail["strong_per_rank_probe"] = {str(n): {"eager": leg(GB // n, False), "graph": leg(GB // n, True)}
-                                               for n in (2, 4, 8)}
+            detail["strong_per_rank_probe"] = {str(n): {"eager": leg(GB // n, False), "graph": leg(GB // n, True),
+                                                        "graph4": leg(GB // n, "graph4")} for n in (2, 4, 8)}
+            #  the strong-scaling factor an N-rank run of the global batch would read if every rank's step
+            # took what ONE GPU measures at B / N here (no collective in the data path; barrier and rank spread not included):
+            # this run's own N = 1 step / the per-rank step, per launch mode; `best` = the mode bench.py --gpus N would lead with
+            base_ms = elapsed / args.steps * 1e3
+            proj = {}
+            for n in (2, 4, 8):
+                modes = {m: base_ms / detail["strong_per_rank_probe"][str(n)][m]["ms_per_step"] for m in ("eager", "graph", "graph4")}
+                modes["best"] = max(modes.values())
+                proj[str(n)] = modes
+            detail["projected_strong_x"] = {"n1_ms_per_step": base_ms, "by_ranks": proj,
+                                            "note": "N = 1 step of this run (B = 65536, eager) / one-GPU step at B = 65536 / N"}
 
     if detail is not None and world > 1:
         detail["loss_ops"] = loss_ops_leg(dev, dist, world, rank, backend, timed)
@@ -487,7 +532,8 @@ def main():
             "config": {"workload": f"GAE fwd+bwd, T={T}, global B={global_B} ({B} per GPU), fp32 (BASELINE.json configs[1])",
                        "T": T, "B_per_gpu": B, "global_B": global_B,
                        "parallelism": f"batch-sharded x{world}, no data-path collective",
-                       "launch": "hpc_rll.graphed (hipGraph replay of the same kernels)" if launch == "graph" else "eager",
+                       "launch": {"graph": "hpc_rll.graphed (hipGraph replay of the same kernels)",
+                                  "graph4": f"hpc_rll.graphed_steps (hipGraph replay of the same kernels, {GRAPH_STEPS} steps per launch)"}.get(launch, "eager"),
                        "launch_modes": launch_modes,
                        "backend": (dist.get_backend() if dist is not None else None)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_launch / t_dom / 1e9, "peak": HBM_PEAK_GBS,
@@ -615,8 +661,7 @@ def loss_ops_leg(dev, dist, world, rank, backend, timed, steps=50, warmup=10):
 
 def run_suite(dev):
     """BASELINE.json configs[2..4] through the drop-in modules (bounded: well under a minute).  The timing harness and
-    the algorithmic byte / flop models are tests/tools/bench_suite.py's (the tool DESIGN.md's tables come from)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    the algorithmic byte / flop models are bench_suite.py's (next to this file; the tool DESIGN.md's tables come from)."""
     import bench_suite as S
     S.QUIET = True
     S.dev = dev

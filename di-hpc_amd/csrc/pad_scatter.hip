@@ -799,7 +799,7 @@ template <bool ADD, bool BUILD>
 __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __restrict__ x,
                                                               const int32_t* __restrict__ idx,
                                                               float* __restrict__ out, int M, int N, int HW, int npb,
-                                                              int order, const int64_t* __restrict__ location, int W) {
+                                                              const int64_t* __restrict__ location, int W) {
     typedef int vint4 __attribute__((ext_vector_type(4)));
     extern __shared__ float s_dyn[];
     const int b = blockIdx.y;
@@ -898,24 +898,63 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
     // (Also tried in round 4, not kept: ONE 4 KiB output block per short-lived 256-thread workgroup with no staging at all --
     // owner quad from L2, owned cells gathered from x 4 bytes at a time -- the shape that fixed the one-hot gradients: 1.47 ms
     // cover / 2.37 ms add against 0.90 / 0.89 here; the staged x tile and owner table are what make this kernel.)
-    // order 0: every wave streams its own contiguous sixteenth of the span (64 KiB-class pieces).  Round-4 experiments
-    // (tests/tools/micro/writebw3.hip: a pure-write stream runs at 6.5 TB/s when the stores a CU has in flight form whole
-    // 4 KiB-aligned blocks, 4.5-5.9 otherwise): order 1 = all 16 waves write ONE contiguous 16 KiB per round, order 2 = only
-    // the first four waves stream, one 4 KiB block per round.
-    long u = u0 + lane, uend = u1;
-    int ustep = 64;
-    if (order == 1) { u = threadIdx.x; uend = units; ustep = 1024; }
-    if (order == 2) {
-        if (wave >= 4) return;
-        u = threadIdx.x; uend = units; ustep = 256;
-    }
+    // Round 5 (tests/tools/micro/scatter_sweep.hip, profiles/r05_scatter_sweep.txt).  The store pattern is NOT the bound: the same
+    // launch shape with nothing but these stores runs at 6.4 TB/s (0.67 ms at C5), with the x tile reads added 6.0-6.4.  In-kernel
+    // clocks: a wave needed 0.43 us per 1 KiB piece (two DEPENDENT LDS round trips -- owner quad, then the gathers -- and ~40
+    // instructions, eight waves per SIMD) against 0.13 us for a store-only wave, and the kernel's time followed the lifetime of
+    // its workgroups (two 1024-thread slots per CU: ~14 us until the staged tile is there, ~14 us of issue, ~14 us until the last
+    // store is acknowledged, per 512 KB), not the memory system's rate.  So the loop is UNROLLED BY FOUR: the owner quads of four
+    // consecutive 1 KiB pieces are read together, `cover` gathers branch-free (an unowned cell reads row 0 and drops it: all
+    // gathers of the four pieces are in flight at once), then four stores: issue 14 -> 6 us per wave, 0.83 -> 0.785 ms at C5.
+    // (Also measured there, not adopted: persistent workgroups with double-buffered staging -- __syncthreads drains the stores --
+    // and with a loader wave + bare s_barrier: 0.767 ms at best, for a second kernel structure; 512-thread workgroups; 16-byte
+    // tile rows; throttled store issue; one 4 KiB / 16 KiB / 64 KiB block per workgroup in sweep order: all slower.)
+    const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    long u = u0 + lane;
     int n = (int)(u / hw4);
     int c4 = (int)(u - (long)n * hw4);                       // float4 index inside the plane
-    const vfloat4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (; u < uend; u += ustep) {
+    constexpr int UNR = 4;
+    if ((hw4 % (64 * UNR)) == 0 && (per % (64 * UNR)) == 0) {   // a wave's four pieces never straddle a plane or its share
+        for (; u < u1; u += 64 * UNR) {
+            int4 f[UNR];
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) f[k] = *reinterpret_cast<const int4*>(s_first + 4 * (c4 + 64 * k));
+            vfloat4 o[UNR];
+            int any = 0;
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) { o[k] = zero4; any |= ~(f[k].x & f[k].y & f[k].z & f[k].w); }
+            if (any < 0) {                                    // some cell of the lane's quads has an owner (owners are >= 0, empty is -1)
+                const float* xn = xs + n;
+#pragma unroll
+                for (int k = 0; k < UNR; ++k) {
+                    const int32_t fi[4] = {f[k].x, f[k].y, f[k].z, f[k].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (ADD) {
+                            float a = 0.f;
+                            if (fi[c] >= 0) {
+                                a = xn[fi[c] * ld];
+                                for (int32_t m = s_next[fi[c]]; m >= 0; m = s_next[m]) a += xn[m * ld];
+                            }
+                            o[k][c] = a;
+                        } else {
+                            const float a = xn[max(fi[c], 0) * ld];
+                            o[k][c] = fi[c] >= 0 ? a : 0.f;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) __builtin_nontemporal_store(o[k], ob + u + 64 * k);
+            c4 += 64 * UNR;
+            if (c4 >= hw4) { c4 -= hw4; ++n; }
+        }
+        return;
+    }
+    for (; u < u1; u += 64) {
         const int4 f = *reinterpret_cast<const int4*>(s_first + 4 * c4);
         vfloat4 o = zero4;
-        if ((f.x & f.y & f.z & f.w) >= 0) {                   // some cell of the quad has an owner (owners are >= 0, empty is -1)
+        if ((f.x & f.y & f.z & f.w) >= 0) {                   // some cell of the quad has an owner
             const int32_t fi[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -929,7 +968,7 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
             }
         }
         __builtin_nontemporal_store(o, ob + u);
-        c4 += ustep;
+        c4 += 64;
         while (c4 >= hw4) { c4 -= hw4; ++n; }
     }
 }
@@ -1503,11 +1542,10 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
                 if (rc) return rc;
             }
             const dim3 grid((N + npb - 1) / npb, B);
-            const int order = g_scatter_lds_fwd >= 3 ? g_scatter_lds_fwd - 2 : 0;
-            if (add && build) hipLaunchKernelGGL((scatter_out_lds_kernel<true, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order, location, W);
-            else if (add) hipLaunchKernelGGL((scatter_out_lds_kernel<true, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order, location, W);
-            else if (build) hipLaunchKernelGGL((scatter_out_lds_kernel<false, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order, location, W);
-            else hipLaunchKernelGGL((scatter_out_lds_kernel<false, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, order, location, W);
+            if (add && build) hipLaunchKernelGGL((scatter_out_lds_kernel<true, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W);
+            else if (add) hipLaunchKernelGGL((scatter_out_lds_kernel<true, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W);
+            else if (build) hipLaunchKernelGGL((scatter_out_lds_kernel<false, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W);
+            else hipLaunchKernelGGL((scatter_out_lds_kernel<false, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W);
             return last_error();
         }
     }

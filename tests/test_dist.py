@@ -406,9 +406,9 @@ def _check_bench_line(d, scaling, launch_word, B_per_gpu):
         assert launch_word in d["config"]["launch"] and d["config"]["launch_modes"] is None
     else:      # auto for N > 1: both host launch paths timed in the run, the faster one leads
         lm = d["config"]["launch_modes"]
-        assert set(lm) == {"eager", "graph"} and all(len(v["per_rank_ms_per_step"]) == 2 for v in lm.values())
+        assert set(lm) == {"eager", "graph", "graph4"} and all(len(v["per_rank_ms_per_step"]) == 2 for v in lm.values())
         fastest = min(lm, key=lambda k: lm[k]["ms_per_step"])
-        assert ("graphed" if fastest == "graph" else "eager") in d["config"]["launch"]
+        assert {"graph": "hpc_rll.graphed (", "graph4": "hpc_rll.graphed_steps ("}.get(fastest, "eager") in d["config"]["launch"]
         assert abs(d["ms_per_step"] - lm[fastest]["ms_per_step"]) < 1e-9
     assert len(d["per_rank_ms_per_step"]) == 2 and d["cpu_baseline"] is None and d["suite"] is None
     assert abs(d["value"] - 1024 * 2 * B_per_gpu / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]

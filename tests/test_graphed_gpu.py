@@ -114,3 +114,50 @@ def test_graphed_ppo_with_device_side_monitors():
     assert all(torch.equal(a, b.detach()) for a, b in zip(loss, ref_loss))
     assert info.approx_kl.item() == ref_info.approx_kl and info.clipfrac.item() == ref_info.clipfrac
     assert torch.equal(dln, ln.grad) and torch.equal(dvn, vn.grad)
+
+
+def test_graphed_steps_micro_batches_in_one_graph():
+    """hpc_rll.graphed_steps: n steps -- micro-batches with their own static buffers, or the same batch n times -- captured
+    into ONE hipGraph (one hipGraphLaunch, and one 8.5 us gap between graph launches, per n steps: profiles/r05_gae_gaps.txt).
+    Every step's outputs and gradients equal the eager ones bit for bit and follow in-place updates of its buffers; a module
+    with parameters (TD-lambda has none, so V-trace's logits stand in as `wrt` tensors) works the same."""
+    import hpc_rll
+    from hpc_rll.rl_utils.gae import GAE
+    from hpc_rll.rl_utils.td import TDLambda
+    g = torch.Generator(device=DEV).manual_seed(11)
+    T, B, n = 256, 1024, 3
+    m = GAE(T, B)
+    sets = [(_randn(g, T + 1, B).requires_grad_(True), _randn(g, T, B).requires_grad_(True), _randn(g, T, B)) for _ in range(n)]
+    steps = hpc_rll.graphed_steps(m, [(v, r, 0.99, 0.97) for v, r, _ in sets], grad_outputs=[ga for _, _, ga in sets])
+    assert steps.steps == n and all(steps.wrt[i][0] is sets[i][0] for i in range(n))
+    for trial in range(2):
+        with torch.no_grad():
+            for v, r, ga in sets:
+                v.copy_(_randn(g, T + 1, B))
+                r.copy_(_randn(g, T, B))
+                ga.copy_(_randn(g, T, B))
+        outs, grads = steps()
+        for i, (v, r, ga) in enumerate(sets):
+            v2, r2 = v.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)
+            ref = m(v2, r2, 0.99, 0.97)
+            ref.backward(ga)
+            assert torch.equal(outs[i], ref.detach()) and torch.equal(grads[i][0], v2.grad) and torch.equal(grads[i][1], r2.grad), (trial, i)
+    # the same batch twice (what bench.py's graph4 launch mode replays): both steps give the eager result
+    v, r, ga = sets[0]
+    two = hpc_rll.graphed_steps(m, [(v, r, 0.99, 0.97)] * 2, grad_outputs=[ga] * 2)
+    outs, grads = two()
+    ref = m(v, r, 0.99, 0.97)
+    gv, gr = torch.autograd.grad(ref, (v, r), ga)
+    for i in range(2):
+        assert torch.equal(outs[i], ref.detach()) and torch.equal(grads[i][0], gv) and torch.equal(grads[i][1], gr)
+    # a scalar loss with default grad_outputs (ones)
+    tl = TDLambda(T, B)
+    vs = [_randn(g, T + 1, B).requires_grad_(True) for _ in range(2)]
+    rw, w = _randn(g, T, B), torch.rand(T, B, device=DEV, generator=g)
+    st = hpc_rll.graphed_steps(tl, [(x, rw, w, 0.9, 0.8) for x in vs])
+    outs, grads = st()
+    for i, x in enumerate(vs):
+        x2 = x.detach().clone().requires_grad_(True)
+        loss = tl(x2, rw, w, 0.9, 0.8)
+        loss.backward()
+        assert torch.equal(outs[i], loss.detach()) and torch.equal(grads[i][0], x2.grad)
