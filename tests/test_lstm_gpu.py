@@ -945,7 +945,7 @@ import torch
 import hpc_torch_utils_network as NW
 from hpc_rll.torch_utils.network.rnn import LSTM
 dev = torch.device("cuda:0")
-S, B, I, H = 6, 16, 32, 1024                # mid-batch persistent kernel (path 5): 128 workgroups with 64 KB of Wh each
+S, B, I, H = 6, 16, 32, 256                 # mid-batch persistent kernel (path 5): 128 workgroups of 512 threads, 16 KB of Wh each
 torch.manual_seed(0)
 m = LSTM(S, B, I, H, 1, check_persistent=True).to(dev)
 x = torch.randn(S, B, I, device=dev)
@@ -956,7 +956,9 @@ assert NW.lstm_last_forward_path() == 5 and NW.async_error() == 0
 NW._test_set_persist_spin_limit(2048, dev)
 side = torch.cuda.Stream()
 with torch.cuda.stream(side):
-    NW._test_occupy_device(1500, dev, 508)    # 508 of the 512 half-CU slots held for 1.5 s: two CUs left for 128 workgroups
+    NW._test_occupy_device(1500, dev, 480)    # 480 of the 512 half-CU slots held for 1.5 s: room for about half of the workgroups
+    # (a shape whose workgroups need more than half a CU's LDS -- H = 1024 -- finds NO slot here: the launch then simply waits for
+    # the other process, no workgroup runs, nothing times out)
 with warnings.catch_warnings(record=True) as caught, torch.no_grad():
     warnings.simplefilter("always")
     chk, _ = m(x, None)                     # starved INSIDE a check_persistent module: detected and recomputed before it returns
