@@ -284,7 +284,10 @@ struct ScanCfg { int v, lc, nw, sub; };
 
 // V=1 or 2 (the fat rows of V-trace/UPGO do not fit V=4), LC = 8, NW up to 16 for small B.
 extern int g_scan_wave_target;   // hpc_rll_tune_set key 19: waves a scan launch aims for (fills NW up to 16)
-inline ScanCfg scan_cfg(int T, int B, bool can_v2) {
+// lc16 (round 5, TD-lambda only: its row payload is four values): SIXTEEN steps per wave where the 8-step form would walk a
+// one-workgroup-per-CU grid through two or more dependent iterations (load round trip -> chunk heads through LDS -> barrier ->
+// stores, each ~3 us): T = 256 at B = 16384 becomes ONE iteration of 16 waves x 16 steps.
+inline ScanCfg scan_cfg(int T, int B, bool can_v2, bool lc16 = false) {
     ScanCfg c;
     c.v = (can_v2 && (B + 127) / 128 >= 512) ? 2 : 1;
     c.lc = 8;
@@ -298,6 +301,7 @@ inline ScanCfg scan_cfg(int T, int B, bool can_v2) {
     c.sub = 1;
     if (c.v == 1 && c.nw == 16)
         while (c.sub < 8 && (long)wgs * c.sub < 256 && chunks >= 2 * c.nw * c.sub) c.sub <<= 1;
+    if (lc16 && c.v == 1 && c.sub == 1 && c.nw == 16 && wgs <= 512 && T > c.nw * c.lc) c.lc = 16;
     return c;
 }
 inline unsigned scan_grid(const ScanCfg& c, int B) {
@@ -305,10 +309,16 @@ inline unsigned scan_grid(const ScanCfg& c, int B) {
     return (unsigned)((B + tile - 1) / tile);
 }
 
-template <class Op, bool ALLOW_V2 = true>
+template <class Op, bool ALLOW_V2 = true, bool ALLOW_LC16 = false>
 inline void launch_colscan(const Op& op, const ScanCfg& c, int T, int B, float* partials, hipStream_t st,
                            const ScanFold& fold = ScanFold{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}}) {
     const unsigned grid = scan_grid(c, B);
+    if constexpr (ALLOW_LC16) {
+        if (c.lc == 16 && c.v == 1 && c.nw == 16 && c.sub == 1) {
+            hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 16, 16>), dim3(grid), dim3(1024), 0, st, op, T, B, partials, fold);
+            return;
+        }
+    }
     if (c.sub == 2 && c.v == 1 && c.nw == 16) {
         hipLaunchKernelGGL((colscan_rev_kernel<Op, 1, 8, 16, 2>), dim3(grid), dim3(1024), 0, st, op, T, B, partials, fold);
         return;

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const int32_t* __restri
     table[(size_t)threadIdx.x * nchunks + blockIdx.x] = s_h[threadIdx.x];   // digit-major: the scan order of a stable sort
 }
 
-// exclusive scan of m int32 entries in place, one workgroup
+// exclusive scan of m int32 entries in place, one workgroup (the tile sums of the three-phase scan below; small m)
 __global__ __launch_bounds__(1024) void scan_i32_kernel(int32_t* __restrict__ a, long m) {
     __shared__ int64_t s_part[1024];
     const int t = threadIdx.x;
@@ -249,6 +249,73 @@ __global__ __launch_bounds__(1024) void scan_i32_kernel(int32_t* __restrict__ a,
     __syncthreads();
     int64_t run = s_part[t];
     for (long i = lo; i < hi; ++i) { const int32_t v = a[i]; a[i] = (int32_t)run; run += v; }
+}
+
+// Round 5: the digit table of a radix pass (256 x n / 1024 counters: 1 MB at 2^20 rows) used to be scanned by the ONE workgroup
+// above, every thread walking 256 consecutive counters (a wave touches 64 lines per step): 0.42 ms of the 1.07 ms the grouped
+// pad of 2^20 rows took (rocprofv3, tests/tools/r05_group_pad_profile.sh).  Now three phases over tiles of kScanTile counters:
+// tile sums (one workgroup per tile, 16 consecutive counters per thread: whole lines per wave), the one-workgroup scan of the
+// tile sums, tile rescan with its offset.  Integer arithmetic: the same result, whatever the order.
+constexpr int kScanTile = 4096;
+__device__ __forceinline__ int32_t tile_thread_load(const int32_t* __restrict__ a, long m, long i0, int32_t (&v)[16]) {
+    typedef int vint4 __attribute__((ext_vector_type(4)));
+    int32_t s = 0;
+    if (i0 + 16 <= m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const vint4 x = reinterpret_cast<const vint4*>(a + i0)[q];
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = i0 + k < m ? a[i0 + k] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+    return s;
+}
+__global__ __launch_bounds__(256) void scan_tile_sums_kernel(const int32_t* __restrict__ a, long m, int32_t* __restrict__ sums) {
+    __shared__ int32_t s_w[4];
+    int32_t v[16];
+    int32_t s = tile_thread_load(a, m, (long)blockIdx.x * kScanTile + 16L * threadIdx.x, v);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(256) void scan_tile_apply_kernel(int32_t* __restrict__ a, long m, const int32_t* __restrict__ sums) {
+    __shared__ int32_t s_w[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long i0 = (long)blockIdx.x * kScanTile + 16L * threadIdx.x;
+    int32_t v[16];
+    const int32_t mine = tile_thread_load(a, m, i0, v);
+    int32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int32_t run = sums[blockIdx.x] + incl - mine;
+    for (int u = 0; u < w; ++u) run += s_w[u];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (i0 + k < m) a[i0 + k] = run;
+        run += v[k];
+    }
+}
+// the launches (tile_sums: ceil(m / kScanTile) int32 of scratch)
+inline void scan_i32(int32_t* a, long m, int32_t* tile_sums, hipStream_t st) {
+    const long nt = (m + kScanTile - 1) / kScanTile;
+    if (nt <= 1) {
+        hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, a, m);
+        return;
+    }
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)nt), dim3(256), 0, st, (const int32_t*)a, m, tile_sums);
+    hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, tile_sums, nt);
+    hipLaunchKernelGGL(scan_tile_apply_kernel, dim3((unsigned)nt), dim3(256), 0, st, a, m, (const int32_t*)tile_sums);
 }
 
 // scatter of one pass.  Row e of a chunk sits in slot s = e / 256 (thread t = e % 256): slots are processed in order,
@@ -293,9 +360,13 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------ 4. all groups, one launch
-// One wave per sorted row p: the row's group, source row and length are wave-uniform (scalar loads), the lanes copy /
-// fill the row's `width` columns; consecutive rows of a group are consecutive in the output, so the workgroups write
-// contiguous spans.  table: rows {pointer, 1, 1, length} of hpc_rll_packed_table.  No division per element.
+// One wave per sorted row p (rows dealt round robin over the waves: neighbouring waves write neighbouring rows at the same
+// time): the row's group, source row and length are wave-uniform, the lanes copy / fill the row's `width` columns; consecutive
+// rows of a group are consecutive in the output.  table: rows {pointer, 1, 1, length} of hpc_rll_packed_table.
+// Round 5: the metadata of the wave's NEXT row (order[p'] -> table row: two dependent round trips) is requested before the
+// current row is copied, so a row costs one exposed round trip (its data) instead of three.  (Also tried: 64 consecutive rows
+// per wave with the metadata fetched per lane and four rows copied at a time -- 0.52 against 0.40 ms: the round-robin order is
+// what keeps the partial lines at the row boundaries of neighbouring rows together in time.)
 template <int G_MAX>
 __global__ __launch_bounds__(256) void pad_groups_kernel(const int64_t* __restrict__ table, const int64_t* __restrict__ order,
                                                          const int64_t* __restrict__ plan, int G, float* __restrict__ out,
@@ -314,20 +385,33 @@ __global__ __launch_bounds__(256) void pad_groups_kernel(const int64_t* __restri
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     int g = 0;
-    for (int64_t p = wave; p < n; p += nwaves) {
+    int64_t p = wave;
+    if (p >= n) return;
+    const int64_t* tr = table + order[p] * 4;
+    const float* sp = reinterpret_cast<const float*>(tr[0]);
+    int len = (int)tr[3];
+    while (true) {
+        const int64_t pn = p + nwaves;
+        const float* spn = nullptr;
+        int lenn = 0;
+        if (pn < n) {                                          // the next row's metadata: in flight during this row's copy
+            const int64_t* trn = table + order[pn] * 4;
+            spn = reinterpret_cast<const float*>(trn[0]);
+            lenn = (int)trn[3];
+        }
         while (g + 1 < ng && p >= s_pos[g + 1]) ++g;       // rows only move forward: amortised O(1)
         const int wdt = s_w[g];
         const int64_t base = s_off[g] + (p - s_pos[g]) * (int64_t)wdt;
-        const int64_t src = order[p];
-        const int64_t* tr = table + src * 4;
-        const float* sp = reinterpret_cast<const float*>(tr[0]);
-        const int len = (int)tr[3];
         for (int c = lane; c < wdt; c += 64) {
             const bool in = c < len;
             const float x = in ? sp[c] : value;
             __builtin_nontemporal_store(x, out + base + c);
             __builtin_nontemporal_store(in ? 1 : 0, mask + base + c);
         }
+        if (pn >= n) break;
+        p = pn;
+        sp = spn;
+        len = lenn;
     }
 }
 
@@ -345,7 +429,8 @@ extern "C" int64_t hpc_rll_pad1d_group_workspace_int64(int64_t n, int max_len, i
     const int64_t dp = bins + (bins + 1) + 2 * (bins + 1) + ((int64_t)(group + 1) * (bins + 1) + 1) / 2;
     const int64_t radix = (256 * (nchunks > 0 ? nchunks : 1) + 1) / 2;
     const int64_t keys = 2 * ((n + 1) / 2);
-    return hist + dp + radix + keys + n + 8;
+    const int64_t tiles = ((256 * (nchunks > 0 ? nchunks : 1) + kScanTile - 1) / kScanTile + 1) / 2;   // tile sums of the digit-table scan
+    return hist + dp + radix + keys + n + tiles + 8;
 }
 
 extern "C" int hpc_rll_pad1d_group_plan(const int64_t* lengths, int64_t n, int max_len, int group, int mode, uint64_t seed,
@@ -363,6 +448,7 @@ extern "C" int hpc_rll_pad1d_group_plan(const int64_t* lengths, int64_t n, int m
     int32_t* keys_a = table + 2 * ((256 * (int64_t)(nchunks > 0 ? nchunks : 1) + 1) / 2);
     int32_t* keys_b = keys_a + 2 * ((n + 1) / 2);
     int64_t* idx_tmp = reinterpret_cast<int64_t*>(keys_b + 2 * ((n + 1) / 2));
+    int32_t* tile_sums = reinterpret_cast<int32_t*>(idx_tmp + n);
     hipError_t e = hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)bins, st);
     if (e == hipSuccess) e = hipMemsetAsync(plan, 0, sizeof(int64_t) * (size_t)(3 * group + 4), st);
     if (e != hipSuccess) return (int)e;
@@ -380,7 +466,7 @@ extern "C" int hpc_rll_pad1d_group_plan(const int64_t* lengths, int64_t n, int m
         const int shift = 8 * p;
         const bool last = p == passes - 1;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nchunks), dim3(256), 0, st, kin, (long)n, shift, table, nchunks);
-        hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, table, (long)256 * nchunks);
+        scan_i32(table, (long)256 * nchunks, tile_sums, st);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nchunks), dim3(256), 0, st, kin, p == 0 ? (const int64_t*)nullptr : idx_tmp,
                            kout, last ? order : idx_tmp, (long)n, shift, table, nchunks);
         const int32_t* tmp = kin;

@@ -92,11 +92,11 @@ inline unsigned* scan_ticket(hipStream_t st, unsigned** sub = nullptr) {
     return dv.base + idx;
 }
 // scan launch + finalisation of its NACC sums into `out` (x scale[k]): one launch when a ticket is available
-template <class Op, bool ALLOW_V2>
+template <class Op, bool ALLOW_V2, bool ALLOW_LC16 = false>
 inline int scan_and_finalize(const Op& op, const ScanCfg& c, int T, int B, float* partials, int nacc, const float* scale,
                              float* out, hipStream_t st) {
     const ScanFold fold = make_fold(st, nacc, scale, out, (long)scan_grid(c, B));
-    launch_colscan<Op, ALLOW_V2>(op, c, T, B, partials, st, fold);
+    launch_colscan<Op, ALLOW_V2, ALLOW_LC16>(op, c, T, B, partials, st, fold);
     const int rc = last_error();
     if (rc || fold.out) return rc;
     return finalize_sums(partials, (int)scan_grid(c, B), nacc, scale, out, st);
@@ -309,12 +309,12 @@ extern "C" int hpc_rll_td_lambda_forward(const float* value, const float* reward
     if (T == 0 || B == 0) return (int)hipMemsetAsync(loss, 0, sizeof(float), st);
     if (!value || !reward || !grad_buf || !partials || (weight_mode != 0 && !weight)) return HPC_RLL_EINVAL;
     const bool v2 = (B % 2 == 0) && al8(value) && al8(reward) && al8(weight) && al8(grad_buf);
-    const ScanCfg c = scan_cfg(T, B, v2);
+    const ScanCfg c = scan_cfg(T, B, v2, true);
     // oracle arithmetic (origin/td.py:239-243): discounts = gamma*lambda ; (gammas - discounts) * V_{t+1}
     const float disc = gamma * lambda;
     TdLambdaOp op{value, reward, weight, weight_mode, grad_buf, T, B, disc, gamma - disc, scale};
     const float sc = 0.5f * scale;
-    return scan_and_finalize<TdLambdaOp, true>(op, c, T, B, partials, 1, &sc, loss, st);
+    return scan_and_finalize<TdLambdaOp, true, true>(op, c, T, B, partials, 1, &sc, loss, st);
 }
 
 extern "C" int hpc_rll_td_lambda_backward(const float* grad_loss, const float* grad_buf, float* grad_value, int T,
