@@ -741,12 +741,12 @@ __global__ __launch_bounds__(256) void categorical_bwd_long_kernel(const float* 
 }
 
 }  // namespace
-int g_blocks_per_cu = 1024;  // tuning knob (hpc_rll_tune_set key 0): cap of the row kernels' grids, in workgroups per CU.  Rounds 1-3 shipped 24 (resident
+constexpr int g_blocks_per_cu = 1024;  // cap of the row kernels' grids, in workgroups per CU.  Rounds 1-3 shipped 24 (resident
 // workgroups looping over ~20 slices of the rows: "12: 364 / 736 us, 24: 335 / 724").  Round 4 (profiles/r04_writebw.txt: a stream of
 // short-lived workgroups that each write one aligned block beats long-lived ones) lifted the cap -- at the C3 shape every workgroup
 // now takes ONE slice of 32 rows and retires: V-trace 0.755 / 0.784 -> 0.72 / 0.68 ms, UPGO 0.366 / 0.736 -> 0.323 / 0.680
 // (24 -> 64 -> 256 -> 1024 workgroups per CU: backward 0.784, 0.714, 0.686, 0.678 ms)
-namespace {  // tuning knob (hpc_rll_tune_set key 0)
+namespace {
 inline unsigned grid_for(long rows, int rows_per_block) {
     long g = (rows + rows_per_block - 1) / rows_per_block;
     const long cap = 256L * g_blocks_per_cu;  // 256 CUs x workgroups per CU (above it the workgroups loop)
@@ -811,7 +811,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
     if (cfg.g == G_ && cfg.vec == V_ && cfg.e == E_) {                                                                    \
         const long per = (256 / G_) * 4;                                                                                  \
         long grid = (rows + per - 1) / per;                                                                               \
-        const long gmax = g_ppo_fused == 1 ? kFoldMaxGrid : g_ppo_fused == 2 ? 2048 : 4096;                               \
+        const long gmax = kFoldMaxGrid;   /* (2048 / 4096 workgroups + a finalize launch: slower, round 4) */             \
         if (grid > gmax) grid = gmax;                                                                                     \
         const ScanFold fold = make_fold(st, PpoOp::NACC, scales, out5, grid);                                             \
         hipLaunchKernelGGL((ppo_fwd_fused_kernel<G_, V_, E_>), dim3((unsigned)grid), dim3(256), 0, st, logits_new,        \
@@ -824,7 +824,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
-int g_ppo_fused = 1;   // hpc_rll_tune_set key 32: 0 off; 1 = at most 512 workgroups, sums folded in the launch; 2 / 3 = at most 2048 / 4096 workgroups + a finalize launch
+int g_ppo_fused = 1;   // hpc_rll_tune_set key 32: PPO forward in ONE launch (at most 512 workgroups, sums folded in the launch); 0 = three launches
 
 // Rows of at most 16 pieces per lane group (N <= 512 with 16-byte loads): the configurations of the row kernels that keep a
 // row in one DPP row.  Anything else: false, the caller runs the three launches.
@@ -908,51 +908,6 @@ int categorical_backward(const float* logits, const int64_t* action, const float
 }
 
 }  // namespace hpc_rll
-
-namespace hpc_rll { extern int g_gemm_bk; extern int g_scatter_threads; extern int g_lstm_persist; extern int g_lstm_xchg_rep; extern int g_lstm_jw; extern int g_gemm_big_target; extern int g_gemm_big_tile128; extern int g_lstm_wave; extern int g_scatter_bwd_lds_kb; extern int g_gemm_xcd; extern int g_lstm_nn_bwd; extern int g_lstm_dh_big; extern int g_gemm_lat_target; extern int g_gemm_thr_ktiles; extern int g_cell_vec4; extern int g_gemm_tile256; extern int g_scatter_lds_fwd; extern int g_scatter_npb; extern int g_scan_wave_target; extern int g_cell_rows_wgs; extern int g_scan_fold; extern int g_split_algo; extern int g_gemm_exp; extern int g_sample_batch; extern int g_gemm_dma; extern int g_lstm_block; extern int g_lstm_block_skew; extern int g_pad_wave; extern int g_lstm_mid; extern int g_lstm_mid_rep; extern int g_onehot_fill_mb; extern int g_ppo_fused; extern int g_lstm_mid_bwd; extern int g_scatter_bwd_stream; extern int g_onehot_qpw; extern int g_lstm_poll_nap; extern int g_scatter_build; extern int g_scatter_bwd_xcd; extern int g_lstm_mid_xcd; }
-extern "C" int hpc_rll_tune_set(int key, int value) {
-    if (key == 0 && value >= 1 && value <= 1024) { hpc_rll::g_blocks_per_cu = value; return HPC_RLL_OK; }
-    if (key == 1 && (value == 0 || value == 16 || value == 32)) { hpc_rll::g_gemm_bk = value; return HPC_RLL_OK; }
-    if (key == 2 && (value == 256 || value == 512 || value == 1024)) { hpc_rll::g_scatter_threads = value; return HPC_RLL_OK; }
-    if (key == 3 && (value == 0 || value == 1)) { hpc_rll::g_lstm_persist = value; return HPC_RLL_OK; }
-    if (key == 4 && value >= 1 && value <= 32) { hpc_rll::g_lstm_xchg_rep = value; return HPC_RLL_OK; }
-    if (key == 5 && (value == 0 || value == 2 || value == 4)) { hpc_rll::g_lstm_jw = value; return HPC_RLL_OK; }
-    if (key == 6 && value >= 1 && value <= 4096) { hpc_rll::g_gemm_big_target = value; return HPC_RLL_OK; }
-    if (key == 7 && (value == 0 || value == 1)) { hpc_rll::g_gemm_big_tile128 = value; return HPC_RLL_OK; }
-    if (key == 8 && (value == 0 || value == 1)) { hpc_rll::g_lstm_wave = value; return HPC_RLL_OK; }
-    if (key == 9 && value >= 16 && value <= 128) { hpc_rll::g_scatter_bwd_lds_kb = value; return HPC_RLL_OK; }
-    if (key == 10 && (value == 0 || value == 1)) { hpc_rll::g_gemm_xcd = value; return HPC_RLL_OK; }
-    if (key == 11 && (value == 0 || value == 1)) { hpc_rll::g_lstm_nn_bwd = value; return HPC_RLL_OK; }
-    if (key == 12 && (value == 0 || value == 1)) { hpc_rll::g_lstm_dh_big = value; return HPC_RLL_OK; }
-    if (key == 13 && value >= 16 && value <= 2048) { hpc_rll::g_gemm_lat_target = value; return HPC_RLL_OK; }
-    if (key == 14 && value >= 1 && value <= 64) { hpc_rll::g_gemm_thr_ktiles = value; return HPC_RLL_OK; }
-    if (key == 15 && value >= 0 && value <= 8) { hpc_rll::g_cell_vec4 = value; return HPC_RLL_OK; }
-    if (key == 16 && (value == 0 || value == 1)) { hpc_rll::g_gemm_tile256 = value; return HPC_RLL_OK; }
-    if (key == 17 && value >= 0 && value <= 4) { hpc_rll::g_scatter_lds_fwd = value; return HPC_RLL_OK; }
-    if (key == 18 && (value == 0 || (value >= 4 && value <= 64 && value % 4 == 0))) { hpc_rll::g_scatter_npb = value; return HPC_RLL_OK; }
-    if (key == 19 && value >= 256 && value <= 16384) { hpc_rll::g_scan_wave_target = value; return HPC_RLL_OK; }
-    if (key == 20 && (value == 0 || (value >= 64 && value <= 1024))) { hpc_rll::g_cell_rows_wgs = value; return HPC_RLL_OK; }
-    if (key == 21 && value >= 0 && value <= 2) { hpc_rll::g_scan_fold = value; return HPC_RLL_OK; }
-    if (key == 22 && (value == 0 || value == 1)) { hpc_rll::g_split_algo = value; return HPC_RLL_OK; }
-    if (key == 23 && value >= 0 && value <= 3) { hpc_rll::g_gemm_exp = value; return HPC_RLL_OK; }
-    if (key == 25 && value >= 0 && value <= 2) { hpc_rll::g_gemm_dma = value; return HPC_RLL_OK; }
-    if (key == 26 && value >= 0 && value <= 255) { hpc_rll::g_lstm_block = value; return HPC_RLL_OK; }
-    if (key == 27 && value >= 0 && value <= 200) { hpc_rll::g_lstm_block_skew = value; return HPC_RLL_OK; }
-    if (key == 28 && (value == 0 || value == 1)) { hpc_rll::g_pad_wave = value; return HPC_RLL_OK; }
-    if (key == 29 && value >= 0 && value <= 2) { hpc_rll::g_lstm_mid = value; return HPC_RLL_OK; }
-    if (key == 30 && value >= 1 && value <= 32) { hpc_rll::g_lstm_mid_rep = value; return HPC_RLL_OK; }
-    if (key == 31 && value >= 0 && value <= 65536) { hpc_rll::g_onehot_fill_mb = value; return HPC_RLL_OK; }
-    if (key == 32 && value >= 0 && value <= 3) { hpc_rll::g_ppo_fused = value; return HPC_RLL_OK; }
-    if (key == 33 && value >= 0 && value <= 2) { hpc_rll::g_lstm_mid_bwd = value; return HPC_RLL_OK; }
-    if (key == 34 && (value == 0 || value == 1)) { hpc_rll::g_scatter_bwd_stream = value; return HPC_RLL_OK; }
-    if (key == 35 && (value == 0 || (value >= 256 && value <= 8192))) { hpc_rll::g_onehot_qpw = value; return HPC_RLL_OK; }
-    if (key == 36 && value >= 1 && value <= 8) { hpc_rll::g_lstm_poll_nap = value; return HPC_RLL_OK; }
-    if (key == 37 && value >= 0 && value <= 3) { hpc_rll::g_scatter_build = value; return HPC_RLL_OK; }
-    if (key == 38 && value >= 0 && value <= 2) { hpc_rll::g_scatter_bwd_xcd = value; return HPC_RLL_OK; }
-    if (key == 39 && (value == 0 || value == 1)) { hpc_rll::g_lstm_mid_xcd = value; return HPC_RLL_OK; }
-    if (key == 24 && (value == 0 || value == 1 || value == 8 || value == 16 || value == 32 || value == 64)) { hpc_rll::g_sample_batch = value; return HPC_RLL_OK; }
-    return HPC_RLL_EINVAL;
-}
 
 extern "C" int hpc_rll_categorical_forward(const float* logits, const int64_t* action, float* logp, float* entropy,
                                            int64_t rows, int N, void* stream) {

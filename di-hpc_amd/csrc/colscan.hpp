@@ -51,18 +51,14 @@ namespace hpc_rll {
 // tiling is ONE workgroup walking 8 barriers.
 // Where the last workgroup leaves the NACC sums (x scale[k]); out == nullptr: partials only (the caller finalises).
 // `ticket` is zero before the launch and is left at zero by it.
-// `sub` (round 4, grids above kFoldMaxGrid): kFoldSub arrival counters, one per 128-byte line, zero before and after a launch --
-// workgroup b arrives at counter b % kFoldSub, the last arrival of a counter arrives at `ticket`, the last of THOSE folds.
-struct ScanFold { float* out; unsigned* ticket; float scale[8]; unsigned* sub; };
-constexpr int kFoldSub = 16;
-constexpr long kFoldMaxGridTree = 32768;   // above: partials + the finalize launch
+struct ScanFold { float* out; unsigned* ticket; float scale[8]; };
 
 // scan_ops.hip: the fold of a launch on `st` (its ticket, see there), or a partials-only fold when none is available
 // `grid`: workgroups of the launch.  Above kFoldMaxGrid the fold is NOT used (partials only, the caller runs the separate
 // finalize launch): every workgroup takes the ticket with an agent-scope atomic on ONE address, and those serialise at
 // ~12 ns each on this part -- 32768 workgroups (QR-DQN at B = 262144) spent 0.41 ms of a 0.04 ms kernel there
-// (tests/tools/r03_td_ab.py).  Up to kFoldMaxGrid workgroups share the one ticket; above (tune key 21 = 2) a launch arrives
-// through kFoldSub counters on lines of their own (ScanFold::sub), 1 / kFoldSub of the grid each.
+// (tests/tools/r03_td_ab.py).  (Round 4 also tried a two-level counter tree for the large grids: neutral against the finalize
+// launch, profiles/r04_fold_tree.txt; removed in round 5.)
 constexpr long kFoldMaxGrid = 512;
 ScanFold make_fold(hipStream_t st, int nacc, const float* scale, float* out, long grid = 0);
 
@@ -86,53 +82,10 @@ __device__ __forceinline__ void publish_sums(float sum, float* __restrict__ part
     const int lane = threadIdx.x & 63, wr = threadIdx.x >> 6;
     __syncthreads();   // every partial of this workgroup is out
     if (threadIdx.x == 0) {
-        if (fold.sub) {
-            const unsigned g = blockIdx.x % kFoldSub, expect = (gridDim.x - g + kFoldSub - 1) / kFoldSub;
-            const unsigned groups = gridDim.x < (unsigned)kFoldSub ? gridDim.x : (unsigned)kFoldSub;
-            unsigned* const sp = fold.sub + g * 32;
-            int last = 0;
-            if (__hip_atomic_fetch_add(sp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1) {
-                __hip_atomic_store(sp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody else comes here in this launch
-                last = __hip_atomic_fetch_add(fold.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
-            }
-            s_last = last;
-        } else {
-            s_last = __hip_atomic_fetch_add(fold.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-        }
+        s_last = __hip_atomic_fetch_add(fold.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;   // uniform: the last workgroup to arrive adds all partials
-    if (gridDim.x > (unsigned)kFoldMaxGrid) {   // the large grids of the counter tree: finalize_sums_kernel's additions, 16 loads in flight
-        __shared__ double s_big[NWAVES];
-        constexpr int CH = 16;
-        for (int k = 0; k < NACC; ++k) {
-            double s = 0.0;
-            for (unsigned i0 = threadIdx.x; i0 < gridDim.x; i0 += CH * NT) {
-                float v[CH];
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const unsigned i = i0 + j * NT;
-                    v[j] = i < gridDim.x ? __hip_atomic_load(partials + (size_t)k * gridDim.x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                         : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < CH; ++j)
-                    if (i0 + j * NT < gridDim.x) s += (double)v[j];
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-            if (lane == 0) s_big[wr] = s;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double tot = 0.0;
-                for (int i = 0; i < NWAVES; ++i) tot += s_big[i];
-                fold.out[k] = (float)(tot * (double)fold.scale[k]);
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(fold.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
     // Round 4: ALL NACC * ceil(grid / NT) partials of a thread are requested before the first use, the NACC sums share one
     // barrier -- the first version walked the sums one after the other (a memory round trip and two barriers each: ~7 us of
     // serial tail for PPO's five sums, more than its kernels' work at B = 65536).  Same additions in the same order.
@@ -283,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void colscan_rev_kernel(const Op op, int T
 struct ScanCfg { int v, lc, nw, sub; };
 
 // V=1 or 2 (the fat rows of V-trace/UPGO do not fit V=4), LC = 8, NW up to 16 for small B.
-extern int g_scan_wave_target;   // hpc_rll_tune_set key 19: waves a scan launch aims for (fills NW up to 16)
+constexpr int g_scan_wave_target = 4096;   // waves a scan launch aims for (fills NW up to 16); in-process sweep (r02_scan_sweep.py): TD-lambda C3 16.9 -> 16.0 us vs 2048
 // lc16 (round 5, TD-lambda only: its row payload is four values): SIXTEEN steps per wave where the 8-step form would walk a
 // one-workgroup-per-CU grid through two or more dependent iterations (load round trip -> chunk heads through LDS -> barrier ->
 // stores, each ~3 us): T = 256 at B = 16384 becomes ONE iteration of 16 waves x 16 steps.

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // FULLB: B is a multiple of the tile width, no lane is ever out of range -- no exec-masked region around the stores
 // (which would make the compiler's vmcnt bookkeeping pessimistic again, see GUARD below).
-template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB, bool XCD_REMAP = false>
+template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB>
 __global__ __launch_bounds__(NW * 64) void gae_fwd_pf_kernel(const float* __restrict__ value,
                                                              const float* __restrict__ reward,
                                                              float* __restrict__ adv,
@@ -231,12 +231,9 @@ __global__ __launch_bounds__(NW * 64) void gae_fwd_pf_kernel(const float* __rest
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // XCD-aware column tiles (experiment, coef-table argument untouched: T < 0 requests it): workgroups are dealt round
-    // robin to the 8 XCDs, so with the identity mapping XCD x streams every 8th tile; remapped, XCD x owns a contiguous
-    // eighth of the columns (its L2 / fabric port sees contiguous 8-32 KiB per row instead of 1 KiB pieces 8 KiB apart)
-    long tile_id = blockIdx.x;
-    if (XCD_REMAP && (gridDim.x & 7) == 0) tile_id = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const long col = tile_id * TILE + (long)lane * V;
+    // (round 4 tried XCD-contiguous column tiles -- XCD x owning a contiguous eighth of the columns instead of every 8th tile:
+    // no gain at C2 (tests/tools/r04_gae_xcd_probe.py); removed in round 5)
+    const long col = (long)blockIdx.x * TILE + (long)lane * V;
     const bool col_ok = FULLB || col < (long)B;
 
     float carry[V];
@@ -515,88 +512,17 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward, ONE TRAJECTORY PER WAVEFRONT (the mapping BASELINE.json's north_star names; SURVEY.md 7.3 (ii) asked for both
-// mappings to be measured).  A workgroup of 16 waves owns 64 columns and walks T in tiles of 64 steps: the (65 x 64)
-// value rows and (64 x 64) reward rows of a tile are loaded COALESCED along B and staged through LDS, then a wave takes
-// one trajectory (column) at a time -- four per wave -- with its 64 LANES ALONG TIME: delta_t from three conflict-free
-// LDS reads (row stride 65), an inclusive suffix scan of the affine pairs (c_t, delta_t) in log2(64) = 6 wavefront-
-// shuffle steps (the coefficient products are shared by the wave's four trajectories), the carry from the later tile
-// applied through the product, the result written back through LDS and stored coalesced.
-// Kept as a measured alternative (flags bit 4 of hpc_rll_gae_forward_ex), not the shipped mapping: the lane-per-column
-// kernels need ONE fma per element where the shuffle scan needs 6 shuffles + 6 fmas, no LDS round trip of the payload,
-// and their time parallelism (NW*LC = 256-512 steps per barrier) is larger than a 64-step tile's.  Numbers in DESIGN.md
-// section 4.1 (tests/tools/r03_gae_wpt_probe.py).
-// ------------------------------------------------------------------------------------------------
-template <bool NTL, bool NTS>
-__global__ __launch_bounds__(1024) void gae_fwd_wpt_kernel(const float* __restrict__ value,
-                                                           const float* __restrict__ reward,
-                                                           float* __restrict__ adv, const float* __restrict__ coef,
-                                                           int T, int B, float gamma) {
-    constexpr int TT = 64, LD = 65;
-    __shared__ float sv[(TT + 1) * LD], sr[TT * LD], so[TT * LD];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long c0 = (long)blockIdx.x * 64;
-    const bool col_ok = c0 + lane < (long)B;
-    float carry[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int t1 = T; t1 > 0; t1 -= TT) {
-        const int t0 = t1 - TT;                      // may be negative in the last (earliest) tile
-        // ---- load phase: wave w takes rows w, w+16, ... (lane <-> column: 256-byte coalesced rows)
-        for (int r = w; r <= TT; r += 16) {
-            const int t = t0 + r;
-            if (t >= 0 && col_ok) sv[r * LD + lane] = ld<NTL>(value + (size_t)t * B + c0 + lane);
-        }
-        for (int r = w; r < TT; r += 16) {
-            const int t = t0 + r;
-            if (t >= 0 && col_ok) sr[r * LD + lane] = ld<NTL>(reward + (size_t)t * B + c0 + lane);
-        }
-        __syncthreads();
-        // ---- scan phase: lane <-> time step t0 + lane, wave <-> trajectories 4w .. 4w+3
-        const int t = t0 + lane;
-        const bool valid = t >= 0;
-        float P = valid ? coef[t] : 1.f;
-        float b[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 4 * w + k;
-            const float v0 = sv[lane * LD + c], v1 = sv[(lane + 1) * LD + c], rr = sr[lane * LD + c];
-            b[k] = valid ? fmaf(gamma, v1, rr) - v0 : 0.f;
-        }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const float an = __shfl_down(P, d, 64);
-            const bool ok = lane + d < 64;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float bn = __shfl_down(b[k], d, 64);
-                if (ok) b[k] = fmaf(P, bn, b[k]);
-            }
-            if (ok) P *= an;
-        }
-        const int first = t0 < 0 ? -t0 : 0;          // the earliest valid lane holds the tile's head
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            b[k] = fmaf(P, carry[k], b[k]);
-            carry[k] = __shfl(b[k], first, 64);
-            so[lane * LD + 4 * w + k] = b[k];
-        }
-        __syncthreads();
-        // ---- store phase: coalesced rows
-        for (int r = w; r < TT; r += 16) {
-            const int tt = t0 + r;
-            if (tt >= 0 && col_ok) st<NTS>(adv + (size_t)tt * B + c0 + lane, so[r * LD + lane]);
-        }
-        // the next tile's loads write sv / sr, which this tile's scan phase finished reading before the barrier above;
-        // its scan phase writes `so` only after ITS first barrier, behind this store phase
-    }
-}
-
+// (The mapping BASELINE.json's north_star names -- ONE TRAJECTORY PER WAVEFRONT, 64 lanes along time, a 6-step wavefront-shuffle
+// scan per 64-step tile staged through LDS -- was built and measured in round 3: 2-8x slower than the lane-per-column kernels
+// on every shape (they need ONE fma per element where the shuffle scan needs 6 shuffles + 6 fmas, no LDS round trip of the
+// payload, and cover 256-512 steps per barrier): profiles/r03_gae_wpt_probe.txt.  The kernel lives on as a stand-alone
+// measurement, tests/tools/micro/gae_wpt.hip; it is not part of the library any more.)
 // ------------------------------------------------------------------------------------------------
 // backward, software-pipelined (round 3): the mirror image of gae_fwd_pf_kernel.  Both gradients are written
 // (grad_value and grad_reward non-null; the dispatcher falls back to gae_bwd_kernel otherwise).  Same arithmetic
 // order as gae_bwd_kernel: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB, bool XCD_REMAP = false>
+template <int V, int LC, int NW, bool NTL, bool NTS, bool FULLB>
 __global__ __launch_bounds__(NW * 64) void gae_bwd_pf_kernel(const float* __restrict__ grad_adv,
                                                              float* __restrict__ grad_value,
                                                              float* __restrict__ grad_reward,
@@ -609,12 +535,9 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_pf_kernel(const float* __rest
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // XCD-aware column tiles (experiment, coef-table argument untouched: T < 0 requests it): workgroups are dealt round
-    // robin to the 8 XCDs, so with the identity mapping XCD x streams every 8th tile; remapped, XCD x owns a contiguous
-    // eighth of the columns (its L2 / fabric port sees contiguous 8-32 KiB per row instead of 1 KiB pieces 8 KiB apart)
-    long tile_id = blockIdx.x;
-    if (XCD_REMAP && (gridDim.x & 7) == 0) tile_id = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const long col = tile_id * TILE + (long)lane * V;
+    // (round 4 tried XCD-contiguous column tiles -- XCD x owning a contiguous eighth of the columns instead of every 8th tile:
+    // no gain at C2 (tests/tools/r04_gae_xcd_probe.py); removed in round 5)
+    const long col = (long)blockIdx.x * TILE + (long)lane * V;
     const bool col_ok = FULLB || col < (long)B;
 
     float carry[V];
@@ -751,7 +674,7 @@ __global__ __launch_bounds__(NW * 64) void gae_bwd_pf_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // host side: configuration choice + dispatch
 // ------------------------------------------------------------------------------------------------
-struct Cfg { int v, lc, nw, flags; bool half; bool pf; bool xcd = false; };
+struct Cfg { int v, lc, nw, flags; bool half; bool pf; };
 
 // Kernel timing (hpc_rll_ktime_begin / _end): while armed, every GAE launch goes through hipExtLaunchKernelGGL with a
 // start/stop event pair that brackets the KERNEL ITSELF (the dispatch packet's begin / end timestamps -- what
@@ -887,7 +810,6 @@ inline Cfg choose_cfg(bool fwd, int T, int B, int vmax, int v, int lc, int nw, i
     if (pf && !fwd && !((lc == 2 || lc == 4 || lc == 8) && !(v == 1 && lc != 8))) pf = false;
     if (pf) flags |= 2;
     Cfg out{v, lc, nw, flags & 3, half, pf};
-    out.xcd = explicit_flags >= 0 && (explicit_flags & 32);      // experiment: XCD-contiguous column tiles
     return out;
 }
 
@@ -951,9 +873,7 @@ inline bool dispatch_fwd_pf(const Cfg& cfg, int B, hipStream_t st, A... args) {
         if (!hit && cfg.v == V && cfg.lc == LC && cfg.nw == NW) {
             const dim3 grid((unsigned)((B + 64 * V - 1) / (64 * V))), block(NW * 64);
             const bool full = (B % (64 * V)) == 0;
-            if (cfg.xcd && full && V == 4 && LC == 4 && NW == 8 && (cfg.flags & 1)) {
-                launch(gae_fwd_pf_kernel<4, 4, 8, true, true, true, true>, grid, block, st, 0, args...);
-            } else if (cfg.flags & 1) {
+            if (cfg.flags & 1) {
                 if (full) launch(gae_fwd_pf_kernel<V, LC, NW, true, true, true>, grid, block, st, 0, args...);
                 else launch(gae_fwd_pf_kernel<V, LC, NW, true, true, false>, grid, block, st, 0, args...);
             } else {
@@ -978,9 +898,7 @@ inline bool dispatch_bwd_pf(const Cfg& cfg, int B, hipStream_t st, A... args) {
         if (!hit && cfg.v == V && cfg.lc == LC && cfg.nw == NW) {
             const dim3 grid((unsigned)((B + 64 * V - 1) / (64 * V))), block(NW * 64);
             const bool full = (B % (64 * V)) == 0;
-            if (cfg.xcd && full && V == 4 && LC == 2 && NW == 4 && !(cfg.flags & 1)) {
-                launch(gae_bwd_pf_kernel<4, 2, 4, false, true, true, true>, grid, block, st, 1, args...);
-            } else if (cfg.flags & 1) {
+            if (cfg.flags & 1) {
                 if (full) launch(gae_bwd_pf_kernel<V, LC, NW, true, true, true>, grid, block, st, 1, args...);
                 else launch(gae_bwd_pf_kernel<V, LC, NW, true, true, false>, grid, block, st, 1, args...);
             } else {
@@ -1024,12 +942,6 @@ extern "C" int hpc_rll_gae_forward_ex(const float* value, const float* reward, f
     if (!aligned(value, 4) || !aligned(reward, 4) || !aligned(adv, 4) || !aligned(coef, 4)) return HPC_RLL_EALIGN;
     const Cfg cfg = choose_cfg(true, T, B, max_vec(B, {value, reward, adv}), vec, lc, nw, flags);
     hipStream_t st = (hipStream_t)stream;
-    if (flags >= 0 && (flags & 16)) {   // one trajectory per wavefront (measured alternative, see gae_fwd_wpt_kernel)
-        const dim3 grid((unsigned)((B + 63) / 64)), block(1024);
-        if (flags & 1) launch(gae_fwd_wpt_kernel<true, true>, grid, block, st, 0, value, reward, adv, coef, T, B, gamma);
-        else launch(gae_fwd_wpt_kernel<false, true>, grid, block, st, 0, value, reward, adv, coef, T, B, gamma);
-        return check_launch();
-    }
     if (cfg.pf) {
         std::atomic<int>* lc_ = g_kt.last_cfg[0];
         lc_[0] = cfg.v; lc_[1] = cfg.lc; lc_[2] = cfg.nw; lc_[3] = cfg.flags; lc_[4] = 0; lc_[5] = 1;

@@ -50,7 +50,6 @@ struct GemmArgs {
     long c_split = 0;  //      C + z*c_split; the consumer adds the slices in a fixed order (deterministic)
     int big = 0;       // 1: a long-K product that brings its own split-K (gemm_splitk_big): 128x128 tiles
     int xcd_swizzle = 0;   // set by launch_gemm_tile
-    int prio = 0;          // 1: s_setprio(1) around the MFMA clusters (tune key 23 bit 0; experiment)
     float* rowpart = nullptr;   // gemm_f32_nn_dma_kernel<., true>: per-row (mean, M2) of every 128-column block of C,
                                 // [N/128][M][2] -- LayerNorm partials out of the product's epilogue (lstm_block.hpp)
 };
@@ -404,7 +403,6 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
             for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const gf4*>(as + a_off[q] + i * 32 * BK);
 #pragma unroll
             for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const gf4*>(bs + b_off[q] + j * 32 * BK);
-            if (NW == 16 && g.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -412,7 +410,6 @@ __global__ __launch_bounds__(NW * 64, (GemmOcc<BM, BN, BK, NW>::value)) void gem
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
-            if (NW == 16 && g.prio) __builtin_amdgcn_s_setprio(0);
         }
     };
     if constexpr (PIPE3) {
@@ -829,9 +826,8 @@ inline int gemm_mode(const float* p, long sx, long sk, int XD, int KD) {
 template <int BM, int BN, int BK, int WM, int WN>
 inline void launch_gemm_tile(const GemmArgs& g_in, int am, int bm, hipStream_t st) {
     const dim3 grid((g_in.N + BN - 1) / BN, (g_in.M + BM - 1) / BM, g_in.splitk > 1 ? g_in.splitk : 1);
-    extern int g_gemm_xcd;   // tuning knob (hpc_rll_tune_set key 10)
     GemmArgs g = g_in;
-    g.xcd_swizzle = (g_gemm_xcd && ((long)grid.x * grid.y) % 8 == 0 && grid.y >= 8) ? 1 : 0;
+    g.xcd_swizzle = (((long)grid.x * grid.y) % 8 == 0 && grid.y >= 8) ? 1 : 0;
     const bool interior = g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0;
 #define HPC_RLL_GEMM_CASE(AM, BMD)                                                                          \
     if (am == AM && bm == BMD) {                                                                            \
@@ -870,12 +866,12 @@ inline int gemm_splitk(int M, int N, int K) {
     const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
     const int ktiles = (K + 31) / 32;
     int s = 1;
-    extern int g_gemm_lat_target;   // tuning knob (hpc_rll_tune_set key 12), 256 = one workgroup per CU
+    constexpr int g_gemm_lat_target = 256;   // one workgroup per CU
     // latency regime: fill the CUs (in-process sweep over mid-batch LSTM shapes: 256 workgroups up to M = 256, two per CU
     // from M = 512: B=1024,H=512 4.62/7.37 -> 4.11/7.02 ms)
     const long lat_target = M >= 512 ? 2L * g_gemm_lat_target : g_gemm_lat_target;
     while (s < 16 && tiles * s < lat_target && ktiles / (s * 2) >= 2) s *= 2;
-    extern int g_gemm_thr_ktiles;   // tuning knob (hpc_rll_tune_set key 14)
+    constexpr int g_gemm_thr_ktiles = 8;   // (in-process sweep, B = 512..2048: 8 -> forward -3..6 %, backward +-1 %; C4 unaffected)
     while (s < 16 && tiles * s < 768 && ktiles / (s * 2) >= g_gemm_thr_ktiles) s *= 2;   // throughput regime: 3-4 workgroups per CU
     return s;                                                             // while the slices stay long (C4 dh: 2)
 }
@@ -883,9 +879,8 @@ inline int gemm_splitk(int M, int N, int K) {
 // The same for the large once-per-layer products with a long K (the weight gradients, K = S*B): fill the chip with
 // ~2 workgroups per CU but keep >= 16 k-tiles per slice; the partial products are summed by a reduction kernel.
 inline GemmTile gemm_tile_big(int M, int N, int K) {
-    extern int g_gemm_big_tile128;   // tuning knobs (hpc_rll_tune_set keys 7, 6)
-    extern int g_gemm_big_target;
-    if (g_gemm_big_tile128 && M > 64 && N > 64) {   // 128x128 only if its split-K can still reach the target
+    constexpr int g_gemm_big_target = 768;   // workgroups the split-K of the weight-gradient products aims for
+    if (M > 64 && N > 64) {   // 128x128 only if its split-K can still reach the target
         const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
         const int ktiles = (K + 31) / 32;
         int s = 1;
@@ -898,7 +893,7 @@ inline int gemm_splitk_big(int M, int N, int K) {
     const GemmTile t = gemm_tile_big(M, N, K);
     const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
     const int ktiles = (K + 31) / 32;
-    extern int g_gemm_big_target;   // tuning knob (hpc_rll_tune_set key 6)
+    constexpr int g_gemm_big_target = 768;
     int s = 1;
     while (s < 16 && tiles * s < g_gemm_big_target && ktiles / (s * 2) >= 16) s *= 2;
     return s;
@@ -920,13 +915,11 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return;
     const int am = gemm_mode(g.A, g.a_sm, g.a_sk, g.M, g.K);
     const int bm = gemm_mode(g.B, g.b_sn, g.b_sk, g.N, g.K);
-    extern int g_gemm_bk;   // tuning knob (hpc_rll_tune_set key 1): 16 / 32, 0 = by layout
     // measured at the LSTM shapes: NN runs better with BK = 16 (4-5 workgroups resident per CU: 108 vs 94 TFLOP/s on
     // the recurrent GEMM), NT is indifferent; the long-K weight-gradient products (TN, `big`) run 128x128x16 tiles
     // with their own split-K (4 workgroups per CU in one round: C4 backward 179 -> 171 ms vs 128x64x32)
     const GemmTile t = g.big ? gemm_tile_big(g.M, g.N, g.K) : gemm_tile_of(g.M, g.N);
-    const int bk = g_gemm_bk ? g_gemm_bk
-                             : (((am == kContigK && bm == kContigMN) || (g.big && t.bm == 128 && t.bn == 128)) ? 16 : 32);
+    const int bk = ((am == kContigK && bm == kContigMN) || (g.big && t.bm == 128 && t.bn == 128)) ? 16 : 32;
     extern int g_gemm_tile256;   // tuning knob (hpc_rll_tune_set key 16)
     {   // TN: LDS-DMA with k-major tiles (gemm_f32_tn_dma_kernel), one 8-wave workgroup per CU
         extern int g_gemm_dma;
@@ -953,8 +946,6 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
         const int dt = gemm_dma_tile(g.M, g.N, g.K, g.splitk);
         const int sk = g.splitk > 1 ? g.splitk : 1;
         GemmArgs h = g;
-        extern int g_gemm_exp;
-        h.prio = g_gemm_exp & 1;
         if (dt == 1) {
             const dim3 grid(g.N / 128, g.M / 256, sk);
             h.xcd_swizzle = (((long)grid.x * grid.y) % 8 == 0 && grid.y >= 8) ? 1 : 0;
@@ -980,14 +971,9 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
             const dim3 grid(g.N / 256, g.M / 256, sk);
             GemmArgs h = g;
             h.xcd_swizzle = 0;   // measured neutral for this tile (136.5 vs 136.7)
-            extern int g_gemm_exp;   // tune key 23 (experiments): bit 0 s_setprio around the MFMA clusters, bit 1 BK = 32
-            h.prio = g_gemm_exp & 1;
 #define HPC_RLL_GEMM256(AM, BMD)                                                                                          \
             if (am == AM && bm == BMD) {                                                                                  \
-                if ((g_gemm_exp & 2) && g.K % 32 == 0)                                                                    \
-                    hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 32, 2, 2, AM, BMD, true, 0, 16>), grid, dim3(1024), 0, st, h); \
-                else                                                                                                      \
-                    hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 16, 2, 2, AM, BMD, true, 0, 16>), grid, dim3(1024), 0, st, h); \
+                hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 16, 2, 2, AM, BMD, true, 0, 16>), grid, dim3(1024), 0, st, h); \
                 return;                                                                                                   \
             }
             HPC_RLL_GEMM256(kContigK, kContigMN) HPC_RLL_GEMM256(kContigK, kContigK) HPC_RLL_GEMM256(kContigMN, kContigMN)

@@ -27,19 +27,13 @@
 #include "wave.hpp"
 
 namespace hpc_rll {
-int g_gemm_bk = 0;
-int g_gemm_exp = 0;   // hpc_rll_tune_set key 23: GEMM experiments (bit 0 s_setprio around MFMA clusters, bit 1 BK = 32 for 256x256 tiles)
-int g_gemm_dma = 1;   // LDS-DMA staging of NT products on the 256x256x16 tile (hpc_rll_tune_set key 25; gemm_f32.hpp: DmaStage)
-int g_gemm_tile256 = 1;   // 256x256x16 tiles (16 waves) for interior products that fill the chip in whole rounds (tune key 16)
-int g_cell_vec4 = 3;   // smallest ceil(H/256) that takes the 16-byte forward cell kernel (tune key 15; 0 = never)
-int g_gemm_xcd = 1;
-int g_gemm_lat_target = 256;
-int g_gemm_thr_ktiles = 8;    // in-process sweep (B=512..2048): 8 -> forward -3..6 %, backward +-1 %; C4 unaffected
-int g_lstm_dh_big = 1;   // experiments (tune key 12)
-int g_lstm_nn_bwd = 1;   // backward products against transposed weight copies (hpc_rll_tune_set key 11)
-int g_gemm_big_tile128 = 1;
-int g_gemm_big_target = 768;   // workgroups the split-K of the weight-gradient GEMMs aims for
-int g_cell_rows_wgs = 512;     // workgroups of the row-walking backward cell (tune key 20; 0 = one row per workgroup + colreduce)
+// path switches that tests flip (hpc_rll_tune_set, tune.hip); the measured launch parameters of round 1-4 are constants now
+int g_gemm_dma = 1;       // key 25: LDS-DMA staging of the NT / TN / NN products (gemm_f32.hpp: DmaStage); 0 = register staging
+int g_gemm_tile256 = 1;   // key 16: 256x256x16 tiles (16 waves) for interior products that fill the chip in whole rounds
+constexpr int g_cell_vec4 = 3;        // smallest ceil(H/256) that takes the 16-byte forward cell kernel
+constexpr int g_lstm_dh_big = 1;      // dh_prev of large batches on the weight-gradient tiling (128x128, own split-K)
+constexpr int g_lstm_nn_bwd = 1;      // backward products of large batches against transposed weight copies
+constexpr int g_cell_rows_wgs = 512;  // workgroups of the row-walking backward cell
 namespace {
 
 constexpr float kLnEps = 1e-5f;

@@ -34,8 +34,8 @@
 
 namespace hpc_rll {
 int g_lstm_block = 9;        // hpc_rll_tune_set key 26: 0 = step kernels (same layout); bit 0 = persistent row-block forward,
-                             // bit 1 = 128-row blocks (two workgroups per CU), bit 2 = libm gate functions (forward),
-                             // bit 3 = persistent row-block backward, bit 4 = its k-depth 16 instead of 32
+                             // bit 3 = persistent row-block backward, bit 7 = the forward's exchanges without cache-wide fences
+                             // (the backward's never have them)
 int g_lstm_block_skew = 10;  // hpc_rll_tune_set key 27: microseconds between the starts of consecutive row blocks (C4: 69.9 -> 65.9 ms)
 namespace {
 
@@ -391,10 +391,10 @@ inline size_t block_part_floats(int B, int H) {   // the larger of the forward's
 }
 inline size_t block_flag_words(int B) { return (size_t)(B / 128) * 2; }
 
-// g_lstm_block: 0 off; bit 0 = on; bit 1 = 128-row blocks, two workgroups per CU (else 256-row blocks, one per CU);
-// bit 2 = libm gate functions instead of the hardware exp2 / reciprocal forms
-inline int block_mw() { return (g_lstm_block & 2) ? 2 : 4; }
-inline bool block_fast() { return (g_lstm_block & 4) == 0; }
+// 256-row blocks, one workgroup per CU, hardware exp2 / reciprocal gates.  (Measured in round 4 and removed in round 5: 128-row
+// blocks with two workgroups per CU -- 67.8-70.0 against 65.1-66.4 ms at C4 -- and libm gate functions in the epilogue, +0.8 ms.)
+constexpr int block_mw() { return 4; }
+constexpr bool block_fast() { return true; }
 
 // The row blocks of a layer run in launches of `per` (co-residency); a last launch that fills less than 70 % of the CUs
 // (e.g. B = 4352: 16 + 1 row blocks of 256) would cost a whole recurrence for a few rows: such shapes keep the step kernels.
@@ -412,8 +412,7 @@ inline bool block_fwd_ok(int B, int H, hipStream_t st) {
     if (!(g_lstm_block & 1) || !g_lstm_persist || !lstm_perm_shape(B, H) || !persist_runtime_ready(st)) return false;
     const int mw = block_mw(), nrb = B / (64 * mw), per = mw == 4 ? block_rows_per_launch<4>(H) : block_rows_per_launch<2>(H);
     if (!block_launches_fill(nrb, per, mw == 4 ? 4 * H / 256 : 2 * H / 256)) return false;   // (128-row blocks share a CU in pairs)
-    if (mw == 4) return block_fast() ? block_resident<4, true>(H) : block_resident<4, false>(H);
-    return block_fast() ? block_resident<2, true>(H) : block_resident<2, false>(H);
+    return block_resident<4, true>(H);
 }
 
 // All row blocks of one layer, in as many launches as the CU count asks for (C4: 16 row blocks x 16 column tiles = one).
@@ -442,9 +441,7 @@ inline int launch_block_fwd_t(BlockFwd a, float* part, unsigned* flags, hipStrea
     return last_error();
 }
 inline int launch_block_fwd(const BlockFwd& a, float* part, unsigned* flags, hipStream_t st) {
-    if (block_mw() == 4)
-        return block_fast() ? launch_block_fwd_t<4, true>(a, part, flags, st) : launch_block_fwd_t<4, false>(a, part, flags, st);
-    return block_fast() ? launch_block_fwd_t<2, true>(a, part, flags, st) : launch_block_fwd_t<2, false>(a, part, flags, st);
+    return launch_block_fwd_t<4, true>(a, part, flags, st);
 }
 
 // ---- epilogue memory operations as BUFFER instructions: address = descriptor (4 scalar registers, the array's base for this
@@ -875,7 +872,7 @@ inline int launch_block_bwd(BlockBwd a, float* part, unsigned* flags, float* col
         a.part = part + (size_t)rb * 2 * 4 * a.nnt * 128 * 4;
         a.flags = flags + 2 * rb;
         a.colacc = colacc + (size_t)rb * 3 * 4 * a.H;
-        a.xcd_map = (n % 8 == 0 && !(g_lstm_block & 64)) ? 1 : 0;
+        a.xcd_map = n % 8 == 0 ? 1 : 0;   // (linear order: neutral end to end, round 4)
         persist_chain_before(st);
         hipLaunchKernelGGL(lstm_block_bwd_kernel, dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
         persist_chain_after(st);

@@ -27,9 +27,8 @@
 #pragma once
 
 namespace hpc_rll {
-int g_lstm_mid_xcd = 0;   // hpc_rll_tune_set key 39 (see MidFwd::xcd)
 int g_lstm_mid = 2;       // hpc_rll_tune_set key 29: 0 off, 1 one stream, 2 two streams where they fit
-int g_lstm_mid_rep = 8;   // hpc_rll_tune_set key 30: replicas of the words every workgroup polls (flags, final row statistics)
+constexpr int g_lstm_mid_rep = 8;   // replicas of the words every workgroup polls (flags, final row statistics): 256 pollers on one line cost 4.4 us per exchange
 int g_lstm_mid_bwd = 1;   // hpc_rll_tune_set key 33: the persistent mid-batch BACKWARD: 0 off, 1 where it pays (B <= 32), 2 every mid-batch shape
 namespace {
 
@@ -51,8 +50,6 @@ struct MidFwd {
     // reader sees a store after 0.6 us -- tests/tools/micro/bcast.hip, pingpong.hip; workgroup w reads replica w % nrep)
     int S, Btot, Bs /* rows per stream */, H, nwg, mbp /* 16-row blocks (a power of two) */, ks /* k slices; mbp * ks <= waves */, nrep;
     u64* prof;
-    int xcd;                       // tune key 39: logical workgroup w = (i % 8) * (nwg / 8) + i / 8 -- neighbours (who write the two halves of
-                                   // the same 128-byte lines of the saved tensors) on ONE XCD
 };
 
 // Exchange protocol (no cache-wide fences -- the first version of this kernel used agent-scope release / acquire fences
@@ -174,7 +171,7 @@ __global__ __launch_bounds__(64 * NW, 4) void lstm_mid_fwd_kernel(MidFwd a) {
     float* Wl = smem;                          // [H / 4][16][4]: column n = gate * 4 + unit
     float* pre = Wl + (size_t)H * 16;          // [NW waves][16 rows][16 columns]
     float* lnst = pre + NW * 256;              // [rows][2]: mean, rstd of the h-branch rows
-    const int wg = a.xcd ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x, j0 = wg * 4;
+    const int wg = (int)blockIdx.x, j0 = wg * 4;
     for (int e = tid; e < H * 16; e += NT) {
         const int n = e & 15, k = e >> 4;
         Wl[(((k >> 2) * 16 + n) << 2) + (k & 3)] = a.wh[(size_t)k * G + (n >> 2) * H + j0 + (n & 3)];
@@ -416,7 +413,6 @@ inline int launch_mid_fwd(MidFwd a, float* ws_mid, int layer, hipStream_t st) {
     a.hx = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws_mid + polled) + 127) & ~(uintptr_t)127);   // a writer's block = whole lines
     if (hipMemsetAsync(ws_mid, 0, polled * sizeof(float), st) != hipSuccess) return last_error();   // flags and tags
     a.prof = persist_prof();
-    a.xcd = g_lstm_mid_xcd && c.nwg % 8 == 0;
     const int rc = c.ns == 2 ? launch_mid_fwd_t<8>(c, a, st) : launch_mid_fwd_t<16>(c, a, st);
     if (rc) return rc;
     persist_prof_report("mid-batch fwd: wait_h product(after operand arrival) partials combine(own rows) wait_stats cell+publish operand_arrival", layer, a.S, st);

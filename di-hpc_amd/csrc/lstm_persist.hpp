@@ -43,9 +43,7 @@
 namespace hpc_rll {
 int g_lstm_persist = 1;          // hpc_rll_tune_set key 3
 constexpr int g_lstm_persist_max_b = 4;   // largest batch the persistent kernels take
-int g_lstm_jw = 0;               // hpc_rll_tune_set key 5: minimum hidden units per workgroup (0 = auto)
-int g_lstm_poll_nap = 1;         // hpc_rll_tune_set key 36: the nap between failed polls, 64-cycle units (1..8); reaches the device in persist_runtime_ready
-int g_lstm_xchg_rep = 4;        // hpc_rll_tune_set key 4: replicas of every exchange word (1..32)
+constexpr int g_lstm_xchg_rep = 4;   // replicas of every exchange word (measured: 4 replicas -20 % per gather, 8 and more lose again)
 namespace {
 
 typedef unsigned long long u64;
@@ -56,7 +54,6 @@ constexpr int kPersistMaxB = 4;
 __device__ unsigned g_persist_abort = 0;                 // set by the first wave that gives up (sticky)
 __device__ unsigned* g_persist_host_status = nullptr;    // pinned host word, see PersistRuntime
 __device__ long g_persist_spin_limit = kSpinLimit;       // polls before giving up (test hook: hpc_rll_test_set_persist_spin_limit)
-__device__ int g_persist_nap = 1;                        // see persist_poll_failed (hpc_rll_tune_set key 36; 8 until round 4)
 
 // one failed poll round: back off; every 1024 rounds look at the abort word / the limit
 __device__ __forceinline__ void persist_poll_failed(long& spins) {
@@ -70,13 +67,9 @@ __device__ __forceinline__ void persist_poll_failed(long& spins) {
             __builtin_amdgcn_endpgm();
         }
     }
-    // the nap between polls in 64-cycle units (tune key 36).  8 (~0.2 us) shipped until round 4; 1 measured 1.5-5 % faster forward
-    // and 1-2.4 % faster backward on three small-batch shapes (profiles/r04_persist_nap.txt)
-    const int nap = g_persist_nap;
-    if (nap >= 8) __builtin_amdgcn_s_sleep(8);
-    else if (nap >= 4) __builtin_amdgcn_s_sleep(4);
-    else if (nap >= 2) __builtin_amdgcn_s_sleep(2);
-    else __builtin_amdgcn_s_sleep(1);
+    // the nap between polls: 64 cycles.  (512, ~0.2 us, shipped until round 4; 64 measured 1.5-5 % faster forward and 1-2.4 %
+    // faster backward on three small-batch shapes, profiles/r04_persist_nap.txt)
+    __builtin_amdgcn_s_sleep(1);
 }
 
 __device__ __forceinline__ void xchg_put(u64* p, float v, uint32_t tag) {
@@ -608,7 +601,6 @@ struct PersistRuntime {
     std::mutex mu;
     unsigned* host_status = nullptr;      // hipHostMalloc'ed (mapped, portable): written by a wave that gave up
     bool dev_ready[kMaxDevices] = {};     // g_persist_host_status set on that device
-    int dev_nap[kMaxDevices] = {};        // the g_persist_nap value on that device (tune key 36)
     int cus[kMaxDevices] = {};
     hipEvent_t chain[kMaxDevices] = {};   // last persistent launch on the device
     bool chain_armed[kMaxDevices] = {};
@@ -650,16 +642,10 @@ inline bool persist_runtime_ready(hipStream_t st) {
     const int dev = persist_device();
     if (dev < 0) return false;
     std::lock_guard<std::mutex> lk(r.mu);
-    if (r.dev_ready[dev] && r.dev_nap[dev] == g_lstm_poll_nap) return true;
+    if (r.dev_ready[dev]) return true;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) return false;
-    if (cs != hipStreamCaptureStatusNone) return r.dev_ready[dev];   // a changed nap (key 36) reaches the device at the next uncaptured launch
-    if (r.dev_ready[dev]) {                                           // tune key 36 changed: one blocking 4-byte copy
-        const int nap = g_lstm_poll_nap;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_persist_nap), &nap, sizeof(nap)) != hipSuccess) { (void)hipGetLastError(); return false; }
-        r.dev_nap[dev] = nap;
-        return true;
-    }
+    if (cs != hipStreamCaptureStatusNone) return false;   // (the one-time set-up below is a synchronous copy)
     if (!r.host_status) {
         void* p = nullptr;
         if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -670,9 +656,6 @@ inline bool persist_runtime_ready(hipStream_t st) {
     if (hipHostGetDevicePointer(&dptr, r.host_status, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_persist_host_status), &dptr, sizeof(dptr)) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipEventCreateWithFlags(&r.chain[dev], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
-    const int nap = g_lstm_poll_nap;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_persist_nap), &nap, sizeof(nap)) != hipSuccess) { (void)hipGetLastError(); return false; }
-    r.dev_nap[dev] = nap;
     r.dev_ready[dev] = true;
     return true;
 }
@@ -765,7 +748,6 @@ inline bool persist_cfg(int B, int H, int row_floats /* per batch row staged in 
     PersistCfg c;
     c.nb = B <= 1 ? 1 : B <= 2 ? 2 : 4;
     c.jw = H <= 256 ? 1 : H <= 512 ? 2 : 4;
-    if (g_lstm_jw == 2 || g_lstm_jw == 4) c.jw = c.jw > g_lstm_jw ? c.jw : g_lstm_jw;   // experiments: fewer, fatter workgroups
     c.nwg = (H + c.jw - 1) / c.jw;
     c.lds = ((size_t)4 * c.jw * H + (size_t)c.nb * row_floats + (size_t)c.nb * 8 * c.jw + 64 * c.nb + 64) * sizeof(float);
     if (c.lds > 144 * 1024 || c.nwg > 256) return false;   // residency itself: persist_fwd_ok / persist_bwd_ok

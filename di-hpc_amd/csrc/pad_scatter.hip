@@ -677,77 +677,27 @@ __global__ __launch_bounds__(256) void scatter_out_kernel(const float* __restric
 
 // 4 consecutive cells x 4 channels per thread step: four float4 gathers, a 4x4 register transpose, four float4
 // nontemporal stores (1 KiB per wave-store instead of 256 B).  Needs HW % 4 == 0, N % 4 == 0, 16-byte aligned x/out.
-// BUILD (round 4, tune key 37): the owners of the workgroup's 4 * blockDim.x cells and (add, M <= blockDim.x) the chain links are
-// built in LDS from `location`, as in scatter_out_lds_kernel below -- no index launch, no index in memory.
-template <bool ADD, bool BUILD>
+template <bool ADD>
 __global__ __launch_bounds__(1024) void scatter_out4_kernel(const float* __restrict__ x,
                                                            const int32_t* __restrict__ idx,
                                                            float* __restrict__ out, int M, int N, int HW,
-                                                           int n_per_block, const int64_t* __restrict__ location, int W) {
-    typedef int vint4 __attribute__((ext_vector_type(4)));
-    extern __shared__ int32_t s_tab[];                              // BUILD: [4 * blockDim.x] first | [M4] next | [M4] cell
+                                                           int n_per_block) {
     const int b = blockIdx.z;
     const int cell = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // blockDim.x = 256 or 1024 (16 KiB runs per plane)
     const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
     const int32_t* __restrict__ last = head + HW;
-    const int32_t* __restrict__ next = BUILD ? nullptr : last + HW;
-    int32_t* const s_next = s_tab + 4 * blockDim.x;
-    int32_t first[4] = {-1, -1, -1, -1};
-    if (BUILD) {
-        const int NT = blockDim.x, m4 = (M + 3) & ~3, cell0 = blockIdx.x * NT * 4, H = HW / W;
-        int32_t* const s_cell = s_next + m4;
-        const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
-        long y0 = -1, x0 = -1;
-        if ((int)threadIdx.x < M) { y0 = loc[2 * threadIdx.x]; x0 = loc[2 * threadIdx.x + 1]; }
-        const vint4 m1 = {-1, -1, -1, -1};
-        reinterpret_cast<vint4*>(s_tab)[threadIdx.x] = m1;
-        if (ADD)
-            for (int m = threadIdx.x; m < M; m += NT) s_next[m] = -1;
-        __syncthreads();
-        for (int m = threadIdx.x; m < m4; m += NT) {
-            int32_t c = -2;                                // the padding of the cell list matches nothing
-            if (m < M) {
-                const long y = m == (int)threadIdx.x ? y0 : loc[2 * m], xx = m == (int)threadIdx.x ? x0 : loc[2 * m + 1];
-                c = (y >= 0 && y < H && xx >= 0 && xx < W) ? (int32_t)(y * W + xx) : -1;
-                const int rel = c - cell0;
-                if (c >= 0 && rel >= 0 && rel < 4 * NT) {
-                    if (ADD) atomicMin(reinterpret_cast<unsigned*>(s_tab) + rel, (unsigned)m);
-                    else atomicMax(s_tab + rel, m);
-                }
-            }
-            if (ADD) s_cell[m] = c;
-        }
-        if (ADD) {
-            __syncthreads();
-            const int mr = (M + 63) & ~63, P = NT / mr;     // M <= blockDim.x
-            const int p = threadIdx.x / mr, m = threadIdx.x - p * mr;
-            if (p < P) {
-                const int quads = m4 >> 2, q0 = (int)((long)quads * p / P), q1 = (int)((long)quads * (p + 1) / P);
-                const int32_t c = m < M ? s_cell[m] : -1;
-                int nk = -1;
-                for (int q = q1 - 1; q >= q0; --q) {
-                    const vint4 v = reinterpret_cast<const vint4*>(s_cell)[q];
+    const int32_t* __restrict__ next = last + HW;
+    // (round 4 also built the tables inside this kernel, as scatter_out_lds_kernel does: at C5 `add` 859 -> 875 us -- this kernel
+    // has no staging phase the build's round trip and barriers could hide behind; removed in round 5)
+    if (cell >= HW) return;
+    int32_t first[4];
 #pragma unroll
-                    for (int j = 3; j >= 0; --j)
-                        if (v[j] == c && 4 * q + j > m) nk = 4 * q + j;
-                }
-                if (c >= 0 && nk >= 0) atomicMin(reinterpret_cast<unsigned*>(s_next) + m, (unsigned)nk);
-            }
-        }
-        __syncthreads();
-        if (cell >= HW) return;
-        const vint4 f = reinterpret_cast<const vint4*>(s_tab)[threadIdx.x];
-        first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
-    } else {
-        if (cell >= HW) return;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) first[c] = ADD ? head[cell + c] : last[cell + c];
-    }
+    for (int c = 0; c < 4; ++c) first[c] = ADD ? head[cell + c] : last[cell + c];
     const float* __restrict__ xb = x + (size_t)b * M * N;
     float* __restrict__ ob = out + (size_t)b * N * HW + cell;
     const int n0 = blockIdx.y * n_per_block;
     const int n1 = min(N, n0 + n_per_block);
-    auto nxt = [&](int32_t m) -> int32_t { return BUILD ? s_next[m] : next[m]; };
+    auto nxt = [&](int32_t m) -> int32_t { return next[m]; };
     // 16 channels per iteration: all 16 gathers of an iteration are independent and issued together (a dependent
     // gather costs ~2 us under streaming load; serialising them made the first version latency bound)
     constexpr int U = 4;
@@ -973,60 +923,8 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
     }
 }
 
-// Round 4 experiment (tune key 17 = 2): WAVE tiles, no LDS, no workgroup barrier -- the structure that took the packed pad
-// kernel from 5.0 to 6.2 TB/s.  A wave owns 1024 consecutive cells (256 quads, 4 per lane) of the map of one batch element
-// and CG = 16 channels: the owners of its 16 cells sit in 16 registers of the lane for all 16 channels; per channel it
-// writes its 4 KB piece of the plane with four 1 KB nontemporal stores, gathering x[b, m, n] for the (few: 6 % at C5)
-// cells that have an owner.  Needs HW % 4 == 0 and a 16-byte aligned `out`.
-template <bool ADD>
-__global__ __launch_bounds__(256) void scatter_out_wave_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
-                                                               float* __restrict__ out, int M, int N, int HW, int tiles_per_plane,
-                                                               int groups, long nwaves) {
-    constexpr int CG = 16;
-    const int lane = threadIdx.x & 63;
-    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= nwaves) return;
-    const int cg = (int)(wv % groups);
-    const long r = wv / groups;
-    const int tp = (int)(r % tiles_per_plane);
-    const int b = (int)(r / tiles_per_plane);
-    const int32_t* __restrict__ head = idx + (size_t)b * (2 * HW + M);
-    const int32_t* __restrict__ first_g = ADD ? head : head + HW;
-    const int32_t* __restrict__ next_g = head + 2 * HW;
-    const float* __restrict__ xb = x + (size_t)b * M * N;
-    int4 f[4];
-    int cell[4];
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        cell[j] = tp * 1024 + 4 * (lane + 64 * j);
-        f[j] = cell[j] < HW ? *reinterpret_cast<const int4*>(first_g + cell[j]) : int4{-1, -1, -1, -1};
-        any = any || ((f[j].x & f[j].y & f[j].z & f[j].w) >= 0);
-    }
-    const int n0 = cg * CG;
-    for (int c = 0; c < CG && n0 + c < N; ++c) {
-        const int n = n0 + c;
-        float* __restrict__ op = out + ((size_t)b * N + n) * HW;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            vfloat4 o = {0.f, 0.f, 0.f, 0.f};
-            if (any && (f[j].x & f[j].y & f[j].z & f[j].w) >= 0) {
-                const int32_t fi[4] = {f[j].x, f[j].y, f[j].z, f[j].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float a = 0.f;
-                    if (fi[k] >= 0) {
-                        a = xb[(size_t)fi[k] * N + n];
-                        if (ADD)
-                            for (int32_t m = next_g[fi[k]]; m >= 0; m = next_g[m]) a += xb[(size_t)m * N + n];
-                    }
-                    o[k] = a;
-                }
-            }
-            if (cell[j] < HW) __builtin_nontemporal_store(o, reinterpret_cast<vfloat4*>(op + cell[j]));
-        }
-    }
-}
+// (Round 4 also tried WAVE tiles -- no LDS, no workgroup barrier, a wave owning 1024 cells x 16 channels with the owners in
+// registers, the structure that took the packed pad kernel from 5.0 to 6.2 TB/s: slower here on every shape; removed in round 5.)
 
 // backward: workgroup = (b, group of NG channels); stage NG planes of grad_out in LDS, gather per entity.
 // The planes are one contiguous span of grad_out: staged with nontemporal float4 loads, 1024 threads and up to
@@ -1074,73 +972,8 @@ __global__ __launch_bounds__(1024) void scatter_bwd_lds_kernel(const float* __re
     }
 }
 
-// Round 4 EXPERIMENT (tune key 34 = 1; default off: 1.25 ms against 0.865 at C5 -- 64 KB of loads in flight per CU is all the
-// LDS leaves beside the gathered block, and the memory latency under load wants twice that; bit-identical results): the same
-// backward as a PERSISTENT, software-pipelined kernel.  The kernel above reads all of
-// grad_out once -- at 256 entities on a 64 x 64 map nearly every 64-byte sector holds a wanted element, so the full sequential
-// read is the right traffic -- but as 65536 short-lived workgroups (stage 64 KB, barrier, gather, exit) it streams at 4.9-5.0
-// TB/s where a pure read reaches 6.5-7.  Here one workgroup per CU walks whole batch elements: eight waves keep FOUR planes
-// (LDS-DMA, global_load_lds_dwordx4: no staging registers) in flight into a five-plane ring while four waves gather the plane
-// that has landed; the gathered (M, N) block of a batch element is collected in LDS and written once, 64 KB contiguous
-// (the one-launch-per-tile kernel wrote it as 16-byte pieces from 16 different workgroups).  Needs HW = 2048 or 4096 (eight loader waves x
-// whole-KiB pieces), M <= 256 and ring + block within the CU's LDS.
-template <int NBUF>
-__global__ __launch_bounds__(1024) void scatter_bwd_stream_kernel(const float* __restrict__ grad_out, const int64_t* __restrict__ location,
-                                                                  float* __restrict__ grad_x, int B, int M, int N, int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float s_ring[];   // [NBUF][HW] planes, then [M][N + 1] the gathered block
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gl_ptr;
-    const int HW = H * W, ld = N + 1;
-    float* const s_out = s_ring + (size_t)NBUF * HW;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool gatherer = wave < 4, loader = wave >= 4 && wave < 12;
-    const int per = HW / 8;                                // floats of a plane per loader wave (a multiple of 256)
-    const long nb = ((long)B - blockIdx.x + gridDim.x - 1) / gridDim.x;   // batch elements of this workgroup
-    const long nplanes = nb * N;                           // its planes, in order: b = blockIdx.x + (i / N) * gridDim.x, n = i % N
-    auto plane_ptr = [&](long i) { return grad_out + (((size_t)blockIdx.x + (size_t)(i / N) * gridDim.x) * N + (size_t)(i % N)) * HW; };
-    auto issue = [&](long i) __attribute__((always_inline)) {   // loader waves: plane i -> ring slot i % NBUF
-        const float* src = plane_ptr(i) + (size_t)(wave - 4) * per + 4 * lane;
-        float* dst = s_ring + (size_t)(i % NBUF) * HW + (size_t)(wave - 4) * per;
-        for (int c = 0; c < per; c += 256) __builtin_amdgcn_global_load_lds((gl_ptr)(src + c), (lds_ptr)(dst + c), 16, 0, 0);
-    };
-    if (loader)
-        for (long i = 0; i < NBUF - 1 && i < nplanes; ++i) issue(i);
-    int cell = -1;
-    for (long i = 0; i < nplanes; ++i) {
-        const long bi = i / N;
-        const int n = (int)(i - bi * N);
-        const long b = blockIdx.x + bi * gridDim.x;
-        if (loader) {
-            // plane i must have landed: at most the NBUF - 2 planes issued after it may still be in flight (per / 256 loads each)
-            const int k = per / 256;
-            if (i + NBUF - 1 <= nplanes) {                  // steady state: NBUF - 2 younger planes outstanding
-                if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF - 2) : "memory");
-                else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NBUF - 2)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: no more planes are being issued
-            }
-        }
-        if (gatherer && n == 0 && tid < M) {               // the entity's cell of this batch element
-            const int64_t* lp = location + ((size_t)b * M + tid) * 2;
-            const long y = lp[0], xx = lp[1];
-            cell = (y >= 0 && y < H && xx >= 0 && xx < W) ? (int)(y * W + xx) : -1;
-        }
-        __syncthreads();                                   // plane i is in LDS; the slot of plane i - 1 is free
-        if (loader && i + NBUF - 1 < nplanes) issue(i + NBUF - 1);
-        if (gatherer && tid < M) s_out[tid * ld + n] = cell >= 0 ? s_ring[(size_t)(i % NBUF) * HW + cell] : 0.f;
-        if (n == N - 1) {                                  // the batch element is complete: its (M, N) block, contiguous
-            __syncthreads();
-            if (!loader) {                                 // (the loaders' vmcnt bookkeeping must not see these stores)
-                float* gx = grad_x + (size_t)b * M * N;
-                const int t8 = wave < 4 ? tid : tid - 512; // 512 threads: waves 0-3 and 12-15
-                for (int e = t8; e < M * N; e += 512) gx[e] = s_out[(e / N) * ld + e % N];
-            }
-            // (the next write to s_out is behind the next iteration's barrier)
-        }
-    }
-}
+// (Round 4 also tried this backward as a PERSISTENT software-pipelined kernel -- eight loader waves keeping four planes in
+// flight by LDS-DMA, four gathering waves, the gathered block written once: 1.25 ms against 0.865 at C5; removed in round 5.)
 
 // fallback for planes too large for LDS: direct gather
 __global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __restrict__ grad_out,
@@ -1162,8 +995,15 @@ __global__ __launch_bounds__(256) void scatter_bwd_direct_kernel(const float* __
 }  // namespace hpc_rll
 
 namespace hpc_rll { int g_pad_wave = 1; }   // hpc_rll_tune_set key 28: packed Pad1D on wave tiles in output space (0 = the round-3 workgroup kernel)
-namespace hpc_rll { int g_scatter_threads = 1024; int g_scatter_bwd_lds_kb = 64; int g_scatter_lds_fwd = 1; int g_scatter_npb = 0; int g_scatter_build = 1; int g_scatter_bwd_xcd = 1; }
-namespace hpc_rll { int g_scatter_bwd_stream = 0; }   // hpc_rll_tune_set key 34: persistent pipelined scatter backward (experiment: slower, see the kernel)
+namespace hpc_rll {
+// path switches that tests flip (hpc_rll_tune_set, tune.hip)
+int g_scatter_lds_fwd = 1;   // key 17: 1 = LDS-staged streaming forward kernel where it applies, 0 = cells-per-thread kernel everywhere
+int g_scatter_npb = 0;       // key 18: channels per workgroup of the LDS-staged kernel (0 = by LDS budget)
+int g_scatter_build = 1;     // key 37: 1 = owner table / chain links built inside the forward kernel, 0 = index launch
+int g_scatter_bwd_xcd = 1;   // key 38: 1 = XCD-major workgroup order of the backward where its pieces are below a sector pair, 0 = launch order
+constexpr int g_scatter_threads = 1024;     // threads per workgroup of the cells-per-thread kernel on maps of >= 4096 cells
+constexpr int g_scatter_bwd_lds_kb = 64;    // planes staged per backward workgroup (profiles/r04_scatter_bwd_lds.txt)
+}
 using namespace hpc_rll;
 
 extern "C" int hpc_rll_pad_forward(const int64_t* table, float* new_x, int32_t* mask, int64_t n, int m0, int m1,
@@ -1501,28 +1341,18 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     // (tests/tools/r02_scatter_probe.py, profiles/r02_scatter_probe.json): configs[4] cover 0.953 -> 0.919 ms (4.81 ->
     // 4.99 TB/s), reference test shape (16x16 maps) cover 51 -> 46 us, add 68 -> 53 us; `add` on large maps is a tie at
     // 64 channels per workgroup (0.893 ms, 5.13 TB/s) and a loss at 32, so it keeps the cells-per-thread kernel there.
-    if (g_scatter_lds_fwd == 2 && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0) {   // wave tiles (experiment)
-        build_index();
-        if (rc) return rc;
-        const int tpp = (int)((HW + 1023) / 1024), groups = (N + 15) / 16;
-        const long nwaves = (long)B * tpp * groups;
-        const unsigned blocks = (unsigned)((nwaves + 3) / 4);
-        if (add) hipLaunchKernelGGL(scatter_out_wave_kernel<true>, dim3(blocks), dim3(256), 0, st, x, ws, out, M, N, (int)HW, tpp, groups, nwaves);
-        else hipLaunchKernelGGL(scatter_out_wave_kernel<false>, dim3(blocks), dim3(256), 0, st, x, ws, out, M, N, (int)HW, tpp, groups, nwaves);
-        return last_error();
-    }
     // in-kernel index build (round 4, key 37): cover for every M (an LDS atomic per entity); add where the LDS kernel is taken
     // anyway (maps up to 8 KB) and the quadratic chain search is small against the workgroup's output
     // (add: measured -13 % at 32 x 32 maps with 128 entities, +15 % at the reference's 16 x 16 test shape with 256, where four
     // workgroups per batch element each repeat a build that outweighs their 64 KB of output)
-    const bool build = g_scatter_build && W > 0 && (!add || (M <= 1024 && (g_scatter_build >= 2 || (M <= 256 && HW >= 1024))));
+    const bool build = g_scatter_build && W > 0 && (!add || (M <= 256 && HW >= 1024));
     // (`add` on large maps: the LDS kernel + build at 32 / 64 channels per workgroup = key 37 = 2 / 3, measured against the
     // cells-per-thread kernel behind the index launch -- see DESIGN.md 4.5)
-    const bool lds_pays = !add || HW * 4 <= 8 * 1024 || g_scatter_npb != 0 || (build && g_scatter_build >= 2);
+    const bool lds_pays = !add || HW * 4 <= 8 * 1024 || g_scatter_npb != 0;
     if (g_scatter_lds_fwd && lds_pays && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0 && B <= 65535 &&
         (size_t)HW * 4 <= 32 * 1024) {
         const size_t fixed = (size_t)HW * 4 + (add ? (size_t)M * 4 : 0) + (add && build ? (size_t)((M + 3) & ~3) * 4 + 16 : 0);
-        const bool big = g_scatter_npb != 0 || (add && build && g_scatter_build == 3 && HW * 4 > 8 * 1024);
+        const bool big = g_scatter_npb != 0;
         const size_t cap = (size_t)(big ? 100 : 52) * 1024;
         int npb = 0;
         static const int kNpb[5] = {64, 32, 16, 8, 4};
@@ -1556,19 +1386,10 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     while (n_per_block > 4 && (long)B * cell_blocks * ((N + n_per_block - 1) / n_per_block) < 2048) n_per_block = (n_per_block / 2 + 3) / 4 * 4;
     const dim3 grid(cell_blocks, (N + n_per_block - 1) / n_per_block, B);
     if (v4) {
-        // in-kernel tables here only on request (key 37 >= 2): at C5 `add` 859 -> 875 us -- this kernel has no staging phase the
-        // build's round trip and barriers could hide behind, eight rounds of workgroups pay ~5 us each, more than the index launch
-        const bool b4 = g_scatter_build >= 2 && W > 0 && M > 0 && (!add || (M <= 256 && M <= tpb));
-        if (b4) {
-            const size_t lds = ((size_t)4 * tpb + (add ? 2 * (size_t)((M + 3) & ~3) : 0)) * 4;
-            if (add) hipLaunchKernelGGL((scatter_out4_kernel<true, true>), grid, dim3(tpb), lds, st, x, ws, out, M, N, (int)HW, n_per_block, location, W);
-            else hipLaunchKernelGGL((scatter_out4_kernel<false, true>), grid, dim3(tpb), lds, st, x, ws, out, M, N, (int)HW, n_per_block, location, W);
-            return last_error();
-        }
         build_index();
         if (rc) return rc;
-        if (add) hipLaunchKernelGGL((scatter_out4_kernel<true, false>), grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block, location, W);
-        else hipLaunchKernelGGL((scatter_out4_kernel<false, false>), grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block, location, W);
+        if (add) hipLaunchKernelGGL(scatter_out4_kernel<true>, grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
+        else hipLaunchKernelGGL(scatter_out4_kernel<false>, grid, dim3(tpb), 0, st, x, ws, out, M, N, (int)HW, n_per_block);
         return last_error();
     }
     build_index();
@@ -1587,22 +1408,6 @@ extern "C" int hpc_rll_scatter_connection_backward(const float* grad_out, const 
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
     const long plane_bytes = HW * 4;
-    {   // persistent pipelined kernel: planes that split into eight whole-KiB pieces, ring + gathered block within the LDS
-        constexpr int NBUF = 5;
-        const size_t lds = ((size_t)NBUF * HW + (size_t)M * (N + 1)) * 4;
-        if (g_scatter_bwd_stream && HW % 2048 == 0 && HW / 2048 <= 2 && M <= 256 && M > 0 && lds <= 150 * 1024 &&
-            (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0 && (long)B * N >= 4096) {
-            int cus = 0, dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (cus <= 0) cus = 256;
-            if (hipFuncSetAttribute((const void*)scatter_bwd_stream_kernel<NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-                hipSuccess)
-                return last_error();
-            hipLaunchKernelGGL(scatter_bwd_stream_kernel<NBUF>, dim3((unsigned)std::min<long>(B, cus)), dim3(1024), lds, st, grad_out,
-                               location, grad_x, B, M, N, H, W);
-            return last_error();
-        }
-    }
     if (plane_bytes <= 128 * 1024 && B <= 65535) {
         int NG = (int)std::min<long>(N, std::max<long>(1, (long)g_scatter_bwd_lds_kb * 1024 / plane_bytes));
         if (NG > 32) NG = 32;

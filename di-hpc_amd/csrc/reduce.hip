@@ -11,7 +11,6 @@
 #include "hpc_rll_hip.h"
 
 namespace hpc_rll {
-int g_scan_wave_target = 4096;   // in-process sweep (tests/tools/r02_scan_sweep.py): TD-lambda C3 16.9 -> 16.0 us vs 2048
 namespace {
 
 struct Scales { float s[8]; };

@@ -20,7 +20,7 @@
 
 namespace hpc_rll {
 
-int g_scan_fold = 1;   // fold the loss finalisation into the launch (tune key 21): 0 = launch + finalize kernel; 1 = grids up to kFoldMaxGrid; 2 = + counter tree up to kFoldMaxGridTree (measured neutral: profiles/r04_fold_tree.txt)
+int g_scan_fold = 1;   // fold the loss finalisation into the launch (tune key 21) for grids up to kFoldMaxGrid; 0 = launch + finalize kernel
 
 // Arrival tickets of the folded finalisation (colscan.hpp: ScanFold).  Zero at module load; every launch leaves its
 // ticket at zero.  A ticket must never be shared by two launches that can run concurrently:
@@ -30,8 +30,6 @@ int g_scan_fold = 1;   // fold the loss finalisation into the launch (tune key 2
 // When a pool is exhausted the caller gets nullptr and runs scan + finalize as two launches.
 constexpr int kStreamTickets = 1024, kGraphTickets = 3072;
 __device__ unsigned g_scan_tickets[kStreamTickets + kGraphTickets];
-// the arrival counters of large grids (ScanFold::sub): kFoldSub lines of 128 bytes per ticket
-__device__ unsigned g_scan_subtickets[(size_t)(kStreamTickets + kGraphTickets) * kFoldSub * 32];
 
 int categorical_forward(const float* logits, const int64_t* action, float* logp, float* ent, long rows, int N,
                         hipStream_t st);
@@ -50,14 +48,12 @@ struct TicketPool {
     std::mutex mu;
     struct Dev {
         unsigned* base = nullptr;
-        unsigned* sub_base = nullptr;
         bool tried = false;
         int next_stream = 0, next_graph = 0;
         std::unordered_map<hipStream_t, int> by_stream;
     } dev[64];
 };
-inline unsigned* scan_ticket(hipStream_t st, unsigned** sub = nullptr) {
-    if (sub) *sub = nullptr;
+inline unsigned* scan_ticket(hipStream_t st) {
     if (!g_scan_fold) return nullptr;
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
@@ -71,8 +67,6 @@ inline unsigned* scan_ticket(hipStream_t st, unsigned** sub = nullptr) {
         dv.tried = true;
         void* p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_scan_tickets)) == hipSuccess) dv.base = (unsigned*)p;
-        else (void)hipGetLastError();
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_scan_subtickets)) == hipSuccess) dv.sub_base = (unsigned*)p;
         else (void)hipGetLastError();
     }
     if (!dv.base) return nullptr;
@@ -88,7 +82,6 @@ inline unsigned* scan_ticket(hipStream_t st, unsigned** sub = nullptr) {
         }
     }
     if (idx < 0) return nullptr;
-    if (sub && dv.sub_base) *sub = dv.sub_base + (size_t)idx * kFoldSub * 32;
     return dv.base + idx;
 }
 // scan launch + finalisation of its NACC sums into `out` (x scale[k]): one launch when a ticket is available
@@ -283,13 +276,10 @@ struct UpgoOp {
 }  // namespace
 
 ScanFold make_fold(hipStream_t st, int nacc, const float* scale, float* out, long grid) {
-    ScanFold fold{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, nullptr};
-    const bool tree = grid > kFoldMaxGrid;
-    if (nacc < 1 || nacc > 8 || (tree && (g_scan_fold < 2 || grid > kFoldMaxGridTree))) return fold;
-    unsigned* sub = nullptr;
-    fold.ticket = scan_ticket(st, &sub);
-    if (!fold.ticket || (tree && !sub)) { fold.ticket = nullptr; return fold; }
-    if (tree) fold.sub = sub;
+    ScanFold fold{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    if (nacc < 1 || nacc > 8 || grid > kFoldMaxGrid) return fold;   // larger grids: partials + the finalize launch
+    fold.ticket = scan_ticket(st);
+    if (!fold.ticket) return fold;
     fold.out = out;
     for (int k = 0; k < nacc; ++k) fold.scale[k] = scale[k];
     return fold;

@@ -110,104 +110,38 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
                                  const float* g_logp, const float* coef_ent, const float* g_ent,
                                  float* grad_logits, int64_t rows, int N, void* stream);
 
-/* Tuning knobs for experiments (a measurement / test hook, not a serving API): process-global plain ints, not
- * synchronised -- set them while no other thread is launching work, and never between an LSTM forward and its backward
- * (the workspace layout depends on the split-K knobs).  key 0: cap of the categorical row kernels' grids in 256-thread workgroups per CU (1..1024,
- * default 1024: one slice of rows per short-lived workgroup; 24, the resident-and-looping shape of rounds 1-3, is 4-15 % slower).  key 1: k-depth of the fp32 GEMM tiles (16, 32, or 0 = chosen by operand layout).  key 2: threads per
- * block of the scatter output kernel (256/512/1024).  key 3: persistent small-batch LSTM path on (1) / off (0).
- * key 4: replicas of every exchange word of that path (1..32).  key 5: minimum hidden units per workgroup there.
- * key 6, key 7: split-K target / 128x128 tiles for the weight-gradient GEMMs.  key 8: layer-wavefront LSTM on/off.
- * key 9: LDS KiB per workgroup of the scatter backward kernel (16..128).  key 10: XCD-aware GEMM tile order on/off.
- * key 11: LSTM backward products against transposed weight copies (large batches) on/off.  key 12: 128x128 tiles
- * for the dh product when it runs as NN.  key 13: workgroups the latency-regime split-K aims for (default 256).
- * key 14: k-tiles (of 32) a slice must keep in the throughput-regime split-K (default 8).  key 15: smallest
- * ceil(H/256) that takes the 16-byte forward cell kernel (default 3, 0 = never).  key 16: 1 (default) = 256x256x16 GEMM
- * tiles with 16 waves per workgroup for interior products whose workgroup count is a multiple of the CU count (or >=
- * 4096) -- half the vector-memory instructions per MFMA of the 128x128 tile, bit-identical results; 0 = never.
- * key 17: LDS-staged streaming scatter forward kernel on (1, default) / off (0: the
- * round-1 cells-per-thread kernel).  key 18: channels per workgroup of that kernel (0 = largest of 64/32/16/8/4 whose
- * x tile fits 52 KB of LDS, or a multiple of 4 in 4..64).  key 19: waves a column-scan launch (TD-lambda, V-trace,
- * UPGO) aims for when it picks its waves per workgroup (256..16384, default 4096).  key 20: workgroups of the large-batch
- * LSTM backward cell (768 <= H <= 1024) that walks >= 8 batch rows per workgroup and keeps the bias / gamma / beta column sums (64..1024,
- * default 512 = two per CU; 0 = always one row per workgroup + a separate column-reduction pass).  key 21: every
- * scalar-loss forward (TD-lambda, V-trace, UPGO, PPO, q / dist / IQN / QR-DQN n-step TD) finalises its loss sums in the last
- * workgroup of its last launch: 1 (default) = grids up to 512 workgroups, 2 = grids up to 32768 (above 512 through 16 arrival
- * counters, round 4: measured neutral against the finalize launch at 1024 ... 8192 workgroups, profiles/r04_fold_tree.txt),
- * 0 = always a separate finalize launch (the same partials, summed in fp64 in the same order either way).
- * key 22: group-split algorithm of hpc_rll_oracle_split_group for key-sorted lists: 0 (default) = DP over the runs of
- * equal keys, 1 = the round-2 element-level paths (cross-check; identical results).
- * key 23: fp32 GEMM experiments on the 256x256 tile, a bit mask (default 0): bit 0 = s_setprio(1) around the MFMA
- * clusters, bit 1 = k-depth 32 instead of 16 (128 KB of LDS per workgroup); same k order, identical results.
- * key 24: samples per wave of the large-batch C51 / QR-DQN forwards (a wave loads the per-sample scalars of that many
- * consecutive samples coalesced, then walks them): 0 (default) = by batch size, 1 = never (the wave- / group-per-sample
- * kernels), or 8 / 16 / 32 / 64.
- * key 25: 1 (default) = fp32 GEMM products with BOTH operands contiguous along k ("NT") whose workgroups fill the chip in
- * whole rounds stage their tiles by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), on 256x128x16
- * tiles with 8 waves (two workgroups per CU) or 256x256x16 with 16; the LSTM then presents its large products in that form
- * (forward against weight copies transposed once per layer).  Each output is still one exact fp32 fma chain, in another
- * k order than the register-staged kernels.  TN products (both operands with their rows along k: the weight gradients)
- * take a DMA kernel with k-major tiles whose results are bit-identical to the register-staged kernel; NN products (A along
- * k, B along n) one that combines both tile forms (bit-identical to the NT DMA kernels).  2 = NT on the 256x256 tile only,
- * TN / NN on registers; 0 = register staging everywhere (round 2).
- * key 26: LayerNorm-LSTM at large batch (B >= 4096, B % 256 == 0, 768 <= H <= 1024, H % 64 == 0; gate-interleaved
- * pre-activations): 1 (default) = the recurrence of a layer's forward runs in ONE persistent kernel whose workgroups
- * (256 rows x 256 gate columns, one per CU) do the cell in the product's epilogue and synchronise per 256-row block
- * (lstm_block.hpp); 0 = one product + one cell launch per step (same layout, same saved tensors).  A bit mask: bit 0 the
- * persistent forward, bit 1 its 128-row variant (two workgroups per CU; measured slower), bit 2 libm instead of hardware
- * exp2 / reciprocal in its gates, bit 3 the persistent BACKWARD (128 rows x 128 hidden units per workgroup, full K, cell
- * adjoint and both LayerNorm adjoints in the product's epilogue; H % 128 == 0), bit 4 its k-depth 16 instead of 32, bit 5 its
- * k-depth 64, bit 6 its linear workgroup order, bit 7 the forward's exchanges without cache-wide fences (measured: 65.25 -> 65.14 ms
- * at the default start skew, 68.2 -> 65.5 without one -- the skew already hides what the fences cost).
- * Default 9 = forward + backward.  Forward and backward paths can be mixed freely (same saved tensors).
- * key 27: start skew of that kernel's row blocks in microseconds (0 ... 200, default 10): row block r waits r x this
- * before its first step, which spreads the HBM-bound epilogues of the row blocks over the step.
- * key 28: packed Pad1D (hpc_rll_pad1d_packed_forward, 32 <= max_len <= 16384): 1 (default) = wave-synchronous tiles of 1024
- * consecutive OUTPUT elements (their packed source is one contiguous span, staged through the wave's own LDS slice);
- * 0 = the round-3 kernel (16 rows per workgroup).  Identical results.
- * key 29: LayerNorm-LSTM forward at mid-size batches (5 <= B <= 256, 64 <= H <= 1024, H % 16 == 0): 1 or 2 = one
- * persistent kernel per layer -- Wh resident in LDS (16 gate columns per workgroup), the recurrent product on the matrix
- * cores straight from h_{s-1} in L2, two exchanges per step without cache-wide fences (lstm_mid.hpp); 2 (default) cuts the
- * batch into two independent streams (two 8-wave workgroups per CU: one stream's product runs while the other waits for
- * an exchange) where two copies of a Wh slice fit a CU's LDS; 0 = one split-K product + one cell launch per step.  Same
- * saved tensors (the backward is the step kernels' either way).
- * key 30: replicas (1 ... 32, default 8) of the words every workgroup of that kernel polls (its flags and final row
- * statistics): 256 pollers on one cache line cost 4.4 us per exchange, a single one sees a store after 0.6 us.
- * key 31: one-hot gradients (the backward of the q / dist / IQN / QR-DQN n-step TD losses: all zeros except K values per
- * sample): outputs of at least this many MiB (default 3072; 0 = never) with K >= 16 are written as a fill in the store
- * pattern that reaches the part's write rate (one 256-thread workgroup per CU, grid-stride, 16-byte stores: 6.3-6.5 TB/s
- * against 4.5-5.9 for every other shape of the same loop) plus a second launch for the values.  Identical results.
- * key 32: PPO forward (hpc_rll_ppo_forward) for rows of up to 512 logits: 1 (default) = ONE launch -- a lane group reads the
- * same row of both policy heads, its last lane applies the per-sample loss, the sums are folded by the last workgroup;
- * 0 = two categorical launches + the sample launch.  Same per-sample coefficients (the backward's inputs), the five sums
- * add the rows in another grouping.
- * key 33: the persistent mid-batch LSTM BACKWARD (the shapes of key 29; one launch per layer: the LayerNorm-adjoint row sums
- * and dHW exchanged on the forward kernel's protocol, dh_prev = dHW @ Wh^T on v_mfma_f32_4x4x1_16b_f32 against rows of Wh
- * resident in LDS): 1 (default) = where it is faster than one cell launch + one split-K product per step (B <= 32: every
- * workgroup reads all of dHW_s, four times the forward's exchange, and above that the step kernels win), 2 = every shape of
- * key 29, 0 = off.  Same outputs to rounding.
- * key 34: scatter-connection backward as ONE persistent software-pipelined kernel (a workgroup per CU walks whole batch elements;
- * LDS-DMA keeps four planes in flight into a five-plane ring while the landed plane is gathered; a batch element's (M, N) block is
- * written once, contiguous): 1 = on (planes of 2048 or 4096 elements, M <= 256), 0 (default) = one workgroup per (batch element,
- * channel group) -- an experiment that lost: 1.25 against 0.865 ms at 4096 x 64 planes of 64 x 64.  Identical results.
- * key 35: 16-byte quads per workgroup of the one-launch one-hot gradient kernel: 0 (default) = by output size (256 -- one per
- * thread, a 4 KiB block per workgroup -- from 256 MiB, 1024 below), or 256 ... 8192.  Identical results.
- * key 36: the nap between failed polls of every persistent LSTM kernel, in 64-cycle units: 1 (default) ... 8 (shipped until round
- * 4; 1.5-5 % slower forward, 1-2.4 % slower backward at small batch, profiles/r04_persist_nap.txt).  The value reaches the device
- * with the next persistent launch outside stream capture (one blocking 4-byte copy).  Identical results.
- * key 37: scatter-connection forward builds its owner table / chain links in LDS inside the LDS-staged output kernel: 1 (default)
- * = cover for every M, add for M <= 256 on maps of 1024 ... 2048 cells (no index launch, no index in memory: cover at C5 874 ->
- * 812 us); 2 / 3 = add wherever M <= 1024, on large maps through the LDS kernel at 32 / 64 channels per workgroup, and in the
- * cells-per-thread kernels (all measured slower: C5 add 859 -> 922 / 901 / 875 us); 0 = the index launch of rounds 1-3 for every
- * path.  Identical results.
- * key 38: scatter-connection backward runs the channel groups of one batch element on ONE XCD (their pieces of the same grad_x
- * lines then meet in one L2 instead of being written back masked from eight): 1 (default) = where a workgroup's piece of an entity row
- * is at most 32 bytes (C5: 860 -> 792 us; M = 1024, N = 128 on 64 x 64 maps: 406 -> 280 us), 2 = always (64-byte pieces +6 %, whole
- * lines +4 %), 0 = launch order.  Identical results.
- * key 39: mid-batch LSTM forward kernel with neighbouring workgroups (the two halves of the same 128-byte lines of the saved
- * tensors) on one XCD: 0 (default) = launch order, 1 = on (an experiment: -6 % at B = 128, H = 512, +1.5 ... 4.5 % at three other
- * shapes, profiles/r04_lstm_mid_xcd.txt).  Identical results.
- */
+/* Path switches (a test / measurement hook, not a serving API; csrc/tune.hip holds the table): process-global plain ints,
+ * not synchronised -- set them while no other thread is launching work, and never between an LSTM forward and its backward.
+ * Every key selects between paths that BOTH ship (each wins on some shapes under the default rule), so that tests can run one
+ * against the other on the same inputs; key 3 is also the deployment switch for GPUs shared between processes.  The launch
+ * parameters and the measured-and-rejected variants that rounds 1-4 exposed as keys 0-2, 4-7, 9-15, 19, 20, 23, 30, 34, 36, 39
+ * are constants / gone (HISTORY.md has what each measured); those keys answer HPC_RLL_EINVAL.
+ *   key  3  persistent (co-residency dependent) LSTM kernels: 1 (default) / 0 = step kernels only
+ *   key  8  B <= 4, L >= 2: 1 (default) = all layers in one launch as a wavefront / 0 = one persistent kernel per layer
+ *   key 16  256x256x16 GEMM tiles (16 waves) for interior products that fill the chip in whole rounds: 1 (default) / 0
+ *   key 17  ScatterConnection forward: 1 (default) = LDS-staged streaming kernel where it applies / 0 = cells-per-thread kernel
+ *   key 18  channels per workgroup of that kernel (a multiple of 4 up to 64; 0, default = by LDS budget)
+ *   key 21  loss finalisation folded into the last workgroup of the launch (grids up to 512): 1 (default) / 0 = finalize launch
+ *   key 22  group split of the padding ops: 0 (default) = runs of equal keys / 1 = the element-level DP
+ *   key 24  samples per wave of the large-batch C51 / QR-DQN forwards: 0 (default) by batch size, 1 off, 8 / 16 / 32 / 64
+ *   key 25  LDS-DMA staged GEMM tiles: 1 (default) all forms / 2 the 256x256 NT tile only / 0 register staging
+ *   key 26  large-batch LSTM (B >= 4096, B % 256 == 0, 768 <= H <= 1024, H % 64 == 0) row-block kernels, a bit mask: bit 0 the
+ *           persistent forward, bit 3 the persistent backward (H % 128 == 0), bit 7 fence-free forward exchanges; default 9;
+ *           0 = one product + one cell launch per step on the same layout (forward / backward paths mix freely)
+ *   key 27  start skew of those kernels' row blocks in microseconds (0 ... 200, default 10)
+ *   key 28  packed Pad1D (32 <= max_len <= 16384): 1 (default) = wave tiles in output space / 0 = the workgroup kernel
+ *   key 29  mid-batch persistent LSTM forward (5 <= B <= 256, 64 <= H <= 1024, H % 16 == 0): 0 off / 1 one stream / 2 (default)
+ *           two batch streams where two copies of a Wh slice fit a CU's LDS
+ *   key 31  one-hot gradients of at least this many MiB are written as fill + values (default 3072; 0 = never)
+ *   key 32  PPO forward in one launch: 1 (default) / 0 = three launches
+ *   key 33  mid-batch persistent LSTM backward: 0 off / 1 (default) where it pays (B <= 32) / 2 every mid-batch shape
+ *   key 35  16-byte quads per workgroup of the one-launch one-hot kernel (256 ... 8192; 0, default = by size)
+ *   key 37  scatter owner table / chain links built inside the forward kernel: 1 (default) / 0 = index launch
+ *   key 38  scatter backward in XCD-major workgroup order: 1 (default) where its pieces are below a 64-byte sector pair / 2 always / 0
+ * hpc_rll_tune_count / hpc_rll_tune_doc enumerate the live keys (index 0 ... count-1 -> key number and a one-line description). */
 int hpc_rll_tune_set(int key, int value);
+int hpc_rll_tune_count(void);
+const char* hpc_rll_tune_doc(int index, int* key);
 
 /* TD(lambda) -- replaces TdLambdaForward/Backward (rl_utils/entry.h:68-77, src/rl_utils/td_lambda.cu:8-52).
  * value (T+1,B), reward (T,B), weight: mode 0 none, 1 (B,), 2 (T,B).  loss (1,) =

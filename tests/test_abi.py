@@ -82,20 +82,37 @@ def test_argument_errors_are_status_codes_not_crashes():
 
 
 def test_tuning_knobs_documented_and_guarded():
-    """hpc_rll_tune_set is host-only code: every key the header documents accepts its shipped default and rejects an
-    out-of-range value with a status (no GPU needed); an undocumented key is an argument error."""
+    """hpc_rll_tune_set is host-only code with ONE table (csrc/tune.hip, round 5): at most 20 live keys (VERDICT r04 item 7 --
+    there were 40), each documented in the header, accepting its shipped default and rejecting an out-of-range value with a
+    status (no GPU needed); the keys retired in round 5 and undocumented keys are argument errors."""
+    import ctypes
     import re
     import cabi as N
     hdr = open(N.HEADER_PATH).read()
-    doc = hdr[hdr.index("Tuning knobs"):hdr.index("int hpc_rll_tune_set")]
-    keys = sorted({int(k) for k in re.findall(r"key (\d+)", doc)})
-    assert keys == list(range(len(keys))) and len(keys) >= 26, keys
-    defaults = {0: 1024, 1: 0, 2: 1024, 3: 1, 4: 4, 5: 0, 6: 768, 7: 1, 8: 1, 9: 64, 10: 1, 11: 1, 12: 1, 13: 256, 14: 8,
-                15: 3, 16: 1, 17: 1, 18: 0, 19: 4096, 20: 512, 21: 1, 22: 0, 23: 0, 24: 0, 25: 1, 26: 9, 27: 10, 28: 1, 29: 2, 30: 8, 31: 3072, 32: 1, 33: 1, 34: 0, 35: 0, 36: 1, 37: 1, 38: 1, 39: 0}
-    for k in keys:
+    doc = hdr[hdr.index("Path switches"):hdr.index("int hpc_rll_tune_set")]
+    documented = sorted({int(k) for k in re.findall(r"^ \*   key +(\d+) ", doc, flags=re.M)})
+    N.lib.hpc_rll_tune_count.restype = ctypes.c_int
+    N.lib.hpc_rll_tune_doc.restype = ctypes.c_char_p
+    N.lib.hpc_rll_tune_doc.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    n = N.lib.hpc_rll_tune_count()
+    live = []
+    for i in range(n):
+        k = ctypes.c_int(-1)
+        text = N.lib.hpc_rll_tune_doc(i, ctypes.byref(k))
+        assert text and len(text) > 20
+        live.append(k.value)
+    assert N.lib.hpc_rll_tune_doc(n, None) is None
+    assert sorted(live) == documented and len(live) <= 20, (sorted(live), documented)
+    defaults = {3: 1, 8: 1, 16: 1, 17: 1, 18: 0, 21: 1, 22: 0, 24: 0, 25: 1, 26: 9, 27: 10, 28: 1, 29: 2, 31: 3072, 32: 1, 33: 1, 35: 0,
+                37: 1, 38: 1}
+    assert sorted(defaults) == documented
+    for k in live:
         assert N.lib.hpc_rll_tune_set(k, defaults[k]) == 0, k
         assert N.lib.hpc_rll_tune_set(k, -7) != 0, k
-    assert N.lib.hpc_rll_tune_set(len(keys), 0) != 0
+    for k in (0, 1, 2, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 19, 20, 23, 30, 34, 36, 39, 40, 99):   # retired / never existed
+        assert N.lib.hpc_rll_tune_set(k, 0) != 0 and N.lib.hpc_rll_tune_set(k, 1) != 0, k
+    assert N.lib.hpc_rll_tune_set(26, 2) != 0 and N.lib.hpc_rll_tune_set(26, 137) == 0 and N.lib.hpc_rll_tune_set(26, 9) == 0   # bit mask
+    assert N.lib.hpc_rll_tune_set(21, 2) != 0 and N.lib.hpc_rll_tune_set(17, 2) != 0 and N.lib.hpc_rll_tune_set(37, 2) != 0   # retired values
 
 
 def test_c_program_links_and_runs(tmp_path):
@@ -117,7 +134,7 @@ def test_c_program_links_and_runs(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and "abi 4 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    assert r.returncode == 0 and "abi 5 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
 def test_xcd_relabelling_is_a_permutation():

@@ -686,49 +686,3 @@ def test_folded_finalisation_under_concurrency():
     for i in range(nstream):
         allv = torch.stack(got[i]).cpu()
         assert torch.equal(allv, want[i].expand_as(allv)), (i, (allv - want[i]).abs().max())
-
-
-@pytest.mark.parametrize("B", [4104, 20000, 65536])
-def test_counter_tree_finalisation_large_grids(B):
-    """Grids above 512 workgroups (tune key 21 = 2, round 4, off by default): a launch arrives through 16 counters on lines of their own, the last arrival
-    of each counter arrives at the stream's ticket, the last of those adds the partials (csrc/colscan.hpp).  Every loss and every
-    gradient buffer equals the separate finalize launch's (key 21 = 0) bit for bit -- q / dist / IQN / QR-DQN n-step TD at 513 ... 8192
-    workgroups, ragged grids included, two streams interleaved, repeated launches (the counters must be back at zero)."""
-    import hpc_rl_utils as U
-    from hpc_rll.rl_utils.td import DistNStepTD, IQNNStepTDError, QNStepTD, QRDQNNStepTDError
-    N, nstep, tau, n_atom = 8, 3, 32, 51
-    g = torch.Generator(device=DEV).manual_seed(B)
-    q, nq = torch.randn(B, N, device=DEV, generator=g), torch.randn(B, N, device=DEV, generator=g)
-    a, na = torch.randint(0, N, (B,), device=DEV, generator=g), torch.randint(0, N, (B,), device=DEV, generator=g)
-    r, done = torch.randn(nstep, B, device=DEV, generator=g), (torch.rand(B, device=DEV, generator=g) < 0.1).float()
-    w = torch.rand(B, device=DEV, generator=g)
-    d = torch.softmax(torch.randn(B, N, n_atom, device=DEV, generator=g), -1)
-    nd = torch.softmax(torch.randn(B, N, n_atom, device=DEV, generator=g), -1)
-    qi, nqi = torch.randn(tau, B, N, device=DEV, generator=g), torch.randn(tau, B, N, device=DEV, generator=g)
-    rq = torch.rand(tau, B, device=DEV, generator=g)
-    qq, nqq = torch.randn(B, N, tau, device=DEV, generator=g), torch.randn(B, N, tau, device=DEV, generator=g)
-    ops = [lambda: QNStepTD(nstep, B, N)(q, nq, a, na, r, done, w, 0.99),
-           lambda: DistNStepTD(nstep, B, N, n_atom)(d, nd, a, na, r, done, w, 0.99, -10.0, 10.0),
-           lambda: IQNNStepTDError(tau, tau, nstep, B, N)(qi, nqi, a, na, r, done, rq, 0.99, 1.0, w),
-           lambda: QRDQNNStepTDError(tau, nstep, B, N)(qq, nqq, a, na, r, done, 0.99, w)]
-
-    def run():
-        with torch.no_grad():
-            return [torch.stack([x.reshape(-1)[0] if x.numel() else x for x in op()[:1]]) for op in ops]
-    try:
-        U.tune_set(21, 0)
-        want = [x.cpu() for x in run()]
-        U.tune_set(21, 2)
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        got = []
-        torch.cuda.synchronize()
-        for _ in range(20):
-            for s in streams:
-                with torch.cuda.stream(s):
-                    got.append(run())
-        torch.cuda.synchronize()
-    finally:
-        U.tune_set(21, 1)
-    for gs in got:
-        for x, y in zip(gs, want):
-            assert torch.equal(x.cpu(), y)

@@ -434,9 +434,9 @@ def test_lstm_persistent_path_matches_step_path(S, B, I, H, L):
             assert rel_err(o, got) < max(base, 2.0 * rel_err(o, a)), (k, rel_err(o, got), rel_err(o, a))
 
 
-# key 26 (bit mask): 1 persistent forward, +2 its 128-row blocks (two per CU), +4 libm gate functions, +8 persistent backward, +16 its k-depth 16,
-# +128 the forward's exchanges without cache-wide fences (write-through stores, agent-scope loads of the partials)
-@pytest.mark.parametrize("mode", [9, 1, 8, 11, 13, 25, 137])
+# key 26 (bit mask): 1 persistent forward, +8 persistent backward, +128 the forward's exchanges without cache-wide fences
+# (write-through stores, agent-scope loads of the partials; the backward's exchanges are always of that kind)
+@pytest.mark.parametrize("mode", [9, 1, 8, 137])
 @pytest.mark.parametrize("S,B,I,H,L,p,skew", [(6, 4096, 192, 768, 2, 0.0, 0), (4, 4096, 64, 1024, 1, 0.0, 7), (3, 8192, 48, 960, 1, 0.0, 0),
                                               (5, 4096, 36, 896, 2, 0.3, 0)])
 def test_lstm_row_block_kernel_matches_step_kernels(S, B, I, H, L, p, skew, mode):
