@@ -811,7 +811,8 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
     if (cfg.g == G_ && cfg.vec == V_ && cfg.e == E_) {                                                                    \
         const long per = (256 / G_) * 4;                                                                                  \
         long grid = (rows + per - 1) / per;                                                                               \
-        const long gmax = kFoldMaxGrid;   /* (2048 / 4096 workgroups + a finalize launch: slower, round 4) */             \
+        const long gmax = kFoldMaxGrid;   /* (2048 / 4096 workgroups + a finalize launch: slower, round 4; 1024-thread */ \
+                                          /*  workgroups instead of looping 256-thread ones: 22 -> 27.5 us, round 5)   */ \
         if (grid > gmax) grid = gmax;                                                                                     \
         const ScanFold fold = make_fold(st, PpoOp::NACC, scales, out5, grid);                                             \
         hipLaunchKernelGGL((ppo_fwd_fused_kernel<G_, V_, E_>), dim3((unsigned)grid), dim3(256), 0, st, logits_new,        \

@@ -37,28 +37,48 @@ inline int last_error() {
     return e == hipSuccess ? HPC_RLL_OK : (int)e;
 }
 
-// Generic "one lane per sample + NACC sums" kernel.  grid = ceil(n/256) workgroups (<= partial capacity).
-template <class Op>
-__global__ __launch_bounds__(256) void sample_kernel(const Op op, long n, float* __restrict__ partials,
-                                                     const ScanFold fold) {
-    constexpr int NACC = Op::NACC;
-    __shared__ float red[NACC * 4];
+// Generic "one lane per sample + NACC sums" kernel: workgroups of NT threads walk the samples grid-stride.
+// Round 5: the launch keeps its grid within the fold's 512 workgroups (colscan.hpp) -- batches above 131072 samples take
+// 1024-thread workgroups, above 524288 the workgroups loop -- so the loss is finalised inside the launch at every batch size
+// (q n-step TD at B = 262144 used to be 1024 workgroups + a finalize launch: two dependent launches for 17 us of work).
+template <class Op, int NT>
+__global__ __launch_bounds__(NT) void sample_kernel(const Op op, long n, float* __restrict__ partials,
+                                                    const ScanFold fold) {
+    constexpr int NACC = Op::NACC, NWV = NT / 64;
+    __shared__ float red[NACC * NWV];
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) op(i, acc);
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) op(i, acc);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
         const float s = wave_sum(acc[k]);
-        if (lane == 0) red[k * 4 + w] = s;
+        if (lane == 0) red[k * NWV + w] = s;
     }
     __syncthreads();
     float sum = 0.f;
-    if (threadIdx.x < NACC)
-        sum = (red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1]) + (red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
-    publish_sums<NACC, 256>(sum, partials, fold);   // with a fold: the last workgroup also finalises the sums (colscan.hpp)
+    if (threadIdx.x < NACC) {
+        if (NWV == 4) sum = (red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1]) + (red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
+        else
+            for (int i = 0; i < NWV; ++i) sum += red[threadIdx.x * NWV + i];
+    }
+    publish_sums<NACC, NT>(sum, partials, fold);   // with a fold: the last workgroup also finalises the sums (colscan.hpp)
+}
+// launch + finalisation of the NACC sums into `out` (x scale[k])
+template <class Op>
+inline int launch_sample(const Op& op, long n, float* partials, int nacc, const float* scale, float* out, hipStream_t st) {
+    const bool wide = (n + 255) / 256 > kFoldMaxGrid;
+    const long nt = wide ? 1024 : 256;
+    long blocks = (n + nt - 1) / nt;
+    if (blocks > kFoldMaxGrid) blocks = kFoldMaxGrid;
+    const ScanFold fold = make_fold(st, nacc, scale, out, blocks);
+    if (wide) hipLaunchKernelGGL((sample_kernel<Op, 1024>), dim3((unsigned)blocks), dim3(1024), 0, st, op, n, partials, fold);
+    else hipLaunchKernelGGL((sample_kernel<Op, 256>), dim3((unsigned)blocks), dim3(256), 0, st, op, n, partials, fold);
+    const hipError_t e = hipGetLastError();
+    const int rc = e == hipSuccess ? HPC_RLL_OK : (int)e;
+    if (rc || fold.out) return rc;
+    return finalize_sums(partials, (int)blocks, nacc, scale, out, st);
 }
 
 // ---------------------------------------------------------------------------------------------- q n-step TD
@@ -252,12 +272,7 @@ extern "C" int hpc_rll_ppo_forward(const float* logits_new, const float* logits_
     if (rc) return rc;
     rc = categorical_forward(logits_old, action, lpo, nullptr, B, N, st);
     if (rc) return rc;
-    const int blocks = (B + 255) / 256;
-    const ScanFold fold = make_fold(st, 5, sc, out5, blocks);
-    hipLaunchKernelGGL(sample_kernel<PpoOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials, fold);
-    rc = last_error();
-    if (rc || fold.out) return rc;
-    return finalize_sums(partials, blocks, 5, sc, out5, st);
+    return launch_sample(op, (long)B, partials, 5, sc, out5, st);
 }
 
 extern "C" int hpc_rll_ppo_backward(const float* g_policy, const float* g_value, const float* g_ent,
@@ -294,12 +309,7 @@ extern "C" int hpc_rll_q_nstep_td_forward(const float* q, const float* next_n_q,
         return HPC_RLL_EINVAL;
     QNStepOp op{q, next_n_q, action, next_n_action, reward, done, weight, td_err, grad_buf,
                 nstep, B, N, gamma, (float)pow((double)gamma, (double)nstep), scale, rescale};
-    const int blocks = (B + 255) / 256;
-    const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);
-    hipLaunchKernelGGL(sample_kernel<QNStepOp>, dim3(blocks), dim3(256), 0, st, op, (long)B, partials, fold);
-    const int rc = last_error();
-    if (rc || fold.out) return rc;
-    return finalize_sums(partials, blocks, 1, &scale, loss, st);
+    return launch_sample(op, (long)B, partials, 1, &scale, loss, st);
 }
 
 extern "C" int hpc_rll_q_nstep_td_backward(const float* grad_loss, const float* grad_buf, const int64_t* action,
