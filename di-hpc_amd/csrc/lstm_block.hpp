@@ -515,7 +515,10 @@ struct BlockBwd {
 //     are the 4 MB of operands a 128 x 128 tile pulls through L2 per step (twice the forward tile's bytes per flop);
 //   * two-row epilogue chunks in four register sets (three chunks of loads in flight instead of one): 157 spill instructions
 //     inside pass A, pass A 33 -> 96 us; start skew by XCD instead of by row block (the four row blocks of an XCD in step, Wh
-//     tiles shared through its L2): 133.6 against 133.2 ms.  Neither shipped.
+//     tiles shared through its L2): 133.6 against 133.2 ms.  Neither shipped;
+//   * 128 x 64 tiles with TWO 4-wave workgroups per CU (one's epilogue under the other's product; commit 7e6db35): 136.2 against
+//     134.5 ms -- a lone wave per SIMD does not drive the matrix pipe at twice its shared rate, the operand bytes per flop grow
+//     1.5 x, the epilogue passes slow down beside the partner's product (profiles/r05_lstm_bwd_bn_probe.txt).
 // BN hidden units per workgroup: 128 = 8 waves, ONE workgroup per CU (rounds 4-5); 64 = 4 waves, TWO workgroups per CU (round 5
 // experiment: while one workgroup is in its exchanges / epilogue passes -- 65 of its 330 us step, during which the CU's matrix
 // pipe idles -- the other one's product has the pipe; costs 1.5 x the operand bytes per flop).

@@ -2,7 +2,8 @@
 """Round 5: C4 LSTM backward with the row-block backward kernel on 128 rows x 128 units (one workgroup per CU, key 26 = 9) against
 128 rows x 64 units (two workgroups per CU, key 26 = 25), one process, interleaved; gradient checksums must agree to rounding
 (the row sums are combined from the same 32-unit partials in the same order: bit-identical expected).
-HPC_RLL_LSTM_PROFILE=1 prints one workgroup's phase times."""
+HPC_RLL_LSTM_PROFILE=1 prints one workgroup's phase times.
+(The 64-unit variant lives in commit 7e6db35 only; measured slower -- profiles/r05_lstm_bwd_bn_probe.txt -- and reverted.)"""
 import os
 import statistics
 import sys
