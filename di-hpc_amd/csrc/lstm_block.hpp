@@ -519,26 +519,21 @@ struct BlockBwd {
 //   * 128 x 64 tiles with TWO 4-wave workgroups per CU (one's epilogue under the other's product; commit 7e6db35): 136.2 against
 //     134.5 ms -- a lone wave per SIMD does not drive the matrix pipe at twice its shared rate, the operand bytes per flop grow
 //     1.5 x, the epilogue passes slow down beside the partner's product (profiles/r05_lstm_bwd_bn_probe.txt).
-// BN hidden units per workgroup: 128 = 8 waves, ONE workgroup per CU (rounds 4-5); 64 = 4 waves, TWO workgroups per CU (round 5
-// experiment: while one workgroup is in its exchanges / epilogue passes -- 65 of its 330 us step, during which the CU's matrix
-// pipe idles -- the other one's product has the pipe; costs 1.5 x the operand bytes per flop).
-template <int BN_> struct BlkBwdCfg {
-    static constexpr int NBUF = 2, BK = 32, BM = 128, BN = BN_, NTH = 4 * BN_, WN = BN_ / 32;
+struct BlkBwdCfg {
+    static constexpr int NBUF = 2, BK = 32, BM = 128, BN = 128, NTH = 512;
     static constexpr int tile_floats = NBUF * BK * (BM + BN);   // operand tiles; their first 32 * NTH floats are also the
                                                                 // accumulator dump [32][NTH] of the epilogue
     static_assert(tile_floats >= 32 * NTH, "accumulator dump");
     static constexpr int lds_floats = tile_floats + BM * 4 + BM * 4 + 3 * 4 * BN;   // + stats, sums, column sums
-    static constexpr size_t lds_bytes = BN_ == 128 ? 96 * 1024 : 72 * 1024;   // one / exactly two workgroups per CU (160 KB)
-    static constexpr int wgs_per_cu = BN_ == 128 ? 1 : 2;
+    static constexpr size_t lds_bytes = 96 * 1024;   // more than half of the 160 KB: one workgroup per CU
     static_assert(lds_floats * sizeof(float) <= lds_bytes, "row-block backward LDS");
 };
 
 // RC rows per load chunk of the two epilogue passes: 32 / RC chunks in NS = 8 / RC statically indexed register sets, NS - 1
 // chunks of loads in flight ahead of the arithmetic.
-template <int BN_>
-__global__ __launch_bounds__(4 * BN_, 2) void lstm_block_bwd_kernel(const BlockBwd a) {
-    typedef BlkBwdCfg<BN_> C;
-    constexpr int NBUF = C::NBUF, RC = 4, BK = C::BK, BM = C::BM, BN = C::BN, NTH = C::NTH, WN = C::WN, NQ = BK / 8, NS = 8 / RC, NCH = 32 / RC;
+__global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a) {
+    typedef BlkBwdCfg C;
+    constexpr int NBUF = C::NBUF, RC = 4, BK = C::BK, BM = C::BM, BN = C::BN, NTH = C::NTH, NQ = BK / 8, NS = 8 / RC, NCH = 32 / RC;
     constexpr bool FAST = true, NF = true;
     constexpr int SC = 16;   // sc1 (write-through / L1-bypassing) on the exchanged stores and loads
     extern __shared__ __attribute__((aligned(16))) float blk_lds[];
@@ -569,7 +564,7 @@ __global__ __launch_bounds__(4 * BN_, 2) void lstm_block_bwd_kernel(const BlockB
     const int unit = nt * BN + wn * 32 + i32;
     unsigned* const flag_s = a.flags + 2 * rbl;
     unsigned* const flag_h = flag_s + 1;
-    float* const part = a.part + (size_t)rbl * 2 * WN * nnt * BM * 4;
+    float* const part = a.part + (size_t)rbl * 2 * 4 * nnt * BM * 4;
     const vfloat4 gx = *reinterpret_cast<const vfloat4*>(a.pp + 4 * unit);
     const vfloat4 gh = *reinterpret_cast<const vfloat4*>(a.pp + G + 4 * unit);
     const vfloat4 bx = *reinterpret_cast<const vfloat4*>(a.pp + 2 * G + 4 * unit);
@@ -738,12 +733,12 @@ __global__ __launch_bounds__(4 * BN_, 2) void lstm_block_bwd_kernel(const BlockB
                 }
             }
         }
-        float* const pslot = part + (size_t)(s & 1) * WN * nnt * BM * 4;
+        float* const pslot = part + (size_t)(s & 1) * 4 * nnt * BM * 4;
         const __amdgpu_buffer_rsrc_t r_ps = blk_rsrc(pslot);
         {
             const int rr = i32 & 15;
             const int row = wm * 64 + (i32 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-            blk_st4<SC>(my, r_ps, (unsigned)(((WN * nt + wn) * BM + row) * 16), 0u);
+            blk_st4<SC>(my, r_ps, (unsigned)(((4 * nt + wn) * BM + row) * 16), 0u);
         }
         block_arrive(flag_s, NF);
         HPC_RLL_BLK_TICK(2)
@@ -751,14 +746,14 @@ __global__ __launch_bounds__(4 * BN_, 2) void lstm_block_bwd_kernel(const BlockB
         HPC_RLL_BLK_TICK(3)
         if (tid < BM) {
             vfloat4 t = {0.f, 0.f, 0.f, 0.f};
-            for (int c0 = 0; c0 < WN * nnt; c0 += 8) {
+            for (int c0 = 0; c0 < 4 * nnt; c0 += 8) {
                 vfloat4 p[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    p[k] = blk_ld4<SC>(r_ps, (unsigned)(tid * 16), (unsigned)((c0 + k < WN * nnt ? c0 + k : 0) * BM * 16));
+                    p[k] = blk_ld4<SC>(r_ps, (unsigned)(tid * 16), (unsigned)((c0 + k < 4 * nnt ? c0 + k : 0) * BM * 16));
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (c0 + k < WN * nnt) t += p[k];
+                    if (c0 + k < 4 * nnt) t += p[k];
             }
             *reinterpret_cast<vfloat4*>(sa + tid * 4) = t * inv_g;
         }
@@ -851,50 +846,42 @@ constexpr int kBlockBwdMaxRowBlocks = kCellRowsMaxWgs;   // (lstm.hip, above thi
 inline bool lstm_block_bwd_shape(int B, int H) {
     return lstm_perm_shape(B, H) && H % 128 == 0 && B % 128 == 0 && B / 128 <= kBlockBwdMaxRowBlocks;
 }
-// BN = 128 (one workgroup per CU) or 64 (two per CU): hpc_rll_tune_set key 26 bit 4 (round-5 experiment)
-inline int block_bwd_bn() { return (g_lstm_block & 16) ? 64 : 128; }
-template <int BN> inline int block_bwd_rows_per_launch_t(int H) {
-    const int nnt = H / BN;
-    return nnt > 0 ? persist_cu_count() * BlkBwdCfg<BN>::wgs_per_cu / nnt : 0;
+inline int block_bwd_rows_per_launch(int H) {
+    const int nnt = H / 128;
+    return nnt > 0 ? persist_cu_count() / nnt : 0;
 }
-inline int block_bwd_rows_per_launch(int H) { return block_bwd_bn() == 64 ? block_bwd_rows_per_launch_t<64>(H) : block_bwd_rows_per_launch_t<128>(H); }
-inline size_t block_bwd_part_floats(int B, int H) { return (size_t)(B / 128) * 2 * (H / 32) * 128 * 4; }
-template <int BN> inline bool block_bwd_resident_t(int H) {
-    const int per = block_bwd_rows_per_launch_t<BN>(H);
-    return per >= 1 && persist_resident_t(lstm_block_bwd_kernel<BN>, 4 * BN, (H / BN) * per, BlkBwdCfg<BN>::lds_bytes);
+inline size_t block_bwd_part_floats(int B, int H) { return (size_t)(B / 128) * 2 * 4 * (H / 128) * 128 * 4; }
+inline bool block_bwd_resident(int H) {
+    const int per = block_bwd_rows_per_launch(H);
+    return per >= 1 && persist_resident_t(lstm_block_bwd_kernel, 512, (H / 128) * per, BlkBwdCfg::lds_bytes);
 }
 inline bool block_bwd_ok(int B, int H, hipStream_t st) {
     if (!(g_lstm_block & 8) || !g_lstm_persist || !lstm_block_bwd_shape(B, H) || !persist_runtime_ready(st)) return false;
-    const int bn = block_bwd_bn();
-    if (!block_launches_fill(B / 128, block_bwd_rows_per_launch(H), H / bn / (bn == 64 ? 2 : 1))) return false;
-    return bn == 64 ? block_bwd_resident_t<64>(H) : block_bwd_resident_t<128>(H);
+    if (!block_launches_fill(B / 128, block_bwd_rows_per_launch(H), H / 128)) return false;
+    return block_bwd_resident(H);
 }
-template <int BN>
-inline int launch_block_bwd_t(BlockBwd a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
-    typedef BlkBwdCfg<BN> C;
-    const int nrb = a.B / 128, per = block_bwd_rows_per_launch_t<BN>(a.H);
+inline int launch_block_bwd(BlockBwd a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
+    typedef BlkBwdCfg C;
+    const int nrb = a.B / 128, per = block_bwd_rows_per_launch(a.H);
     if (hipMemsetAsync(flags, 0, block_flag_words(a.B) * sizeof(unsigned), st) != hipSuccess) return last_error();
-    const hipError_t e = hipFuncSetAttribute((const void*)lstm_block_bwd_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+    const hipError_t e = hipFuncSetAttribute((const void*)lstm_block_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
     if (e != hipSuccess) return (int)e;
-    a.nnt = a.H / BN;
+    a.nnt = a.H / 128;
     a.skew_ticks = g_lstm_block_skew * 100;
     a.prof = persist_prof();
     for (int rb = 0; rb < nrb; rb += per) {
         const int n = nrb - rb < per ? nrb - rb : per;
         a.rb0 = rb;
-        a.part = part + (size_t)rb * 2 * (a.H / 32) * 128 * 4;
+        a.part = part + (size_t)rb * 2 * 4 * a.nnt * 128 * 4;
         a.flags = flags + 2 * rb;
         a.colacc = colacc + (size_t)rb * 3 * 4 * a.H;
         a.xcd_map = n % 8 == 0 ? 1 : 0;   // (linear order: neutral end to end, round 4)
         persist_chain_before(st);
-        hipLaunchKernelGGL(lstm_block_bwd_kernel<BN>, dim3(n * a.nnt), dim3(4 * BN), C::lds_bytes, st, a);
+        hipLaunchKernelGGL(lstm_block_bwd_kernel, dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
         persist_chain_after(st);
     }
     persist_prof_report("row-block bwd: wait_h product passA+publish wait_s combine passB arrive_h", 0, a.S, st);
     return last_error();
-}
-inline int launch_block_bwd(const BlockBwd& a, float* part, unsigned* flags, float* colacc, hipStream_t st) {
-    return block_bwd_bn() == 64 ? launch_block_bwd_t<64>(a, part, flags, colacc, st) : launch_block_bwd_t<128>(a, part, flags, colacc, st);
 }
 
 }  // namespace
