@@ -338,6 +338,58 @@ def test_qntd_oracle_reference_shape(rescale, T):
     assert grad_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("B", [131073, 300001, 600011])
+def test_per_sample_ops_fold_at_every_batch_size(B):
+    """Round 5: the one-lane-per-sample kernels (q n-step TD, PPO's three-launch form) keep their grid within the 512 workgroups
+    of the in-launch loss finalisation at every batch size -- 1024-thread workgroups above 131072 samples, looping workgroups
+    above 524288 -- instead of a second (finalize) launch.  Ragged batches in all three regimes against the fp64 oracle, and
+    (q-TD) bit for bit against the separate finalize launch of tune key 21 = 0 on the per-sample outputs."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.ppo import PPO
+    from hpc_rll.rl_utils.td import QNStepTD
+    rng = np.random.default_rng(B)
+    T, N = 3, 6
+    q, nq = f32(rng, B, N), f32(rng, B, N)
+    a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+    r, done, w = f32(rng, T, B), (rng.random(B) < 0.2).astype(np.float32), rng.random(B).astype(np.float32)
+    q64 = D(q, True)
+    l64, p64 = R.q_nstep_td_error(q64, D(nq), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(w), 0.97, False)
+    l64.backward()
+    res = {}
+    try:
+        for key in (1, 0):
+            U.tune_set(21, key)
+            dq = G(q, True)
+            loss, per = QNStepTD(T, B, N)(dq, G(nq), G(a), G(na), G(r), G(done), G(w), 0.97)
+            loss.backward()
+            res[key] = (loss.detach().clone(), per.detach().clone(), dq.grad.clone())
+    finally:
+        U.tune_set(21, 1)
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for key in (0, 1):
+        assert rel_err(l64.item(), res[key][0].item()) < 2e-5, key
+    assert rel_err(p64.detach().numpy(), res[1][1].cpu().numpy()) < 2e-5
+    assert grad_err(q64.grad.numpy(), res[1][2].cpu().numpy()) < 2e-5
+    # PPO through its three-launch form (key 32 = 0: the per-sample kernel with five sums)
+    ln = f32(rng, B, N)
+    lo = (ln + 0.3 * f32(rng, B, N)).astype(np.float32)
+    vn, vo, adv, ret = f32(rng, B), f32(rng, B), f32(rng, B), f32(rng, B)
+    l64n, v64 = D(ln, True), D(vn, True)
+    o64, _ = R.ppo_error(l64n, D(lo), torch.from_numpy(a), v64, D(vo), D(adv), D(ret), D(w), 0.2, True, None)
+    (o64[0] + 0.5 * o64[1] - 0.01 * o64[2]).backward()
+    try:
+        U.tune_set(32, 0)
+        dln, dvn = G(ln, True), G(vn, True)
+        ls, info = PPO(B, N)(dln, G(lo), G(a), dvn, G(vo), G(adv), G(ret), G(w), 0.2, True, None)
+        (ls[0] + 0.5 * ls[1] - 0.01 * ls[2]).backward()
+    finally:
+        U.tune_set(32, 1)
+    for k in range(3):
+        assert rel_err(o64[k].item(), ls[k].item()) < 2e-5, k
+    assert grad_err(l64n.grad.numpy(), dln.grad.cpu().numpy()) < 2e-5
+    assert grad_err(v64.grad.numpy(), dvn.grad.cpu().numpy()) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------ dist (C51)
 def test_dntd_golden(golden):
     from hpc_rll.rl_utils.td import DistNStepTD
