@@ -512,6 +512,39 @@ __global__ __launch_bounds__(256) void iqn_fwd_group_kernel(
     });
 }
 
+// The QR-DQN pair arithmetic (round 5).  For e = target - q, the quantile Huber term of a pair is
+//   qw * u,  u = du * (e - 0.5 du),  du = clamp(e, -1, 1),  qw = e <= 0 ? |tau - 1| : |tau|
+// and its derivative qw * du.  Rounds 2-4 formed du with v_med3_f32 and qw with v_cmp + v_cndmask per element: 11 VALU
+// instructions per PAIR of targets (5 packed + 6 scalar), and on gfx950 every v_cmp -> v_cndmask hand-over through VCC costs two
+// wait states the compiler could fill only half of the time (221 s_nop in the unrolled loop of the batch kernel: 0.61 of the
+// issue slots doing work).  Here the two signs are split by the CLAMP output modifier of the packed subtract:
+//   dp = clamp01(t - q),  dn = clamp01(q - t)            (one of them is 0; du = dp - dn)
+//   up = dp * (e - 0.5 dp),  un = dn * (-e - 0.5 dn)     (u = up + un, one of them is 0; same roundings as du * (e - 0.5 du))
+// and the two quantile weights multiply the four SUMS once per sample instead of every term:
+//   loss_i = |tau| * sum(up) + |tau - 1| * sum(un),   dloss_i = |tau| * sum(dp) - |tau - 1| * sum(dn)
+// -- 9 packed instructions per pair, nothing through VCC.  Per-term values are those of the old form; the sums differ from
+// it by where the weight is applied (fp32 rounding of a 32-term sum; tests pin the fp64 oracle at 2e-5).
+struct QrSums { vfloat2 up, un, dp, dn; };
+__device__ __forceinline__ vfloat2 pk_sub_clamp01(vfloat2 a, vfloat2 b) {
+    vfloat2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void qr_pair(QrSums& s, vfloat2 t2, vfloat2 q2) {
+    const vfloat2 mh2 = {-0.5f, -0.5f};
+    const vfloat2 e = t2 - q2;
+    const vfloat2 dp = pk_sub_clamp01(t2, q2), dn = pk_sub_clamp01(q2, t2);
+    s.up = __builtin_elementwise_fma(dp, __builtin_elementwise_fma(mh2, dp, e), s.up);
+    s.un = __builtin_elementwise_fma(dn, __builtin_elementwise_fma(mh2, dn, -e), s.un);
+    s.dp += dp;
+    s.dn += dn;
+}
+// (li, gi) of lane i from the four sums: even targets in .x, odd ones in .y
+__device__ __forceinline__ void qr_finish(const QrSums& s, float qneg, float qpos, float& li, float& gi) {
+    li = fmaf(qneg, s.un.x + s.un.y, qpos * (s.up.x + s.up.y));
+    gi = fmaf(-qneg, s.dn.x + s.dn.y, qpos * (s.dp.x + s.dp.y));
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void qrdqn_fwd_group_kernel(
     const float* __restrict__ q, const float* __restrict__ next_q, const int64_t* __restrict__ action,
@@ -533,26 +566,20 @@ __global__ __launch_bounds__(256) void qrdqn_fwd_group_kernel(
             }
         }
         const float inv_tau = 1.f / (float)tau;
-        // as iqn_fwd_group_kernel: packed pairs, du = med3(e, -1, 1), smooth_l1 = du * (e - 0.5 du), hoisted weights
+        // qr_pair above: two targets per iteration; an odd tail pairs the last target with e = 0 (contributes nothing)
         const float qneg = fabsf(tau_value - 1.f), qpos = fabsf(tau_value);
-        const vfloat2 q2 = {qi, qi}, mh2 = {-0.5f, -0.5f};
-        vfloat2 li2 = {0.f, 0.f}, gi2 = {0.f, 0.f};
+        const vfloat2 q2 = {qi, qi};
+        QrSums sm = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         for (int j = 0; j < tau; j += 2) {
             const bool two = j + 1 < tau;
             vfloat2 t2;
             t2.x = __shfl(tgt, base + j, 64);
             t2.y = __shfl(tgt, base + (two ? j + 1 : j), 64);
-            const vfloat2 e = t2 - q2;
-            vfloat2 du, qw;
-            du.x = __builtin_amdgcn_fmed3f(e.x, -1.f, 1.f);
-            du.y = __builtin_amdgcn_fmed3f(e.y, -1.f, 1.f);
-            const vfloat2 u = du * __builtin_elementwise_fma(mh2, du, e);       // smooth_l1, beta = 1
-            qw.x = e.x <= 0.f ? qneg : qpos;
-            qw.y = two ? (e.y <= 0.f ? qneg : qpos) : 0.f;
-            li2 = __builtin_elementwise_fma(qw, u, li2);
-            gi2 = __builtin_elementwise_fma(qw, du, gi2);
+            if (!two) t2.y = qi;
+            qr_pair(sm, t2, q2);
         }
-        const float li = li2.x + li2.y, gi = gi2.x + gi2.y;
+        float li, gi;
+        qr_finish(sm, qneg, qpos, li, gi);
         if (ok && gl < tau) buf[(size_t)b * tau + gl] = -gi * inv_tau * w * scale;
         const float loss = group_sum<G>(gl < tau ? li : 0.f) * inv_tau;
         if (ok && gl == 0) td_err[b] = loss;
@@ -579,7 +606,9 @@ __global__ __launch_bounds__(256, 4) void qrdqn_fwd_batch_kernel(
     constexpr int SPW = 64 / G, NIT = SW / SPW, U = NIT < 4 ? NIT : 4;
     static_assert(SW % SPW == 0 && NIT % U == 0, "samples per wave");
     __shared__ float red[4];
-    __shared__ __attribute__((aligned(16))) float tg[4][U][64];   // the targets of U iterations, per wave
+    // per wave, two buffers of U iterations: the q row elements (lane = element) and the next-q row elements, which become the
+    // targets in place
+    __shared__ __attribute__((aligned(16))) float rq[4][2][U][64], tg[4][2][U][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gl = lane % G, gs = lane / G;
     const long b0 = ((long)blockIdx.x * 4 + w) * SW;
     // phase A (lanes >= SW repeat the first SW samples: harmless)
@@ -592,69 +621,206 @@ __global__ __launch_bounds__(256, 4) void qrdqn_fwd_batch_kernel(
     const float vg_l = vgm_l * (1.f - dn_l);
     const int glc = gl < tau ? gl : tau - 1;                  // clamped: the row loads are unconditional
     const float inv_tau = 1.f / (float)tau;
-    float qneg = fabsf(tau_value - 1.f), qpos = fabsf(tau_value);
-    asm volatile("" : "+v"(qneg), "+v"(qpos));         // opaque: else the compiler selects first and takes |.| per pair
-    const vfloat2 mh2 = {-0.5f, -0.5f};
+    const float qneg = fabsf(tau_value - 1.f), qpos = fabsf(tau_value);
     float mine = 0.f;                                         // td_err of the sample this lane owns
-    for (int c = 0; c < NIT; c += U) {
-        float qv[U], nv[U];
+    // Round 5: the two rows of an iteration come by LDS-DMA (global_load_lds_dword: lane l's element lands in word l of the
+    // wave's slot, no registers), and the rows of the NEXT U iterations are requested before the pair loops of the current
+    // ones run.  Rounds 3-4 loaded them into registers right before use: a 2-3 us round trip exposed once per U iterations
+    // with four waves per SIMD to cover it -- the pair loops themselves measured at the VALU issue rate (31 us of the kernel's
+    // 57 at B = 262144, tests/tools/r05_qrdqn_ablate.py), the rest was this.  (Prefetching into registers instead: the
+    // compiler spilled the prefetched values to scratch, one vmcnt(0) each.)
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gl_ptr;
+    auto rows = [&](int c, int pb) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int sl = (c + u) * SPW + gs;                // sample of this group, as a lane index of phase A
-            qv[u] = q[__shfl(row_l, sl, 64) + glc];
-            nv[u] = next_q[__shfl(rown_l, sl, 64) + glc];
+            __builtin_amdgcn_global_load_lds((gl_ptr)(q + __shfl(row_l, sl, 64) + glc), (lds_ptr)&rq[w][pb][u][0], 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gl_ptr)(next_q + __shfl(rown_l, sl, 64) + glc), (lds_ptr)&tg[w][pb][u][0], 4, 0, 0);
         }
-        // Targets go through LDS: a group then reads FOUR of them with one broadcast ds_read_b128 (a ds_bpermute per
-        // target plus its lane arithmetic was half of the loop's instructions, and its latency was exposed in every iteration).
-        // One wave writes and reads its own slots: LDS operations of a wave execute in order, no barrier needed.
+    };
+    rows(0, 0);
+    for (int c = 0, pb = 0; c < NIT; c += U, pb ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the rows of these U iterations are in LDS
+        // Targets stay in LDS: a group reads FOUR of them with one broadcast ds_read_b128 (a ds_bpermute per target plus its
+        // lane arithmetic was half of the loop's instructions).  One wave writes and reads its own slots: LDS operations of a
+        // wave execute in order, no barrier needed.
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int sl = (c + u) * SPW + gs;
-            tg[w][u][lane] = fmaf(__shfl(vg_l, sl, 64), nv[u], __shfl(R_l, sl, 64));
+            tg[w][pb][u][lane] = fmaf(__shfl(vg_l, sl, 64), tg[w][pb][u][lane], __shfl(R_l, sl, 64));
         }
         __builtin_amdgcn_wave_barrier();
+        if (c + U < NIT) rows(c + U, pb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int sl = (c + u) * SPW + gs;
             const bool ok = b0 + sl < (long)B;
-            const float* tgs = &tg[w][u][gs * G];
-            const vfloat2 q2 = {qv[u], qv[u]};
-            vfloat2 li2 = {0.f, 0.f}, gi2 = {0.f, 0.f};
-            // as qrdqn_fwd_group_kernel: packed pairs, du = med3(e, -1, 1), smooth_l1 = du * (e - 0.5 du), hoisted weights;
-            // even targets accumulate in .x, odd ones in .y, in target order
-            auto pair = [&](vfloat2 t2, bool two) {
-                const vfloat2 e = t2 - q2;
-                vfloat2 du, qw;
-                du.x = __builtin_amdgcn_fmed3f(e.x, -1.f, 1.f);
-                du.y = __builtin_amdgcn_fmed3f(e.y, -1.f, 1.f);
-                const vfloat2 uu = du * __builtin_elementwise_fma(mh2, du, e);
-                qw.x = e.x <= 0.f ? qneg : qpos;
-                qw.y = two ? (e.y <= 0.f ? qneg : qpos) : 0.f;
-                li2 = __builtin_elementwise_fma(qw, uu, li2);
-                gi2 = __builtin_elementwise_fma(qw, du, gi2);
-            };
+            const float* tgs = &tg[w][pb][u][gs * G];
+            const float qvu = rq[w][pb][u][lane];
+            const vfloat2 q2 = {qvu, qvu};
+            QrSums sm = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // qr_pair: as qrdqn_fwd_group_kernel
             if constexpr (FULL) {                             // tau == G: no tail, fully unrolled
 #pragma unroll
                 for (int j = 0; j < G; j += 4) {
                     const vfloat4 t = *reinterpret_cast<const vfloat4*>(tgs + j);
-                    pair(vfloat2{t.x, t.y}, true);
-                    pair(vfloat2{t.z, t.w}, true);
+                    qr_pair(sm, vfloat2{t.x, t.y}, q2);
+                    qr_pair(sm, vfloat2{t.z, t.w}, q2);
                 }
             } else {
                 for (int j = 0; j < tau; j += 2) {
-                    const vfloat2 t = *reinterpret_cast<const vfloat2*>(tgs + j);
-                    pair(t, j + 1 < tau);
+                    vfloat2 t = *reinterpret_cast<const vfloat2*>(tgs + j);
+                    if (j + 1 >= tau) t.y = qvu;
+                    qr_pair(sm, t, q2);
                 }
             }
-            const float li = li2.x + li2.y, gi = gi2.x + gi2.y;
+            float li, gi;
+            qr_finish(sm, qneg, qpos, li, gi);
             const float wu = __shfl(w_l, sl, 64);             // outside the branch: a masked-off owner lane would read as 0
-            if (ok && gl < tau) buf[(size_t)(b0 + sl) * tau + gl] = -gi * inv_tau * wu * scale;
+            // tau == G: stored WITHOUT a branch (the compiler sinks the dp / dn sums into a conditional store's block and keeps
+            // all 32 of them alive until then: 64 registers, spills).  A group past the end of the batch holds sample B - 1
+            // again (phase A clamps) and stores that sample's values a second time.
+            const long bst = b0 + sl < (long)B ? b0 + sl : (long)B - 1;
+            if (FULL || (ok && gl < tau)) buf[(size_t)bst * tau + gl] = -gi * inv_tau * wu * scale;
             const float loss = group_sum_last<G>(gl < tau ? li : 0.f);  // DPP: the group's LAST lane holds the sum
             const float theirs = __shfl(loss, (lane % SPW) * G + G - 1, 64);   // the group that holds my sample in this iteration
             if ((lane % SW) / SPW == c + u) mine = theirs * inv_tau;
             __builtin_amdgcn_sched_barrier(0);                // one sample's 32 target registers at a time (else: spills)
         }
+    }
+    const bool own = lane < SW && bown < (long)B;
+    if (own) td_err[bown] = mine;
+    const float contrib = wave_sum(own ? mine * w_l : 0.f);
+    if (lane == 0) red[w] = contrib;
+    __syncthreads();
+    float tot = 0.f;
+    if (threadIdx.x == 0) tot = (red[0] + red[1]) + (red[2] + red[3]);
+    publish_sums<1, 256>(tot, partials, fold);
+}
+
+// Round 5, large batches, tau a multiple of 4 (<= 64): FOUR quantiles per lane, a sample on G = 8 (tau <= 32) or 16 lanes,
+// 64 / G samples per iteration of a wave.  qrdqn_fwd_batch_kernel above reads all tau targets into every one of a sample's
+// tau lanes -- 4 KB of LDS reads per sample at tau = 32, and those reads, not the arithmetic, set its time: with a quarter of
+// them the kernel ran 44 us instead of 58 at B = 262144 (tests/tools/r05_qrdqn_ablate.py; dropping the pair arithmetic
+// from 11 to 9 instructions per pair changed nothing).  Here a target read serves four quantiles (1 KB per sample), the
+// packed lanes are two QUANTILES against one broadcast target (op_sel picks the half of the register pair the target sits
+// in), a quantile's terms add up in target order, rows move as 16 bytes per lane and the row / target / reduction overhead
+// of an iteration is spread over four times the samples.  Per-term arithmetic: qr_pair.
+template <bool HI>
+__device__ __forceinline__ void qr_quad(QrSums& s, vfloat2 tp, vfloat2 q2) {
+    const vfloat2 mh2 = {-0.5f, -0.5f};
+    const float t = HI ? tp.y : tp.x;
+    const vfloat2 e = vfloat2{t, t} - q2;
+    vfloat2 dp, dn;
+    if (HI) {
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(dp) : "v"(tp), "v"(q2));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(dn) : "v"(q2), "v"(tp));
+    } else {
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(dp) : "v"(tp), "v"(q2));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(dn) : "v"(q2), "v"(tp));
+    }
+    s.up = __builtin_elementwise_fma(dp, __builtin_elementwise_fma(mh2, dp, e), s.up);
+    s.un = __builtin_elementwise_fma(dn, __builtin_elementwise_fma(mh2, dn, -e), s.un);
+    s.dp += dp;
+    s.dn += dn;
+}
+
+template <int G, int SW, bool FULL>
+__global__ __launch_bounds__(256, 4) void qrdqn_fwd_quad_kernel(
+    const float* __restrict__ q, const float* __restrict__ next_q, const int64_t* __restrict__ action,
+    const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
+    const float* __restrict__ weight, const float* __restrict__ value_gamma, float* __restrict__ td_err,
+    float* __restrict__ buf, float* __restrict__ partials, int tau, int nstep, int B, int N, float gamma,
+    float gamma_n, float tau_value, float scale, const ScanFold fold) {
+    constexpr int SPW = 64 / G, NIT = SW / SPW;
+    static_assert(SW % SPW == 0 && SW <= 64 && G >= 8, "samples per wave");
+    __shared__ float red[4];
+    // per wave, two buffers: the q rows (lane l's four quantiles in words 4l ..) and the next-q rows, which become the targets
+    // in place (a sample's targets contiguous: G * 4 words)
+    __shared__ __attribute__((aligned(16))) float rq[4][2][256], tg[4][2][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gl = lane % G, gs = lane / G;
+    const long b0 = ((long)blockIdx.x * 4 + w) * SW;
+    // phase A as qrdqn_fwd_batch_kernel: lane l holds the scalars of sample b0 + l (lanes >= SW repeat the first SW samples)
+    const long bown = b0 + lane % SW;
+    const long bl = bown < (long)B ? bown : (long)B - 1;
+    const long row_l = ((long)bl * N + action[bl]) * tau, rown_l = ((long)bl * N + next_action[bl]) * tau;   // element offsets
+    const float dn_l = done[bl], vgm_l = value_gamma ? value_gamma[bl] : gamma_n;
+    const float w_l = weight ? weight[bl] : 1.f;
+    const float R_l = nstep_return1(reward, B, nstep, gamma, bl);
+    const float vg_l = vgm_l * (1.f - dn_l);
+    const int nq4 = tau >> 2;                                 // lanes of a group that hold quantiles
+    const int glc = gl < nq4 ? gl : nq4 - 1;                  // clamped: the row loads are unconditional
+    const float inv_tau = 1.f / (float)tau;
+    const float qneg = fabsf(tau_value - 1.f), qpos = fabsf(tau_value);
+    float mine = 0.f;                                         // td_err of the sample this lane owns
+    // The rows come by LDS-DMA (global_load_lds_dwordx4: lane l's 16 bytes land at word 4l of the wave's slot, no registers),
+    // those of the NEXT iteration requested before the pair loops of the current one run.
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gl_ptr;
+    auto rows = [&](int c, int pb) {
+        const int sl = c * SPW + gs;                          // sample of this group, as a lane index of phase A
+        __builtin_amdgcn_global_load_lds((gl_ptr)(q + __shfl(row_l, sl, 64) + 4 * glc), (lds_ptr)&rq[w][pb][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gl_ptr)(next_q + __shfl(rown_l, sl, 64) + 4 * glc), (lds_ptr)&tg[w][pb][0], 16, 0, 0);
+    };
+    rows(0, 0);
+#pragma unroll 1
+    for (int c = 0, pb = 0; c < NIT; ++c, pb ^= 1) {
+        const int sl = c * SPW + gs;
+        const float vg = __shfl(vg_l, sl, 64), R = __shfl(R_l, sl, 64), wu = __shfl(w_l, sl, 64);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the rows of this iteration are in LDS
+        vfloat4* const t4 = reinterpret_cast<vfloat4*>(&tg[w][pb][4 * lane]);
+        vfloat4 nv = *t4;
+        nv.x = fmaf(vg, nv.x, R);
+        nv.y = fmaf(vg, nv.y, R);
+        nv.z = fmaf(vg, nv.z, R);
+        nv.w = fmaf(vg, nv.w, R);
+        *t4 = nv;                                             // one wave writes and reads its own slots: in order, no barrier
         __builtin_amdgcn_wave_barrier();
+        if (c + 1 < NIT) rows(c + 1, pb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const vfloat4 q4 = *reinterpret_cast<const vfloat4*>(&rq[w][pb][4 * lane]);
+        const vfloat2 q01 = {q4.x, q4.y}, q23 = {q4.z, q4.w};
+        QrSums s01 = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, s23 = s01;
+        const float* tgs = &tg[w][pb][gs * G * 4];
+        auto four = [&](int j) {
+            const vfloat4 t = *reinterpret_cast<const vfloat4*>(tgs + j);
+            const vfloat2 ta = {t.x, t.y}, tb = {t.z, t.w};
+            qr_quad<false>(s01, ta, q01);
+            qr_quad<false>(s23, ta, q23);
+            qr_quad<true>(s01, ta, q01);
+            qr_quad<true>(s23, ta, q23);
+            qr_quad<false>(s01, tb, q01);
+            qr_quad<false>(s23, tb, q23);
+            qr_quad<true>(s01, tb, q01);
+            qr_quad<true>(s23, tb, q23);
+        };
+        if constexpr (FULL) {                                 // tau == 4 G: fully unrolled
+#pragma unroll
+            for (int j = 0; j < 4 * G; j += 4) four(j);
+        } else {
+            for (int j = 0; j < tau; j += 4) four(j);
+        }
+        // loss_i = |tau| sum(up) + |tau - 1| sum(un), dloss_i likewise (qr_finish, per quantile)
+        vfloat4 li, gi;
+        li.x = fmaf(qneg, s01.un.x, qpos * s01.up.x);
+        li.y = fmaf(qneg, s01.un.y, qpos * s01.up.y);
+        li.z = fmaf(qneg, s23.un.x, qpos * s23.up.x);
+        li.w = fmaf(qneg, s23.un.y, qpos * s23.up.y);
+        gi.x = fmaf(-qneg, s01.dn.x, qpos * s01.dp.x);
+        gi.y = fmaf(-qneg, s01.dn.y, qpos * s01.dp.y);
+        gi.z = fmaf(-qneg, s23.dn.x, qpos * s23.dp.x);
+        gi.w = fmaf(-qneg, s23.dn.y, qpos * s23.dp.y);
+        // tau == 4 G: stored without a branch (a conditional store's block attracts the sums and keeps their terms alive);
+        // a group past the end of the batch holds sample B - 1 again (phase A clamps) and stores its values a second time
+        const long bst = b0 + sl < (long)B ? b0 + sl : (long)B - 1;
+        const float gsc = -inv_tau * wu * scale;
+        if (FULL || gl < nq4)
+            *reinterpret_cast<vfloat4*>(buf + (size_t)bst * tau + 4 * gl) = vfloat4{gi.x * gsc, gi.y * gsc, gi.z * gsc, gi.w * gsc};
+        const float lsum = (li.x + li.y) + (li.z + li.w);
+        const float loss = group_sum_last<G>(FULL || gl < nq4 ? lsum : 0.f);   // DPP: the group's LAST lane holds the sum
+        const float theirs = __shfl(loss, (lane % SPW) * G + G - 1, 64);       // the group that holds my sample in this iteration
+        if ((lane % SW) / SPW == c) mine = theirs * inv_tau;
     }
     const bool own = lane < SW && bown < (long)B;
     if (own) td_err[bown] = mine;
@@ -793,8 +959,32 @@ extern "C" int hpc_rll_qrdqn_nstep_td_forward(const float* q, const float* next_
     if (sw == 0) sw = B >= 262144 ? 32 : B >= 32768 ? 8 : 1;
     if (tau > 64 || sw < 64 / group_lanes(tau)) sw = 1;
     if (sw > 1) blocks = (int)(((long)B + 4 * sw - 1) / (4 * sw));
+    // tau a multiple of 4, rows 16-byte aligned: four quantiles per lane (qrdqn_fwd_quad_kernel)
+    const bool quad = sw >= 8 && tau % 4 == 0 && tau >= 8 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(next_n_q) |
+                                                                reinterpret_cast<uintptr_t>(buf)) & 15) == 0;
+    if (quad) {
+        const int G = tau <= 32 ? 8 : 16;
+        if (sw < 64 / G) sw = 64 / G;
+        blocks = (int)(((long)B + 4 * sw - 1) / (4 * sw));
+    }
     const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);
-    if (sw > 1) {
+    if (quad) {
+        const int G = tau <= 32 ? 8 : 16;
+#define HPC_RLL_QR_Q(G_, SW_)                                                                                         \
+        if (G == G_ && sw == SW_) {                                                                                   \
+            if (tau == 4 * G_)                                                                                        \
+                hipLaunchKernelGGL((qrdqn_fwd_quad_kernel<G_, SW_, true>), dim3(blocks), dim3(256), 0, st, q, next_n_q, \
+                                   action, next_n_action, reward, done, weight, value_gamma, td_err, buf, partials, tau, \
+                                   nstep, B, N, gamma, gamma_n, tau_value, scale, fold);                              \
+            else                                                                                                      \
+                hipLaunchKernelGGL((qrdqn_fwd_quad_kernel<G_, SW_, false>), dim3(blocks), dim3(256), 0, st, q, next_n_q, \
+                                   action, next_n_action, reward, done, weight, value_gamma, td_err, buf, partials, tau, \
+                                   nstep, B, N, gamma, gamma_n, tau_value, scale, fold);                              \
+        }
+        HPC_RLL_QR_Q(8, 8) HPC_RLL_QR_Q(8, 16) HPC_RLL_QR_Q(8, 32) HPC_RLL_QR_Q(8, 64)
+        HPC_RLL_QR_Q(16, 8) HPC_RLL_QR_Q(16, 16) HPC_RLL_QR_Q(16, 32) HPC_RLL_QR_Q(16, 64)
+#undef HPC_RLL_QR_Q
+    } else if (sw > 1) {
         const int G = group_lanes(tau);
 #define HPC_RLL_QR_B(G_, SW_)                                                                                         \
         if (G == G_ && sw == SW_) {                                                                                   \
