@@ -356,14 +356,22 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_mov(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, 0xF, false); }
 
 __device__ __forceinline__ float c51_project_scan(int* __restrict__ se, int lane, int n_atom, float R, float nd_scale,
-                                                  float pn_j, float v_min, float v_max, float dz) {
+                                                  float pn_j, float v_min, float v_max, float dz, float inv_dz) {
     const bool src = lane < n_atom;
     const int j = src ? lane : n_atom - 1;
     const float step = (v_max - v_min) / (float)(n_atom - 1);
     const float sup = (j < n_atom / 2) ? (v_min + step * (float)j) : (v_max - step * (float)(n_atom - 1 - j));
     float tz = __fadd_rn(R, __fmul_rn(nd_scale, sup));
     tz = fminf(fmaxf(tz, v_min), v_max);
-    const float bp = __fdiv_rn(__fsub_rn(tz, v_min), dz);
+    // bp = (tz - v_min) / dz, correctly rounded, without the division sequence (two v_div_scale, v_rcp, five fmas, v_div_fmas,
+    // v_div_fixup): dz is one number per launch, so its correctly rounded reciprocal comes from the host, and two residual
+    // corrections of x * (1 / dz) give the rounded quotient (Markstein; the hardware sequence is the same two corrections on a
+    // reciprocal it refines itself, plus scaling for exponents this quotient -- an atom position in [0, n_atom) -- cannot have).
+    // Checked against exact rational arithmetic on 48000 positions incl. the near-integer ones.
+    const float x = __fsub_rn(tz, v_min);
+    const float q0 = __fmul_rn(x, inv_dz);
+    const float q1 = fmaf(fmaf(-dz, q0, x), inv_dz, q0);
+    const float bp = fmaf(fmaf(-dz, q1, x), inv_dz, q1);
     const float lo = floorf(bp), up = ceilf(bp);
     int i_lo = (int)lo;
     i_lo = i_lo < 0 ? 0 : i_lo > 63 ? 63 : i_lo;              // NaN inputs must not leave the table
@@ -405,12 +413,13 @@ __global__ __launch_bounds__(256) void dist_nstep_fwd_batch_kernel(
     const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
     const float* __restrict__ weight, float* __restrict__ td_err, float* __restrict__ buf,
     float* __restrict__ partials, int nstep, int B, int N, int n_atom, float gamma, float gamma_n, float v_min,
-    float v_max, float dz, float scale, const ScanFold fold) {
+    float v_max, float dz, float inv_dz, float scale, const ScanFold fold) {
     constexpr int U = 8;
     static_assert(SW % U == 0, "samples per wave");
     __shared__ float red[4];
     __shared__ __attribute__((aligned(8))) int runs[4][128];       // per wave: {start, end} lane of the run of every atom
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // the wave index as a scalar: sample numbers and the addresses built from them stay in the scalar unit
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long b0 = ((long)blockIdx.x * 4 + w) * SW;
     const long bown = b0 + lane % SW;
     const long bl = bown < (long)B ? bown : (long)B - 1;
@@ -436,13 +445,19 @@ __global__ __launch_bounds__(256) void dist_nstep_fwd_batch_kernel(
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool live = b0 + c + u < (long)B;
             const float proj = c51_project_scan(runs[w], lane, n_atom, bcast(R_l, c + u), bcast(nd_l, c + u), pnj[u],
-                                                v_min, v_max, dz);
+                                                v_min, v_max, dz, inv_dz);
+            // a sample past the end of the batch is sample B - 1 again (phase A clamps): stored a second time, without a branch
+            // (round 5: 69 -> 63 us at B = 262144)
+            const long bst = b0 + c + u < (long)B ? b0 + c + u : (long)B - 1;
             float ce = 0.f;
             if (lane < n_atom) {
                 ce = proj * logf(pk[u]);
-                if (live) buf[(size_t)(b0 + c + u) * n_atom + lane] = -bcast(w_l, c + u) * proj / pk[u] * scale;
+                // (-w proj) / p: v_rcp_f32 and one residual correction (within an ulp of the division sequence, a third of its
+                // instructions)
+                const float num = -bcast(w_l, c + u) * proj, rp = __builtin_amdgcn_rcpf(pk[u]);
+                const float g0 = num * rp;
+                buf[(size_t)bst * n_atom + lane] = fmaf(fmaf(-pk[u], g0, num), rp, g0) * scale;
             }
             const float tot = bcast(group_sum_last<64>(ce), 63);      // DPP sum: no LDS round trips
             if (lane % SW == c + u) mine = -tot;
@@ -859,6 +874,7 @@ extern "C" int hpc_rll_dist_nstep_td_forward(const float* dist, const float* nex
     const int blocks = sw > 1 ? (int)(((long)B + 4 * sw - 1) / (4 * sw)) : (B + 3) / 4;
     // delta_z is a python double in the oracle, rounded to fp32 when it meets the fp32 tensor
     const float dz = (float)(((double)v_max - (double)v_min) / (double)(n_atom - 1));
+    const float inv_dz = (float)(1.0 / (double)dz);            // the correctly rounded reciprocal (c51_project_scan)
     const ScanFold fold = make_fold(st, 1, &scale, loss, blocks);
     const float gamma_n = (float)pow((double)gamma, (double)nstep);
     if (sw > 1) {
@@ -866,7 +882,7 @@ extern "C" int hpc_rll_dist_nstep_td_forward(const float* dist, const float* nex
         if (sw == SW_)                                                                                                \
             hipLaunchKernelGGL(dist_nstep_fwd_batch_kernel<SW_>, dim3(blocks), dim3(256), 0, st, dist, next_n_dist,    \
                                action, next_n_action, reward, done, weight, td_err, buf, partials, nstep, B, N, n_atom, \
-                               gamma, gamma_n, v_min, v_max, dz, scale, fold);
+                               gamma, gamma_n, v_min, v_max, dz, inv_dz, scale, fold);
         HPC_RLL_C51_B(8) HPC_RLL_C51_B(16) HPC_RLL_C51_B(32) HPC_RLL_C51_B(64)
 #undef HPC_RLL_C51_B
     } else if (n_atom <= 64)
