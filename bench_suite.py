@@ -16,21 +16,49 @@ import torch  # noqa: E402
 dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cuda:0")
 QUIET = False      # bench.py imports this module for its `suite` object and sets QUIET (one JSON line on stdout)
 HBM, MFMA_F32 = 8000.0, 157.3   # GB/s, TFLOP/s (MI355X_MICROARCH.md)
-# vector-ALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction = 4 cycles of its SIMD, 2.4 GHz peak shader clock
-VALU_PEAK = 1024 * 2.4e9 / 4     # wave-instructions / s
+# vector-ALU issue peak: 256 CUs x 4 SIMDs x 2.4 GHz peak shader clock SIMD-cycles per second.  What a wave64 instruction
+# costs its SIMD depends on its encoding (tests/tools/micro/valu_rate.hip, profiles/r05_valu_rate.txt: e32 VOP1/VOP2 2.4
+# cycles, VOP3 / DPP / v_readlane 4.3, packed fp32 4.4 for two lanes' worth, transcendental 8.2) -- rounds 3-4 priced every
+# instruction at 4 cycles, which called a kernel of mostly e32 instructions (C51) "82 % VALU-bound" when removing a fifth of
+# its instructions did not change its time.
+SIMD_CYCLES = 1024 * 2.4e9
+VALU_CPI_DEFAULT = 4.0
 rows = []
 
 
 def valu_counts():
-    """VALU wave-instructions per SAMPLE of the instruction-bound forwards, from hardware counters (rocprofv3 --pmc
-    SQ_INSTS_VALU, tests/tools/r04_td_valu.sh -> profiles/td_valu.json).  A static property of the compiled kernel at
-    the recorded shape; the record names the source file's hash so that a stale count is not quoted for a changed kernel."""
-    path = os.path.join(ROOT, "profiles", "td_valu.json")
+    """Per forward kernel: VALU wave-instructions per SAMPLE from hardware counters (rocprofv3 --pmc SQ_INSTS_VALU,
+    tests/tools/r04_td_valu.sh -> profiles/td_valu.json), the mean issue cost of its instructions (static classification of
+    the compiled kernel, tests/tools/r05_valu_classify.py -> profiles/r05_td_valu_classes.json) and the hand-counted
+    minimum of its inner loop.  Static properties of the compiled kernel at the recorded shape."""
+    out = {}
     try:
-        rec = json.load(open(path))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "td_valu.json")))
+        for k, v in rec.get("valu_wave_insts_per_sample", {}).items():
+            out[k] = {"insts": v}
     except Exception:  # noqa: BLE001
         return {}
-    return rec.get("valu_wave_insts_per_sample", {})
+    try:
+        cls = json.load(open(os.path.join(ROOT, "profiles", "r05_td_valu_classes.json")))
+        for k, v in cls.get("kernels", {}).items():
+            if k in out:
+                out[k]["cpi"] = v["cycles_per_valu_inst"]
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
+# Hand counts of the irreducible vector work per SAMPLE, in wave-instructions (DESIGN.md section 4):
+#   QR-DQN / IQN: tau x tau' pairs of (quantile, target), two per packed instruction, NINE packed instructions per two pairs
+#                 (e, two clamped differences, two Huber factors, four accumulations), 64 lanes: tau tau' / 2 x 9 / 64, at 4.4 cycles;
+#   C51 (one sample per wave): position 10, run table 12, one shuffle step 5, the two fetches and their select 13, log 10,
+#                 quotient 7, cross-entropy term and its 64-lane sum 9, per-sample scalars and row addresses 14: 80, at 3.1 cycles.
+def valu_min(name, tau=32, tau_p=32):
+    if name in ("qrdqn_nstep_td_fwd", "iqn_nstep_td_fwd"):
+        return tau * tau_p / 2 * 9 / 64, 4.4
+    if name == "dist_nstep_td_fwd":
+        return 80.0, 3.1
+    return None
 
 
 def timed(fn, n=5, rounds=3):
@@ -57,13 +85,18 @@ def report(name, shape, t_f, bytes_f, t_b=None, bytes_b=None, flops_f=None, flop
         r.update(fwd_tflops=flops_f / t_f / 1e12, fwd_frac=flops_f / t_f / 1e12 / MFMA_F32, bound="mfma")
     else:
         r.update(fwd_gbs=bytes_f / t_f / 1e9, fwd_frac=bytes_f / t_f / 1e9 / HBM, bound="hbm")
-        if valu_f:
-            vf = valu_f / t_f / VALU_PEAK
-            r.update(fwd_valu_frac=vf, fwd_valu_insts=valu_f)
+        if valu_f and valu_f.get("insts"):
+            n, cpi = valu_f["insts"] * valu_f["samples"], valu_f.get("cpi", VALU_CPI_DEFAULT)
+            vf = n * cpi / (SIMD_CYCLES * t_f)
+            r.update(fwd_valu_frac=vf, fwd_valu_insts=n, fwd_valu_cycles_per_inst=cpi)
+            if valu_f.get("min"):
+                mn, mcpi = valu_f["min"]
+                r.update(fwd_valu_min_insts=mn * valu_f["samples"], fwd_valu_min_frac=mn * valu_f["samples"] * mcpi / (SIMD_CYCLES * t_f))
             if vf > r["fwd_frac"]:
                 r.update(bound="valu", fwd_hbm_frac=r["fwd_frac"], fwd_frac=vf,
-                         bound_note="forward is VALU-issue bound: fwd_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x "
-                                    "time); backward (a write stream) stays HBM")
+                         bound_note="forward is VALU-issue bound: fwd_frac = SQ_INSTS_VALU x mean cycles per instruction (by encoding, "
+                                    "profiles/r05_valu_rate.txt) / (1024 SIMDs x 2.4 GHz x time); fwd_valu_min_frac = the same with the "
+                                    "hand-counted minimum of the inner loop; backward (a write stream) stays HBM")
     if t_b is not None:
         r.update(bwd_ms=t_b * 1e3)
         if flops_b:
@@ -137,7 +170,7 @@ def add_kernel_times(t_f, bytes_f, t_b, bytes_b):
                     bwd_kernel_frac=bytes_b / t_b / 1e9 / HBM)
     if rows[-1].get("bound") == "valu":
         rows[-1].update(fwd_kernel_hbm_frac=rows[-1]["fwd_kernel_frac"],
-                        fwd_kernel_frac=rows[-1]["fwd_valu_insts"] / t_f / VALU_PEAK)
+                        fwd_kernel_frac=rows[-1]["fwd_valu_insts"] * rows[-1]["fwd_valu_cycles_per_inst"] / (SIMD_CYCLES * t_f))
     if not QUIET:
         print(json.dumps(rows[-1]), flush=True)
 
@@ -248,6 +281,11 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     per_sample = 16 + 4 * nstep + 4 + 4 + 4   # actions, rewards, done, weight, td_err
     vc = valu_counts()
 
+    def vf(name, samples):
+        return dict(vc.get(name, {}), samples=samples, min=valu_min(name, tau, tau))
+    # a gathered row that does not start on a 128-byte line touches 1 + (bytes - 4) / 128 lines on average (4-byte aligned start)
+    lines_unaligned = lambda nbytes: 128.0 * (1.0 + (nbytes - 4) / 128.0)  # noqa: E731
+
     q = torch.randn(B, N, device=dev, generator=g, requires_grad=True)
     nq = torch.randn(B, N, device=dev, generator=g)
     m = QNStepTD(nstep, B, N)
@@ -261,10 +299,14 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     nd = torch.softmax(torch.randn(B, N, n_atom, device=dev, generator=g), -1)
     m = DistNStepTD(nstep, B, N, n_atom)
     t_f, t_b = fwd_bwd(lambda: m(d, nd, a, na, reward, done, weight, 0.99, -10.0, 10.0)[0], [d])
-    report("dist_nstep_td", f"B={B} N={N} atoms={n_atom}", t_f, B * (2 * line(4 * n_atom) + 128 + per_sample + 4 * n_atom),
-           t_b, B * (4 * N * n_atom + 4 * n_atom), valu_f=vc.get("dist_nstep_td_fwd", 0) * B)
+    row_b = line(4 * n_atom) if (4 * n_atom) % 128 == 0 else lines_unaligned(4 * n_atom)
+    report("dist_nstep_td", f"B={B} N={N} atoms={n_atom}", t_f, B * (2 * row_b + per_sample + 4 * n_atom),
+           t_b, B * (4 * N * n_atom + 4 * n_atom), valu_f=vf("dist_nstep_td_fwd", B))
+    rows[-1].update(fwd_line_gather_ceiling_gbs=5800.0, fwd_frac_of_gather_ceiling=rows[-1]["fwd_gbs"] / 5800.0,
+                    fwd_bound_note="two 204-byte rows per sample at 4-byte alignment: 2.56 lines of 128 bytes each on average; a bare gather "
+                                   "of lines runs at 5.3-5.9 TB/s (profiles/r04_gather_micro.txt)")
     add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(d, nd, a, na, reward, done, weight, 0.99, -10.0, 10.0)[0], [d]),
-                                         (B * (2 * line(4 * n_atom) + 128 + per_sample + 4 * n_atom), B * (4 * N * n_atom + 4 * n_atom)))
+                                         (B * (2 * row_b + per_sample + 4 * n_atom), B * (4 * N * n_atom + 4 * n_atom)))
                        for x in pair])
     del d, nd
 
@@ -277,7 +319,7 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     t_f, t_b = fwd_bwd(lambda: m(qi, nqi, ai, nai, reward[:, :Bi].contiguous(), done[:Bi].contiguous(), rq, 0.99, 1.0,
                                  weight[:Bi].contiguous())[0], [qi])
     report("iqn_nstep_td", f"tau=tau'={tau} B={Bi} N={N}", t_f, Bi * (2 * tau * 128 + 8 * tau + per_sample), t_b,
-           Bi * (4 * tau * N + 4 * tau), valu_f=vc.get("iqn_nstep_td_fwd", 0) * Bi)
+           Bi * (4 * tau * N + 4 * tau), valu_f=vf("iqn_nstep_td_fwd", Bi))
     # the forward is a 128-byte-line gather (every other line of q / next_n_q): what that pattern reaches with the loss arithmetic
     # left out is measured (tests/tools/micro/gather.hip, profiles/r04_gather_micro.txt: 5.3-5.9 TB/s of lines in four lane -> row
     # maps, a contiguous read 6.3) -- reported beside the fraction of the 8 TB/s peak
@@ -293,7 +335,7 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     m = QRDQNNStepTDError(tau, nstep, B, N)
     t_f, t_b = fwd_bwd(lambda: m(qq, nqq, a, na, reward, done, 0.99, weight)[0], [qq])
     report("qrdqn_nstep_td", f"B={B} N={N} tau={tau}", t_f, B * (2 * line(4 * tau) + per_sample + 4 * tau), t_b,
-           B * (4 * N * tau + 4 * tau), valu_f=vc.get("qrdqn_nstep_td_fwd", 0) * B)
+           B * (4 * N * tau + 4 * tau), valu_f=vf("qrdqn_nstep_td_fwd", B))
     add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(qq, nqq, a, na, reward, done, 0.99, weight)[0], [qq]),
                                          (B * (2 * line(4 * tau) + per_sample + 4 * tau), B * (4 * N * tau + 4 * tau))) for x in pair])
 

@@ -376,29 +376,43 @@ __device__ __forceinline__ float c51_project_scan(int* __restrict__ se, int lane
     int i_lo = (int)lo;
     i_lo = i_lo < 0 ? 0 : i_lo > 63 ? 63 : i_lo;              // NaN inputs must not leave the table
     float yl = src ? __fmul_rn(pn_j, up - bp) : 0.f, yu = src ? __fmul_rn(pn_j, bp - lo) : 0.f;
-    const int prev = dpp_mov<0x138>(-1, i_lo), next = dpp_mov<0x130>(-1, i_lo);     // wave_shr:1 / wave_shl:1
-    const bool is_start = src && (lane == 0 || prev != i_lo), is_end = src && (lane == n_atom - 1 || next != i_lo);
+    // Round 5: a source at an INTEGRAL position (up == lo: both weights are 0, the reference's l == u case) stays outside
+    // the runs.  Those are the sources clamped to v_min / v_max -- a run of a dozen zeros at an end of the support in an
+    // ordinary sample -- and they alone made "some run is longer than two" the common case: with them out, a sample whose
+    // atoms land more than half an atom apart (gamma^n (1 - done) > 0.5) has runs of one or two sources and needs ONE shuffle
+    // step instead of three.  By monotonicity an integral position is the first (or last) of its floor's sources, never
+    // between two others, so the remaining sources of a floor are still contiguous; the sums are unchanged (zeros left out).
+    const bool nz = src && up != lo;
+    const int key = nz ? i_lo : -1;
+    const int prev = dpp_mov<0x138>(-2, key), next = dpp_mov<0x130>(-2, key);     // wave_shr:1 / wave_shl:1
+    const bool is_start = nz && (lane == 0 || prev != key), is_end = nz && (lane == n_atom - 1 || next != key);
     int2* __restrict__ se2 = reinterpret_cast<int2*>(se);
     se2[lane] = int2{0, -1};                                  // empty run
     __builtin_amdgcn_wave_barrier();
     if (is_start) se[2 * i_lo] = lane;
     if (is_end) se[2 * i_lo + 1] = lane;
     __builtin_amdgcn_wave_barrier();
-    const int d = src ? lane - se[2 * i_lo] : 0;              // distance to the start of my run
+    const int d = nz ? lane - se[2 * i_lo] : 0;               // distance to the start of my run
     const int2 mine = se2[lane];                              // run of target atom k = lane
     int2 below = se2[lane > 0 ? lane - 1 : 0];
     if (lane == 0) below = int2{0, -1};
     __builtin_amdgcn_wave_barrier();                          // the table is reused by the wave's next sample
-#pragma unroll
-    for (int off = 1; off <= 4; off <<= 1) {
-        const float tl = __shfl_up(yl, off, 64), tu = __shfl_up(yu, off, 64);
-        if (off <= d) { yl += tl; yu += tu; }
+    {
+        const float tl = __shfl_up(yl, 1, 64), tu = __shfl_up(yu, 1, 64);
+        if (1 <= d) { yl += tl; yu += tu; }
     }
-    if (__builtin_amdgcn_ballot_w64(d >= 8)) {
+    if (__builtin_amdgcn_ballot_w64(d >= 2)) {
 #pragma unroll
-        for (int off = 8; off <= 32; off <<= 1) {
+        for (int off = 2; off <= 4; off <<= 1) {
             const float tl = __shfl_up(yl, off, 64), tu = __shfl_up(yu, off, 64);
             if (off <= d) { yl += tl; yu += tu; }
+        }
+        if (__builtin_amdgcn_ballot_w64(d >= 8)) {
+#pragma unroll
+            for (int off = 8; off <= 32; off <<= 1) {
+                const float tl = __shfl_up(yl, off, 64), tu = __shfl_up(yu, off, 64);
+                if (off <= d) { yl += tl; yu += tu; }
+            }
         }
     }
     const float fsum = __shfl(yl, mine.y < 0 ? 0 : mine.y, 64), csum = __shfl(yu, below.y < 0 ? 0 : below.y, 64);
@@ -423,25 +437,22 @@ __global__ __launch_bounds__(256) void dist_nstep_fwd_batch_kernel(
     const long b0 = ((long)blockIdx.x * 4 + w) * SW;
     const long bown = b0 + lane % SW;
     const long bl = bown < (long)B ? bown : (long)B - 1;
-    // element offsets of the two rows of the owned sample (64-bit: B * N * n_atom may pass 2^31)
-    const long row_l = ((long)bl * N + action[bl]) * n_atom, rown_l = ((long)bl * N + next_action[bl]) * n_atom;
+    const int a_l = (int)action[bl], na_l = (int)next_action[bl];
     const float w_l = weight ? weight[bl] : 1.f;
     const float nd_l = (1.f - done[bl]) * gamma_n;
     const float R_l = nstep_return1(reward, B, nstep, gamma, bl);
     const int jl = lane < n_atom ? lane : n_atom - 1;
     auto bcast = [](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
-    auto bcast64 = [](long x, int l) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x & 0xffffffffL), l);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long)x >> 32), l);
-        return (long)(((unsigned long)hi << 32) | lo);
-    };
     float mine = 0.f;
     for (int c = 0; c < SW; c += U) {
         float pk[U], pnj[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {                           // sample c+u is owned by lane c+u: uniform row addresses
-            pk[u] = dist[bcast64(row_l, c + u) + jl];
-            pnj[u] = next_dist[bcast64(rown_l, c + u) + jl];
+        for (int u = 0; u < U; ++u) {
+            // sample c+u is owned by lane c+u; its index (clamped as in phase A: a sample past the end of the batch is sample
+            // B - 1 again) and its row offsets are scalars: 64-bit element offsets, B * N * n_atom may pass 2^31
+            const long bs = b0 + c + u < (long)B ? b0 + c + u : (long)B - 1;
+            pk[u] = dist[(bs * N + __builtin_amdgcn_readlane(a_l, c + u)) * n_atom + jl];
+            pnj[u] = next_dist[(bs * N + __builtin_amdgcn_readlane(na_l, c + u)) * n_atom + jl];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

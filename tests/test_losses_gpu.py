@@ -577,6 +577,51 @@ def test_qrdqn_oracle_reference_shape(quirks):
     assert grad_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
 
 
+def test_c51_integral_positions_stay_outside_the_runs():
+    """Round 5: the large-batch projection leaves a source at an integral position (l == u: the reference gives it weight 0 on
+    both sides, origin/td.py:100-103) out of the runs it sums.  With delta_z = 0.5, gamma = 1 and rewards that are multiples
+    of 0.25 every quantity is exact in fp32 and fp64 alike: samples whose return is a multiple of 0.5 have EVERY source at an
+    integral position (projection 0, error 0), the others none; returns beyond the support put a dozen clamped -- integral --
+    sources at its ends, terminal samples put all 33 on the same position.  Batch kernel against the gather kernel and
+    the fp64 oracle."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.td import DistNStepTD
+    T, B, N, n_atom = 2, 40000, 3, 33
+    v_min, v_max, gamma = -8., 8., 1.0
+    rng = np.random.default_rng(5)
+    dist = (np.abs(f32(rng, B, N, n_atom)) + 1e-3).astype(np.float32)
+    nd = np.abs(f32(rng, B, N, n_atom))
+    a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+    r = (rng.integers(-24, 25, (T, B)) * 0.25).astype(np.float32)       # n-step returns in [-12, 12]: some leave the support
+    done = (rng.random(B) < 0.2).astype(np.float32)
+    w = rng.random(B).astype(np.float32)
+    res = {}
+    try:
+        for key in (1, 8, 0):
+            U.tune_set(24, key)
+            dd = G(dist, True)
+            loss, per = DistNStepTD(T, B, N, n_atom)(dd, G(nd), G(a), G(na), G(r), G(done), G(w), gamma, v_min, v_max)
+            loss.backward()
+            res[key] = (loss.item(), per.detach().cpu(), dd.grad.cpu())
+    finally:
+        U.tune_set(24, 0)
+    ret = r.sum(0)
+    whole = (np.mod(ret * 2.0, 1.0) == 0)                               # return a multiple of delta_z: all positions integral
+    assert 0.3 < whole.mean() < 0.7
+    for key in (8, 0):
+        l0, p0, g0 = res[key]
+        assert float(p0[torch.from_numpy(whole)].abs().max()) == 0.0
+        assert float((g0 - res[1][2]).abs().max()) < 4e-7 * float(res[1][2].abs().max())
+        assert float((p0 - res[1][1]).abs().max()) < 1e-6 * float(res[1][1].abs().max())
+    d64 = D(dist, True)
+    l64, p64 = R.dist_nstep_td_error(d64, D(nd), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(w), gamma, v_min, v_max,
+                                     n_atom)
+    l64.backward()
+    assert rel_err(l64.item(), res[0][0]) < 2e-5
+    assert rel_err(p64.detach().numpy(), res[0][1].numpy()) < 2e-5
+    assert grad_err(d64.grad.numpy(), res[0][2].numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("tau,B,sw", [(32, 65536 + 37, 0), (32, 40000, 64), (20, 33000, 64), (51, 33000, 64), (5, 70001, 0),
                                       (16, 33001, 32), (64, 20000, 8), (3, 9000, 64), (40, 140000, 0), (8, 33003, 16), (64, 70001, 0),
                                       (12, 40001, 8), (34, 33000, 32), (32, 33000, 16), (48, 262144 + 5, 0)])
