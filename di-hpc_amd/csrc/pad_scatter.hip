@@ -749,7 +749,7 @@ template <bool ADD, bool BUILD>
 __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __restrict__ x,
                                                               const int32_t* __restrict__ idx,
                                                               float* __restrict__ out, int M, int N, int HW, int npb,
-                                                              const int64_t* __restrict__ location, int W) {
+                                                              const int64_t* __restrict__ location, int W, int pf_wgs) {
     typedef int vint4 __attribute__((ext_vector_type(4)));
     extern __shared__ float s_dyn[];
     const int b = blockIdx.y;
@@ -834,6 +834,29 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
         stage_x();
     }
     __syncthreads();
+    // Round 5: what THIS workgroup stages came slowly -- its loads queue behind the other workgroups' stores (the memory system
+    // is store-saturated: ~12 us until the tile is there, of a ~30 us lifetime) -- so before it starts streaming, a workgroup
+    // touches the lines that workgroup L + pf_wgs will stage (one dword per 128-byte line of its x tile rows and of its
+    // locations).  pf_wgs is a multiple of 8, so that workgroup runs on the SAME XCD (dispatch is round-robin over the eight)
+    // and finds them in this L2; the launcher picks half the resident set, i.e. the workgroup that starts about when these
+    // loads have returned.  At C5: 0.778 -> 0.724 ms (profiles/r05_scatter_pf.txt; the distance swept 64 ... 512 workgroups).
+    float pfv = 0.f;
+    if (pf_wgs > 0) {
+        const unsigned L2 = blockIdx.y * gridDim.x + blockIdx.x + (unsigned)pf_wgs;
+        const unsigned b2 = L2 / gridDim.x, bx2 = L2 - b2 * gridDim.x;
+        if (b2 < gridDim.y) {
+            const int n02 = (int)bx2 * npb, nl = (min(npb, N - n02) + 31) >> 5;      // 128-byte lines per tile row
+            const float* xp = x + (size_t)b2 * M * N + n02;
+            for (int e = threadIdx.x; e < M * nl; e += 1024) {
+                const int m = e / nl, j = e - m * nl;
+                pfv += xp[(size_t)m * N + 32 * j];
+            }
+            if (BUILD) {
+                const float* lp = reinterpret_cast<const float*>(location + (size_t)b2 * M * 2);
+                for (int e = 1023 - (int)threadIdx.x; e * 32 < M * 4; e += 1024) pfv += lp[e * 32];
+            }
+        }
+    }
     // ---- stream the span: wave w writes float4 units [w*per, (w+1)*per) of the nn*HW/4 units of this workgroup
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hw4 = HW >> 2;
@@ -899,6 +922,7 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
             c4 += 64 * UNR;
             if (c4 >= hw4) { c4 -= hw4; ++n; }
         }
+        asm volatile("" :: "v"(pfv));
         return;
     }
     for (; u < u1; u += 64) {
@@ -921,6 +945,7 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
         c4 += 64;
         while (c4 >= hw4) { c4 -= hw4; ++n; }
     }
+    asm volatile("" :: "v"(pfv));
 }
 
 // (Round 4 also tried WAVE tiles -- no LDS, no workgroup barrier, a wave owning 1024 cells x 16 channels with the owners in
@@ -1372,10 +1397,15 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
                 if (rc) return rc;
             }
             const dim3 grid((N + npb - 1) / npb, B);
-            if (add && build) hipLaunchKernelGGL((scatter_out_lds_kernel<true, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W);
-            else if (add) hipLaunchKernelGGL((scatter_out_lds_kernel<true, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W);
-            else if (build) hipLaunchKernelGGL((scatter_out_lds_kernel<false, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W);
-            else hipLaunchKernelGGL((scatter_out_lds_kernel<false, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W);
+            // staging prefetch distance (see the kernel): half of the workgroups the chip holds -- two 1024-thread workgroups per
+            // CU, fewer when LDS limits -- rounded to a multiple of 8
+            static const int pf_env = getenv("HPC_RLL_SCATTER_PF") ? atoi(getenv("HPC_RLL_SCATTER_PF")) : -1;
+            const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+            const int pf_wgs = pf_env >= 0 ? pf_env : (256 * per_cu / 2) & ~7;
+            if (add && build) hipLaunchKernelGGL((scatter_out_lds_kernel<true, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W, pf_wgs);
+            else if (add) hipLaunchKernelGGL((scatter_out_lds_kernel<true, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W, pf_wgs);
+            else if (build) hipLaunchKernelGGL((scatter_out_lds_kernel<false, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W, pf_wgs);
+            else hipLaunchKernelGGL((scatter_out_lds_kernel<false, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W, pf_wgs);
             return last_error();
         }
     }
