@@ -1371,9 +1371,12 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     // (add: measured -13 % at 32 x 32 maps with 128 entities, +15 % at the reference's 16 x 16 test shape with 256, where four
     // workgroups per batch element each repeat a build that outweighs their 64 KB of output)
     const bool build = g_scatter_build && W > 0 && (!add || (M <= 256 && HW >= 1024));
-    // (`add` on large maps: the LDS kernel + build at 32 / 64 channels per workgroup = key 37 = 2 / 3, measured against the
-    // cells-per-thread kernel behind the index launch -- see DESIGN.md 4.5)
-    const bool lds_pays = !add || HW * 4 <= 8 * 1024 || g_scatter_npb != 0;
+    // (`add` on large maps, rounds 4-5 before the prefetch: the LDS kernel + build at 32 / 64 channels per workgroup lost to the
+    // cells-per-thread kernel behind the index launch, 0.837 / 0.89 against 0.828 ms -- DESIGN.md 4.5)
+    // (round 5, with the staging prefetch: at C5 the LDS kernel + build at 32 channels per workgroup runs `add` in 0.811 ms against
+    // 0.823 for the cells-per-thread kernel behind its index launch -- and has no second launch: taken wherever the tables are built
+    // in the kernel)
+    const bool lds_pays = !add || HW * 4 <= 8 * 1024 || g_scatter_npb != 0 || build;
     if (g_scatter_lds_fwd && lds_pays && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0 && B <= 65535 &&
         (size_t)HW * 4 <= 32 * 1024) {
         const size_t fixed = (size_t)HW * 4 + (add ? (size_t)M * 4 : 0) + (add && build ? (size_t)((M + 3) & ~3) * 4 + 16 : 0);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Round 5: ScatterConnection `add` forward at C5 -- the cells-per-thread kernel behind the index launch (default) against the
-LDS-staged kernel with in-kernel chain tables (tune key 37 = 2: 32 channels per workgroup, 3: 64), now that its stream loop is
-unrolled.  Interleaved rounds, HIP events; bit-identical outputs expected."""
+"""Round 5: ScatterConnection `add` forward at C5 -- the cells-per-thread kernel behind the index launch (tune key 18 = 0: the
+rule's choice before the staging prefetch) against the LDS-staged kernel with in-kernel chain tables at 32 / 64 channels per
+workgroup (key 18 = 32 / 64), whose stream loop is unrolled and whose staging lines are prefetched into L2 by an earlier
+workgroup.  Interleaved rounds, HIP events; bit-identical outputs expected."""
 import os
 import statistics
 import sys
@@ -20,10 +21,10 @@ loc = torch.stack([torch.randint(0, H, (B, M), device=dev), torch.randint(0, W, 
 for mode in ("add", "cover"):
     m = ScatterConnection(B, M, C, H, W, mode)
     res, outs = {}, {}
-    keys = (1, 2, 3) if mode == "add" else (1, 0)
+    keys = (0, 32, 64) if mode == "add" else (0, 32)
     for rnd in range(3):
         for k in keys:
-            N.tune_set(37, k)
+            N.tune_set(18, k)
             y = m(x, loc)
             torch.cuda.synchronize()
             outs.setdefault(k, y.clone())
@@ -35,6 +36,6 @@ for mode in ("add", "cover"):
             e1.synchronize()
             res.setdefault(k, []).append(e0.elapsed_time(e1) / 10)
             del y
-    N.tune_set(37, 1)
+    N.tune_set(18, 0)
     for k in keys:
-        print(f"{mode} key37={k}: {statistics.median(res[k]):.4f} ms {['%.4f' % t for t in res[k]]} identical to key 1: {torch.equal(outs[k], outs[keys[0]])}")
+        print(f"{mode} key18={k}: {statistics.median(res[k]):.4f} ms {['%.4f' % t for t in res[k]]} identical to key 0: {torch.equal(outs[k], outs[keys[0]])}")
