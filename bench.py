@@ -678,7 +678,7 @@ def run_suite(dev):
             out[name + "_error"] = repr(e)
         torch.cuda.empty_cache()
     out["seconds"] = time.perf_counter() - t0
-    out["peaks"] = {"hbm_GBs": S.HBM, "mfma_f32_TFLOPs": S.MFMA_F32, "valu_wave_insts_per_s": S.VALU_PEAK}
+    out["peaks"] = {"hbm_GBs": S.HBM, "mfma_f32_TFLOPs": S.MFMA_F32, "valu_simd_cycles_per_s": S.SIMD_CYCLES}
     return out
 
 
