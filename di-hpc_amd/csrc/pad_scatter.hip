@@ -745,6 +745,7 @@ __global__ __launch_bounds__(1024) void scatter_out4_kernel(const float* __restr
 // min (empty = -1 = the largest unsigned), next[m] = the smallest later entity at the same cell, found with broadcast reads of
 // the cell list (M <= 1024; 1024 / M threads share an entity's walk over the M / 4 quads).  The same table scatter_index_kernel leaves in memory, so the
 // same output bits.  At C5 the index launch took 64 of the forward's 880 us; a workgroup spends ~1 us here.
+constexpr int kScatterCollRows = 32;   // extra x-tile rows for the cells with several entities (add, in-kernel tables)
 template <bool ADD, bool BUILD>
 __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __restrict__ x,
                                                               const int32_t* __restrict__ idx,
@@ -757,7 +758,8 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
     const int nn = min(npb, N - n0);                       // channels of this workgroup
     const int ld = npb + 1;
     float* xs = s_dyn;                                     // [M][ld]
-    int32_t* s_first = reinterpret_cast<int32_t*>(s_dyn + (((size_t)M * ld + 3) & ~(size_t)3));   // [HW] head (add) / last (cover), 16-byte aligned
+    const int tile_rows = M + (ADD && BUILD ? kScatterCollRows : 0);
+    int32_t* s_first = reinterpret_cast<int32_t*>(s_dyn + (((size_t)tile_rows * ld + 3) & ~(size_t)3));   // [HW] head (add) / last (cover), 16-byte aligned
     int32_t* s_next = s_first + HW;                        // [M]   (add only)
     const float* __restrict__ xb = x + (size_t)b * M * N + n0;
     // the x tile (float4 along the channels when aligned)
@@ -777,6 +779,13 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
             }
         }
     };
+    // add with in-kernel tables (round 5): a cell that holds TWO OR MORE entities -- 0.2 % of the cells at 256 entities on a 64 x 64
+    // map -- gets a row of its own in the x tile, the chain's sum per channel (ascending m, as everywhere), and points at it: the
+    // stream loop then treats `add` like `cover`, ONE branch-free gather per cell.  Up to kScatterCollRows such cells per batch
+    // element; a batch element with more keeps the chain walk in the loop.
+    int32_t* s_coll = s_next + 2 * ((M + 3) & ~3);         // [kScatterCollRows] cells, [kScatterCollRows] chain heads, then the counter
+    int32_t* s_ncoll = s_coll + 2 * kScatterCollRows;
+    if (ADD && BUILD && threadIdx.x == 0) *s_ncoll = 0;
     if (BUILD) {
         int32_t* s_cell = s_next + ((M + 3) & ~3);         // [M rounded to 4]   (add only)
         const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
@@ -834,6 +843,31 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
         stage_x();
     }
     __syncthreads();
+    bool walk = ADD;                                        // the stream loop walks chains (uniform)
+    if (ADD && BUILD) {
+        const int32_t* s_cell = s_next + ((M + 3) & ~3);
+        for (int m = threadIdx.x; m < M; m += 1024) {
+            const int32_t c = s_cell[m];
+            if (c >= 0 && s_first[c] == m && s_next[m] >= 0) {   // m heads a chain of two or more
+                const int i = atomicAdd(s_ncoll, 1);
+                if (i < kScatterCollRows) { s_coll[i] = c; s_coll[kScatterCollRows + i] = m; }
+            }
+        }
+        __syncthreads();
+        const int nc = *s_ncoll;
+        walk = nc > kScatterCollRows;
+        if (!walk) {
+            for (int e = threadIdx.x; e < nc * nn; e += 1024) {
+                const int ci = e / nn, nch = e - ci * nn;
+                int32_t m = s_coll[kScatterCollRows + ci];
+                float a = xs[m * ld + nch];
+                for (m = s_next[m]; m >= 0; m = s_next[m]) a += xs[m * ld + nch];
+                xs[(M + ci) * ld + nch] = a;
+                if (nch == 0) s_first[s_coll[ci]] = M + ci;
+            }
+        }
+        __syncthreads();
+    }
     // Round 5: what THIS workgroup stages came slowly -- its loads queue behind the other workgroups' stores (the memory system
     // is store-saturated: ~12 us until the tile is there, of a ~30 us lifetime) -- so before it starts streaming, a workgroup
     // touches the lines that workgroup L + pf_wgs will stage (one dword per 128-byte line of its x tile rows and of its
@@ -903,14 +937,14 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
                     const int32_t fi[4] = {f[k].x, f[k].y, f[k].z, f[k].w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        if (ADD) {
+                        if (ADD && walk) {
                             float a = 0.f;
                             if (fi[c] >= 0) {
                                 a = xn[fi[c] * ld];
                                 for (int32_t m = s_next[fi[c]]; m >= 0; m = s_next[m]) a += xn[m * ld];
                             }
                             o[k][c] = a;
-                        } else {
+                        } else {                              // cover: the owner; add: the entity, or the row that holds the cell's sum
                             const float a = xn[max(fi[c], 0) * ld];
                             o[k][c] = fi[c] >= 0 ? a : 0.f;
                         }
@@ -935,7 +969,7 @@ __global__ __launch_bounds__(1024) void scatter_out_lds_kernel(const float* __re
                 float a = 0.f;
                 if (fi[c] >= 0) {
                     a = xs[fi[c] * ld + n];
-                    if (ADD)
+                    if (ADD && walk)
                         for (int32_t m = s_next[fi[c]]; m >= 0; m = s_next[m]) a += xs[m * ld + n];
                 }
                 o[c] = a;
@@ -1379,19 +1413,21 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     const bool lds_pays = !add || HW * 4 <= 8 * 1024 || g_scatter_npb != 0 || build;
     if (g_scatter_lds_fwd && lds_pays && (HW % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && M > 0 && B <= 65535 &&
         (size_t)HW * 4 <= 32 * 1024) {
-        const size_t fixed = (size_t)HW * 4 + (add ? (size_t)M * 4 : 0) + (add && build ? (size_t)((M + 3) & ~3) * 4 + 16 : 0);
+        const size_t fixed = (size_t)HW * 4 + (add ? (size_t)M * 4 : 0) +
+                             (add && build ? (size_t)((M + 3) & ~3) * 4 + 16 + ((size_t)2 * kScatterCollRows + 2) * 4 : 0);   // + cell list, collision list
+        const size_t rows = (size_t)M + (add && build ? kScatterCollRows : 0);   // x tile rows (+ the rows of the cells with several entities)
         const bool big = g_scatter_npb != 0;
-        const size_t cap = (size_t)(big ? 100 : 52) * 1024;
+        const size_t cap = (size_t)(big ? 100 : add && build ? 60 : 52) * 1024;   // two workgroups per CU
         int npb = 0;
         static const int kNpb[5] = {64, 32, 16, 8, 4};
         for (int i = 0; i < 5 && !npb; ++i) {
             const int c = g_scatter_npb ? g_scatter_npb : kNpb[i];
-            if (c <= 64 && c >= 1 && (size_t)M * (c + 1) * 4 + 16 + fixed <= cap) npb = c;
+            if (c <= 64 && c >= 1 && rows * (c + 1) * 4 + 16 + fixed <= cap) npb = c;
             if (g_scatter_npb) break;
         }
         if (npb > N) npb = (N + 3) / 4 * 4;
-        if (npb >= 1 && (size_t)M * (npb + 1) * 4 + 16 + fixed <= cap) {
-            const size_t lds = (((size_t)M * (npb + 1) + 3) & ~(size_t)3) * 4 + fixed;
+        if (npb >= 1 && rows * (npb + 1) * 4 + 16 + fixed <= cap) {
+            const size_t lds = ((rows * (npb + 1) + 3) & ~(size_t)3) * 4 + fixed;
             const void* k = add ? (build ? (const void*)scatter_out_lds_kernel<true, true> : (const void*)scatter_out_lds_kernel<true, false>)
                                 : (build ? (const void*)scatter_out_lds_kernel<false, true> : (const void*)scatter_out_lds_kernel<false, false>);
             if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return last_error();

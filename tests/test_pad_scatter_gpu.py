@@ -469,13 +469,17 @@ def test_packed_table_rows_through_the_c_abi(n, misalign):
 
 @pytest.mark.parametrize("B,M,N,H,W", [(3, 256, 64, 64, 64), (2, 500, 12, 32, 32), (2, 512, 8, 16, 16), (2, 513, 8, 16, 16),
                                        (1, 3000, 8, 32, 32), (4, 1, 4, 8, 8), (3, 37, 17, 16, 12), (2, 255, 70, 4, 4), (2, 1024, 8, 32, 32),
-                                       (2, 1025, 8, 32, 32), (3, 700, 5, 16, 16), (2, 200, 64, 128, 128), (2, 300, 8, 100, 100)])
+                                       (2, 1025, 8, 32, 32), (3, 700, 5, 16, 16), (2, 200, 64, 128, 128), (2, 300, 8, 100, 100),
+                                       (6, 256, 8, 32, 32), (5, 240, 33, 32, 40), (4, 120, 64, 64, 64)])
 def test_scatter_in_kernel_index_build(B, M, N, H, W):
     """Round 4 (tune key 37): the LDS-staged forward kernel builds the owner table (cover: LDS atomic max; add: LDS atomic min for the
     head + a broadcast search for the next entity of the chain, M <= 512) itself instead of reading the index launch's tables.
     Against the CPU oracle and against key 37 = 0, bit for bit: heavy collisions (4 x 4 maps), M = 1, M % 4 != 0, the add
     fallback above 512 entities, cover with several entities per thread, and -- on / off only, the oracle has no such case --
-    out-of-range locations (dropped)."""
+    out-of-range locations (dropped).  Round 5: `add` gives a cell with several entities a row of its own in the staged tile (the
+    chain's sum) for up to 32 such cells per batch element and walks the chains in the stream loop beyond that: 256 entities on a
+    32 x 32 map hold 27 such cells on average -- batch elements on both sides of the limit -- 240 on 32 x 40 about 20, 120 on
+    64 x 64 two."""
     import hpc_torch_utils_network as NW
     from oracle import ref_torch as R
     rng = np.random.default_rng(M * 7 + N)

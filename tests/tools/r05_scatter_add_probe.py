@@ -37,5 +37,16 @@ for mode in ("add", "cover"):
             res.setdefault(k, []).append(e0.elapsed_time(e1) / 10)
             del y
     N.tune_set(18, 0)
+    N.tune_set(17, 0)                                   # the cells-per-thread kernel behind the index launch
+    ref = m(x, loc)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(10):
+        y = m(x, loc)
+    t1.record()
+    t1.synchronize()
+    N.tune_set(17, 1)
+    print(f"{mode} cells-per-thread kernel (key 17 = 0): {t0.elapsed_time(t1) / 10:.4f} ms; LDS kernel output identical to it: {torch.equal(ref, outs[keys[0]])}")
+    del ref, y
     for k in keys:
         print(f"{mode} key18={k}: {statistics.median(res[k]):.4f} ms {['%.4f' % t for t in res[k]]} identical to key 0: {torch.equal(outs[k], outs[keys[0]])}")
