@@ -25,7 +25,7 @@ for l in lines:
         flush()
         code = not code
         out.append(l)
-    elif code or l.strip() == "":
+    elif code or l.strip() == "" or l.startswith("#"):
         flush()
         out.append(l)
     else:
