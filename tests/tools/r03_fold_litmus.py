@@ -58,7 +58,8 @@ bad = 0
 for i in range(NSTREAM):
     bad += int((got[i] != want[i][None, :]).any(dim=1).sum().item())
 res = {"folded_launches": 3 * PER * NSTREAM, "streams": NSTREAM, "launches_per_stream": 3 * PER,
-       "workgroups_per_launch": {"td_lambda": "128+ (B=8192 columns)", "vtrace_scan": "128+", "qrdqn": B // 32}   # tau=4: 8-lane groups, 32 samples per 256-thread workgroup (dist_ops.hip); all <= kFoldMaxGrid,
+       # tau=4: 8-lane groups, 32 samples per 256-thread workgroup (dist_ops.hip); all <= kFoldMaxGrid
+       "workgroups_per_launch": {"td_lambda": "128+ (B=8192 columns)", "vtrace_scan": "128+", "qrdqn": B // 32},
        "mismatching_results": bad, "seconds": dt,
        "compared_with": "separate finalize launch (hpc_rll_tune_set(21, 0)), bit for bit, same partials",
        "device": torch.cuda.get_device_name(0)}
