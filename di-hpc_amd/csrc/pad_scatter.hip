@@ -1012,6 +1012,22 @@ __global__ __launch_bounds__(1024) void scatter_bwd_lds_kernel(const float* __re
     const int HW = H * W;
     const float* __restrict__ g = grad_out + ((size_t)b * N + n0) * HW;
     const int total = ng * HW;
+    // Round 5: the location of the thread's first (entity, channel) item is requested BEFORE the planes -- read after the
+    // barrier, as it was, every workgroup spent a memory round trip between its staging and its stores (C5 0.8155 -> 0.803 ms, 32 x 32
+    // maps 0.2125 -> 0.203, same box, profiles/r05_scatter_pf.txt).  Held RAW: a cell computed here would make the planes wait for it.
+    const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
+    constexpr int KP = 1;                                  // (four items: registers past 64, one workgroup per CU)
+    long yp[KP], xp[KP];                                   // raw: nothing waits for them before the planes are requested
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int i = threadIdx.x + 1024 * j;
+        yp[j] = xp[j] = -1;
+        if (i < M * ng) {
+            const int m = i / ng;
+            yp[j] = loc[2 * m];
+            xp[j] = loc[2 * m + 1];
+        }
+    }
     if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
         for (int i = threadIdx.x * 4; i + 3 < total; i += 4096)
             *reinterpret_cast<vfloat4*>(s_plane + i) = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(g + i));
@@ -1020,10 +1036,18 @@ __global__ __launch_bounds__(1024) void scatter_bwd_lds_kernel(const float* __re
         for (int i = threadIdx.x; i < total; i += 1024) s_plane[i] = g[i];
     }
     __syncthreads();
-    const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
     float* __restrict__ gx = grad_x + (size_t)b * M * N + n0;
     // thread <-> (entity m, channel k) with k fastest so that each entity's ng outputs are contiguous
-    for (int i = threadIdx.x; i < M * ng; i += 1024) {
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int i = threadIdx.x + 1024 * j;
+        if (i < M * ng) {
+            const int m = i / ng, k = i - m * ng;
+            const bool ok = yp[j] >= 0 && yp[j] < H && xp[j] >= 0 && xp[j] < W;
+            gx[(size_t)m * N + k] = ok ? s_plane[k * HW + (int)(yp[j] * W + xp[j])] : 0.f;
+        }
+    }
+    for (int i = threadIdx.x + 1024 * KP; i < M * ng; i += 1024) {
         const int m = i / ng, k = i - m * ng;
         const long y = loc[2 * m], xx = loc[2 * m + 1];
         const bool ok = y >= 0 && y < H && xx >= 0 && xx < W;
