@@ -184,6 +184,69 @@ def test_fuzz_dist_nstep_td():
         assert grad_err(d32.grad.numpy(), dd.grad.cpu().numpy()) < 1e-4, (T, B, N, n_atom)
 
 
+def test_fuzz_large_batch_td_kernels():
+    """Round 5: the samples-per-wave forwards (QR-DQN: four quantiles per lane / the lane-per-quantile kernel by tau % 4; C51: run
+    sums with integral positions outside the runs) over random shapes at the batch sizes that select them, against the small-batch
+    kernels (tune key 24 = 1) and -- on a slice -- the oracle.  C51 draws gamma so that runs of one, two, three-to-seven and
+    (terminal samples) all atoms occur, value ranges whose atom step is and is not a power of two, returns beyond the support."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.td import DistNStepTD, QRDQNNStepTDError
+    rng = np.random.default_rng(77)
+    n = 1500
+    try:
+        for case in range(10):
+            tau = int(rng.choice([4, 8, 12, 20, 31, 32, 33, 40, 51, 64]))
+            B = int(rng.integers(32768, 70000))
+            N, T = int(rng.integers(1, 9)), int(rng.integers(1, 5))
+            a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+            r, done = f32(rng, T, B), (rng.random(B) < 0.2).astype(np.float32)
+            w = rng.random(B).astype(np.float32) if case % 3 else None
+            vg = (0.8 + 0.2 * rng.random(B)).astype(np.float32) if case % 2 else None
+            q, nq = f32(rng, B, N, tau), f32(rng, B, N, tau)
+            res = {}
+            for key in (1, 0):
+                U.tune_set(24, key)
+                dq = G(q, True)
+                loss, per = QRDQNNStepTDError(tau, T, B, N)(dq, G(nq), G(a), G(na), G(r), G(done), 0.93, None if w is None else G(w),
+                                                            None if vg is None else G(vg))
+                loss.backward()
+                res[key] = (loss.item(), per.detach().cpu(), dq.grad.cpu())
+            (l1, p1, g1), (l0, p0, g0) = res[1], res[0]
+            assert float((g0 - g1).abs().max()) <= 4e-6 * float(g1.abs().max()), ("qrdqn grad", tau, B, N, T)
+            assert float((p0 - p1).abs().max()) <= 4e-6 * float(p1.abs().max()), ("qrdqn td_err", tau, B, N, T)
+            assert abs(l0 - l1) <= 4e-6 * abs(l1)
+            q64 = D(q[-n:], True)
+            l64, p64 = R.qrdqn_nstep_td_error(q64, D(nq[-n:]), torch.from_numpy(a[-n:]), torch.from_numpy(na[-n:]), D(r[:, -n:]),
+                                              D(done[-n:]), tau, None if w is None else D(w[-n:]), 0.93, None if vg is None else D(vg[-n:]))
+            l64.backward()
+            assert rel_err(p64.detach().numpy(), p0[-n:].numpy()) < 2e-5, ("qrdqn oracle", tau, B, N, T)
+            assert grad_err(q64.grad.numpy() * (n / B), g0[-n:].numpy()) < 2e-5
+        for case in range(10):
+            n_atom = int(rng.choice([2, 3, 18, 33, 51, 51, 64]))
+            B = int(rng.integers(16384, 50000))
+            N, T = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+            gamma = float(rng.choice([1.0, 0.99, 0.9, 0.75, 0.6, 0.4]))
+            v_min, v_max = [(-10., 10.), (-8., 8.), (0., 25.), (-3.5, 1.25)][case % 4]
+            dist = (np.abs(f32(rng, B, N, n_atom)) + 1e-3).astype(np.float32)
+            nd = np.abs(f32(rng, B, N, n_atom))
+            a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+            r = (f32(rng, T, B) * float(rng.choice([0.5, 2.0, 6.0]))).astype(np.float32)
+            done, w = (rng.random(B) < 0.2).astype(np.float32), rng.random(B).astype(np.float32)
+            res = {}
+            for key in (1, 0):
+                U.tune_set(24, key)
+                dd = G(dist, True)
+                loss, per = DistNStepTD(T, B, N, n_atom)(dd, G(nd), G(a), G(na), G(r), G(done), G(w), gamma, v_min, v_max)
+                loss.backward()
+                res[key] = (loss.item(), per.detach().cpu(), dd.grad.cpu())
+            (l1, p1, g1), (l0, p0, g0) = res[1], res[0]
+            assert float((g0 - g1).abs().max()) < 1e-6 * float(g1.abs().max()), ("c51 grad", n_atom, B, N, T, gamma, v_min)
+            assert float((p0 - p1).abs().max()) < 2e-6 * float(p1.abs().max()), ("c51 td_err", n_atom, B, N, T, gamma, v_min)
+            assert abs(l0 - l1) < 2e-6 * abs(l1)
+    finally:
+        U.tune_set(24, 0)
+
+
 def test_fuzz_scatter_and_padding():
     from hpc_rll.rl_utils import padding as P
     from hpc_rll.torch_utils.network.scatter_connection import ScatterConnection
