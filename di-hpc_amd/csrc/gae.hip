@@ -940,6 +940,7 @@ extern "C" int hpc_rll_gae_forward_ex(const float* value, const float* reward, f
     if (T == 0 || B == 0) return HPC_RLL_OK;
     if (!value || !reward || !adv || !coef) return HPC_RLL_EINVAL;
     if (!aligned(value, 4) || !aligned(reward, 4) || !aligned(adv, 4) || !aligned(coef, 4)) return HPC_RLL_EALIGN;
+    if (flags >= 0 && (flags & ~15)) return HPC_RLL_EUNSUPPORTED;   // bits 4, 5: retired in round 5
     const Cfg cfg = choose_cfg(true, T, B, max_vec(B, {value, reward, adv}), vec, lc, nw, flags);
     hipStream_t st = (hipStream_t)stream;
     if (cfg.pf) {
@@ -970,6 +971,7 @@ extern "C" int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value,
     if (!grad_value && !grad_reward) return HPC_RLL_OK;
     if (!aligned(grad_adv, 4) || !aligned(grad_value, 4) || !aligned(grad_reward, 4) || !aligned(coef, 4))
         return HPC_RLL_EALIGN;
+    if (flags >= 0 && (flags & ~15)) return HPC_RLL_EUNSUPPORTED;   // bits 4, 5: retired in round 5
     const Cfg cfg = choose_cfg(false, T, B, max_vec(B, {grad_adv, grad_value, grad_reward}), vec, lc, nw, flags);
     hipStream_t st = (hipStream_t)stream;
     if (cfg.pf && grad_value && grad_reward) {

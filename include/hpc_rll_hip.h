@@ -69,11 +69,10 @@ int hpc_rll_gae_forward_ex(const float* value, const float* reward, float* adv, 
                            int T, int B, float gamma, int vec, int lc, int nw, int flags, void* stream);
 int hpc_rll_gae_backward_ex(const float* grad_adv, float* grad_value, float* grad_reward, const float* coef,
                             int T, int B, float gamma, int vec, int lc, int nw, int flags, void* stream);
-/* Forward flags bit 3 (value 8, with explicit vec/lc/nw): the software-pipelined forward kernel (the next chunk's row
- * loads are issued before the current chunk's barrier / stores); bit-identical results.  Forward flags bit 4 (value
- * 16): the one-trajectory-per-wavefront mapping (tile staged through LDS, 64-lane shuffle scan along time) -- a
- * measured alternative, results equal up to fp32 re-association.  Flags bit 5 (value 32, with the shipped B = 65536
- * configurations (4,4,8) forward / (4,2,4) backward): XCD-contiguous column tiles (experiment; identical results).
+/* Flags bit 2 (value 4): half-wave tiles (32 columns, two time chunks per wave; narrow batches).  Bit 3 (value 8, with explicit
+ * vec/lc/nw): the software-pipelined kernel (the next chunk's row loads are issued before the current chunk's barrier /
+ * stores); bit-identical results.  Bits 4 and 5 (the one-trajectory-per-wavefront mapping and XCD-contiguous column tiles of
+ * rounds 3-4) left the library in round 5 (tests/tools/micro/gae_wpt.hip keeps the former): HPC_RLL_EUNSUPPORTED.
  *
  * Diagnostics (no reference counterpart; the reference times whole python calls, tests/test_gae.py:31-52).
  * hpc_rll_ktime_begin(capacity) arms per-launch KERNEL timing for the next `capacity` GAE launches of this process

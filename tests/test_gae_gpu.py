@@ -160,6 +160,9 @@ def test_unsupported_configuration_is_reported(dev):
     v = np.zeros((3, 4), np.float32)
     st1, st2, *_ = _ex_call(dev, v, v[:2], v[:2], 0.99, 0.97, 4, 16, 4, 0)
     assert st1 == -3 and st2 == -3
+    for retired in (16, 32, 16 | 3):   # flags bits 4 / 5 (wave-per-trajectory mapping, XCD tiles) left the library in round 5
+        st1, st2, *_ = _ex_call(dev, v, v[:2], v[:2], 0.99, 0.97, 1, 4, 4, retired)
+        assert st1 == -3 and st2 == -3
 
 
 def test_optional_gradients(dev, cref):
