@@ -78,7 +78,7 @@ __device__ __forceinline__ void xchg_put(u64* p, float v, uint32_t tag) {
 
 // Every workgroup reads every exchange word: with 192 readers per line one poll round takes ~2.6 us although the data
 // is already there (measured: 1.0 poll rounds per gather), against 0.5-0.65 us for a single reader.  Each word is
-// therefore published to `nrep` replicas (tune key 4, default 4) and workgroup w reads replica w % nrep: nrep x more
+// therefore published to `nrep` = 4 replicas (a constant since round 5) and workgroup w reads replica w % nrep: nrep x more
 // (fire-and-forget) stores, nrep x fewer readers per line.  Measured: 4 replicas -20 % per gather, 8 and more lose
 // again to the extra stores; spreading the lines over memory channels instead made no difference.
 constexpr int kMaxRep = 32;
