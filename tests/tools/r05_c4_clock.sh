@@ -22,11 +22,15 @@ for d in disp.values():
     if d["dur"] < 1e6 or "GRBM_GUI_ACTIVE" not in d:
         continue
     a = agg.setdefault(d["k"], [])
-    a.append((d["dur"], d["GRBM_GUI_ACTIVE"] / 8 / d["dur"], d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(d.get("SQ_BUSY_CYCLES", 1.0), 1.0)))
-print("# kernel: launches, mean duration ms, shader clock GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration) mean [min, max], 157.3 TF x clock / 2.4", file=out)
+    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 4 SIMDs x 256 CUs; GRBM_GUI_ACTIVE / 8 = cycles of the launch
+    a.append((d["dur"], d["GRBM_GUI_ACTIVE"] / 8 / d["dur"], d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(d["GRBM_GUI_ACTIVE"] / 8 * 1024, 1.0)))
+print("# kernel: launches, mean duration ms, shader clock GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration) mean [min, max], 157.3 TF x clock / 2.4,", file=out)
+print("#         SQ_VALU_MFMA_BUSY_CYCLES / (launch cycles x 1024 SIMDs) -- uncalibrated: read it as a ratio between kernels", file=out)
 for k, a in agg.items():
     ghz = [x[1] for x in a]
-    line = "%-50s n=%3d  %8.3f ms  %.3f GHz [%.3f, %.3f]  fp32 matrix peak at that clock %.1f TF" % (k, len(a), sum(x[0] for x in a) / len(a) / 1e6, sum(ghz) / len(ghz), min(ghz), max(ghz), 157.3 * sum(ghz) / len(ghz) / 2.4)
+    line = "%-50s n=%3d  %8.3f ms  %.3f GHz [%.3f, %.3f]  fp32 matrix peak at that clock %.1f TF  MFMA busy %.3f" % (
+        k, len(a), sum(x[0] for x in a) / len(a) / 1e6, sum(ghz) / len(ghz), min(ghz), max(ghz), 157.3 * sum(ghz) / len(ghz) / 2.4,
+        sum(x[2] for x in a) / len(a))
     print(line, file=out)
     print(line)
 PY
