@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void onehot_rows4_kernel(const float* __restri
     if (rb == 1 && planes == 1) {
         // Round 5, a workgroup per sample (rows of 4 KiB and more): the zeros of the whole row go out FIRST -- no load in front of
         // them -- and the K values are stored over them by the threads whose quads they fall in once the action has arrived (the
-        // same thread to the same address: in program order).  QR-DQN backward at B = 262144: 0.373 -> 0.363 ms, same bits.
+        // same thread to the same address: in program order).  QR-DQN backward at B = 262144: 0.373 -> 0.363 ms, same bits.  (Rows
+    // shorter than a workgroup's block -- IQN: one value per 256-byte row -- lose with it, 0.118 -> 0.140 ms: every value quad is
+    // a second, partial-line store.)
         const long a = action[b0];
         for (unsigned q = threadIdx.x; q < quads; q += 256) __builtin_nontemporal_store(zero4, reinterpret_cast<vfloat4*>(out + (long)q * 4));
         const int lo = (a >= 0 && a < (long)N) ? (int)a * K : -K - 4;
