@@ -781,7 +781,10 @@ __global__ __launch_bounds__(256, 4) void qrdqn_fwd_quad_kernel(
     const float qneg = fabsf(tau_value - 1.f), qpos = fabsf(tau_value);
     float mine = 0.f;                                         // td_err of the sample this lane owns
     // The rows come by LDS-DMA (global_load_lds_dwordx4: lane l's 16 bytes land at word 4l of the wave's slot, no registers),
-    // those of the NEXT iteration requested before the pair loops of the current one run.
+    // those of the NEXT iteration requested before the pair loops of the current one.  (The compiler puts s_waitcnt vmcnt(0) in
+    // front of every LDS read that may alias a DMA destination, so those rows are in fact awaited before the pair loops start;
+    // with the LDS reads written in assembly and the buf store deferred past the wait -- vmcnt counts stores on this part -- the
+    // overlap is real and the kernel takes the same 51 us: five to six waves per SIMD hide the round trip either way.)
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gl_ptr;
     auto rows = [&](int c, int pb) {
