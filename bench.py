@@ -21,8 +21,10 @@ What the headline ``value`` is (BASELINE.json metric: "T=1024, B=64k; 1/2/4/8 GP
     eager vs 40 us graphed on one, 48 vs 40 on another).  So BOTH are timed in the run (W warmup + K steps each): eager
     ``module(...)`` + ``.backward()``, and ``hpc_rll.graphed`` (forward + backward captured once into a hipGraph, one
     hipGraphLaunch per step; same kernels, same order, same results), and ``hpc_rll.graphed_steps`` (4 steps per hipGraphLaunch:
-    two consecutive graph launches leave the GPU idle for 8.5 us, profiles/r05_gae_gaps.txt); the headline is the fastest,
-    named in ``config.launch``, all listed in ``config.launch_modes``.  ``--scaling weak`` / ``--launch eager|graph|graph4`` pin a reading.
+    two consecutive graph launches leave the GPU idle for 8.5 us, profiles/r05_gae_gaps.txt); the headline is the faster of
+    the two ONE-STEP-PER-LAUNCH modes (eager, graph), named in ``config.launch``; graph4 replays one static batch four times per
+    launch (a gradient-accumulation reading: the host cannot refresh inputs between its steps), so it is listed in
+    ``config.launch_modes`` and never leads.  ``--scaling weak`` / ``--launch eager|graph|graph4`` pin a reading.
     ``scaling_detail.loss_ops`` times what the GAE headline has none of -- the collective: batch-sharded V-trace + TD-lambda
     at the C3 global shape, each forward ending in its ONE all-reduce (RCCL over xGMI), with the all-reduce's share.
 Whatever the headline is, the same JSON line carries ``scaling_detail`` with BOTH readings, measured in this run after
@@ -106,6 +108,7 @@ def cpu_baseline(T, B, gamma, lam, budget_s=12.0):
     Bq = max(1, min(B, 16384))
     quarter, reps_q, dt_q = run(Bq, budget_s * 0.4, 200)
     res = {"value": full, "unit": "samples/s", "cores": int(lib.gae_ref_num_threads()), "kind": "port",
+           "value_source": "c_port_openmp (oracle/gae_ref.c); the torch restatement, run the way hpc_rll.origin runs, is `pytorch_restatement`",
            "sample": f"T={T} B={B} (the full batch of the metric's configuration) x {reps} fwd+bwd passes, "
                      f"oracle/gae_ref.c OpenMP, {dt:.1f}s",
            "quarter_batch_sample": {"value": quarter, "sample": f"T={T} B={Bq} x {reps_q} passes, {dt_q:.1f}s"}}
@@ -213,8 +216,9 @@ class SclkSampler:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # default K: a timed region of >= 2 s at N = 1 (0.244 ms per step), long enough for a 5 s SMI sampler and a DVFS hiccup
+    ap.add_argument("--steps", type=int, default=10000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--T", type=int, default=T_DEFAULT)
     ap.add_argument("--B", type=int, default=B_DEFAULT,
                     help="weak scaling: batch per GPU; strong scaling: the GLOBAL batch, split over the ranks")
@@ -382,7 +386,10 @@ def main():
             el_m, per_m = timed(st_m, args.steps, args.warmup)
             launch_modes[mode] = {"ms_per_step": el_m / args.steps * 1e3,
                                   "per_rank_ms_per_step": [p_ / args.steps * 1e3 for p_ in per_m]}
-            if best is None or el_m < best[0]:
+            #  graph4 replays 4 steps of ONE static batch per hipGraphLaunch -- the host cannot refresh the inputs
+            # between them, which is not the metric's "one training step per launch": it is timed and listed
+            # (launch_modes), it never leads.  The headline is the faster of the one-step-per-launch modes.
+            if mode != "graph4" and (best is None or el_m < best[0]):
                 best = (el_m, per_m, mode, st_m, keep_m)
             del st_m, keep_m
         elapsed, per_rank_s, launch, step, keep = best
@@ -408,7 +415,7 @@ def main():
     v_d, r_d = value.detach(), reward.detach()
     adv = torch.empty_like(r_d)
     gv, gr = torch.empty_like(v_d), torch.empty_like(r_d)
-    n_ev = max(args.steps, 100)
+    n_ev = min(max(args.steps, 100), 500)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_ev + 1)]
     U.GaeForward([v_d, r_d], [adv], gamma, lam)
     U.GaeBackward([grad_adv], [gv, gr], gamma, lam)
@@ -476,7 +483,7 @@ def main():
             proj = {}
             for n in (2, 4, 8):
                 modes = {m: base_ms / detail["strong_per_rank_probe"][str(n)][m]["ms_per_step"] for m in ("eager", "graph", "graph4")}
-                modes["best"] = max(modes.values())
+                modes["best"] = max(modes["eager"], modes["graph"])   # one step per launch only; graph4 listed beside it
                 proj[str(n)] = modes
             detail["projected_strong_x"] = {"n1_ms_per_step": base_ms, "by_ranks": proj,
                                             "note": "N = 1 step of this run (B = 65536, eager) / one-GPU step at B = 65536 / N"}
@@ -548,6 +555,11 @@ def main():
                          "stream_event_fwd_us": t_fwd_ev * 1e6, "stream_event_bwd_us": t_bwd_ev * 1e6,
                          "sclk_mhz": sclk.summary(), "launch_config": cfg},
             "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per_rank_s],
+            # what carried the barriers and the gather of the per-rank times: "nccl" = RCCL with `rccl_ranks` ranks; "gloo" =
+            # the fall-back (or a test hook) -- then this line is NOT an RCCL result, whatever `n_gpus` says
+            "backend": (dist.get_backend() if dist is not None else None),
+            "rccl_ranks": (dist.get_world_size() if dist is not None and dist.get_backend() == "nccl" else None),
+            "devices_distinct": (not one_device),
             "scaling_detail": detail,
             "suite": suite,
             "cpu_baseline": None if (args.skip_cpu_baseline or world > 1) else cpu_baseline(T, B, gamma, lam),

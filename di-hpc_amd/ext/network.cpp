@@ -67,7 +67,10 @@ bool lstm_recover_from_timeout(const char* what) {
 }
 
 // y_hseq: y is also the last layer's saved h sequence (hpc_rll_lstm_forward_y / _backward_y): written by the cells, no copy
-void lstm_forward_launch(const LstmDims& d, const Tensor& x, const Tensor& h0, const Tensor& c0, const Tensor& wx,
+// Returns the recurrence path THIS call ran on (hpc_rll_lstm_last_forward_path codes).  The C ABI records it per host
+// thread inside the call (csrc/lstm.hip: t_lstm_last_path), and it is read here before this thread can run anything
+// else -- another thread's forward cannot be mistaken for this one.
+int lstm_forward_launch(const LstmDims& d, const Tensor& x, const Tensor& h0, const Tensor& c0, const Tensor& wx,
                          const Tensor& wh, const Tensor& bias, const Tensor& gamma, const Tensor& beta, const Tensor& y,
                          const Tensor& hn, const Tensor& cn, const Tensor& ws, double dropout, uint64_t seed,
                          bool y_hseq = false) {
@@ -77,8 +80,9 @@ void lstm_forward_launch(const LstmDims& d, const Tensor& x, const Tensor& h0, c
             fmut(ws), (int)d.S, (int)d.B, (int)d.I, (int)d.H, (int)d.L, (float)dropout, seed, stream_of(d.dev));
         if (rc == HPC_RLL_ETIMEOUT && attempt == 0 && lstm_recover_from_timeout("this forward")) continue;
         check(rc, "hpc_rll_lstm_forward");
-        return;
+        return hpc_rll_lstm_last_forward_path();
     }
+    return -1;
 }
 
 struct LstmGrads { Tensor dx, dh0, dc0, dwx, dwh, dbias, dgamma, dbeta; };
@@ -234,7 +238,7 @@ struct LstmFn : public ag::Function<LstmFn> {
         // allowed and caught by the version counter if (and only if) a backward through this node follows.
         Tensor y = new_f32({d.S, d.B, d.H}, d.dev);
         const bool y_hseq = y_saved && d.S > 0;
-        lstm_forward_launch(d, x, h0, c0, wx, wh, bias, gamma, beta, y, hn, cn, ws, dropout, (uint64_t)seed, y_hseq);
+        const int fwd_path = lstm_forward_launch(d, x, h0, c0, wx, wh, bias, gamma, beta, y, hn, cn, ws, dropout, (uint64_t)seed, y_hseq);
         if (y_hseq) ctx->save_for_backward({x, h0, c0, wx, wh, gamma, ws, y});
         else ctx->save_for_backward({x, h0, c0, wx, wh, gamma, ws});
         ctx->saved_data["dropout"] = dropout;
@@ -242,7 +246,7 @@ struct LstmFn : public ag::Function<LstmFn> {
         ctx->saved_data["bias_shape"] = bias.sizes().vec();
         ctx->saved_data["beta_shape"] = beta.sizes().vec();
         ctx->saved_data["persist_epoch"] = g_persist_epoch.load();
-        ctx->saved_data["persistent_fwd"] = hpc_rll_lstm_last_forward_path() != 0 && hpc_rll_lstm_last_forward_path() != 3;
+        ctx->saved_data["persistent_fwd"] = fwd_path != 0 && fwd_path != 3;   // the path of THIS node's own launch
         return {y, hn, cn};
     }
     static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {

@@ -59,5 +59,22 @@ nqi = torch.randn(tau, Bi, Nt, device=dev, generator=g)
 IQNNStepTDError(tau, tau, nstep, Bi, Nt)(qi, nqi, at_[:Bi].contiguous(), nat[:Bi].contiguous(), rew[:, :Bi].contiguous(),
                                         done[:Bi].contiguous(), torch.rand(tau, Bi, device=dev, generator=g), 0.99, 1.0,
                                         w[:Bi].contiguous())[0].backward()
+del qi, nqi
+# round 6: the packed Pad1D over 2^20 ragged rows (C5) and the fused PPO launch
+from hpc_rll.rl_utils import padding as P
+from hpc_rll.rl_utils.ppo import PPO
+import numpy as np
+n1m = 1 << 20
+lens1m = torch.from_numpy(np.random.default_rng(1).integers(32, 128, n1m)).to(dev)
+flat1m = torch.randn(int(lens1m.sum().item()), device=dev)
+P.Padding1DPacked(flat1m, lens1m, max_len=127)
+del flat1m, lens1m
+Bp, Np = 65536, 128
+ln = torch.randn(Bp, Np, device=dev, generator=g, requires_grad=True)
+lo = torch.randn(Bp, Np, device=dev, generator=g)
+ap = torch.randint(0, Np, (Bp,), device=dev, generator=g)
+vn = torch.randn(Bp, device=dev, generator=g, requires_grad=True)
+vo, advp, retp = (torch.randn(Bp, device=dev, generator=g) for _ in range(3))
+sum(PPO(Bp, Np)(ln, lo, ap, vn, vo, advp, retp)[0]).backward()
 torch.cuda.synchronize()
 print("pmc suite done")
