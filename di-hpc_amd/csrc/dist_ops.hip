@@ -468,7 +468,12 @@ __global__ __launch_bounds__(256) void dist_nstep_fwd_batch_kernel(
                 // instructions)
                 const float num = -bcast(w_l, c + u) * proj, rp = __builtin_amdgcn_rcpf(pk[u]);
                 const float g0 = num * rp;
-                buf[(size_t)bst * n_atom + lane] = fmaf(fmaf(-pk[u], g0, num), rp, g0) * scale;
+                float gq = fmaf(fmaf(-pk[u], g0, num), rp, g0);
+                //  v_rcp_f32 flushes subnormal inputs: a probability below FLT_MIN with proj == 0 (common when
+                // done = 1) would give 0 * inf = NaN where the division -- the small-batch kernels, the reference -- gives 0,
+                // and an overflowing quotient turns into NaN in the correction step.  Those lanes take the division.
+                if (pk[u] < 1.17549435e-38f || !(fabsf(g0) <= 3.402823466e+38f)) gq = num / pk[u];
+                buf[(size_t)bst * n_atom + lane] = gq * scale;
             }
             const float tot = bcast(group_sum_last<64>(ce), 63);      // DPP sum: no LDS round trips
             if (lane % SW == c + u) mine = -tot;

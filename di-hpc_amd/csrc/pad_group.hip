@@ -444,7 +444,9 @@ extern "C" int hpc_rll_pad1d_group_plan(const int64_t* lengths, int64_t n, int m
     int32_t* hist = reinterpret_cast<int32_t*>(ws);
     int64_t* dp = ws + (bins + 1) / 2;
     const int64_t dp_words = bins + (bins + 1) + 2 * (bins + 1) + ((int64_t)(group + 1) * (bins + 1) + 1) / 2;
-    int32_t* table = reinterpret_cast<int32_t*>(dp + dp_words);
+    //  the digit table is read with 16-byte loads (tile_thread_load): it starts on an EVEN int64 word of the
+    // workspace (one pad word where hist + dp is odd, inside the 8 spare words hpc_rll_pad1d_group_workspace_int64 adds)
+    int32_t* table = reinterpret_cast<int32_t*>(dp + dp_words + ((((bins + 1) / 2) + dp_words) & 1));
     int32_t* keys_a = table + 2 * ((256 * (int64_t)(nchunks > 0 ? nchunks : 1) + 1) / 2);
     int32_t* keys_b = keys_a + 2 * ((n + 1) / 2);
     int64_t* idx_tmp = reinterpret_cast<int64_t*>(keys_b + 2 * ((n + 1) / 2));

@@ -1464,7 +1464,16 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
             // CU, fewer when LDS limits -- rounded to a multiple of 8
             static const int pf_env = getenv("HPC_RLL_SCATTER_PF") ? atoi(getenv("HPC_RLL_SCATTER_PF")) : -1;
             const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
-            const int pf_wgs = pf_env >= 0 ? pf_env : (256 * per_cu / 2) & ~7;
+            // CU count of the device the launch goes to (was the literal 256), read once per device
+            static int cu_cache[16] = {0};
+            int devid = 0;
+            (void)hipGetDevice(&devid);
+            int cus = devid >= 0 && devid < 16 ? cu_cache[devid] : 0;
+            if (cus <= 0) {
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess || cus <= 0) cus = 256;
+                if (devid >= 0 && devid < 16) cu_cache[devid] = cus;
+            }
+            const int pf_wgs = pf_env >= 0 ? pf_env : (cus * per_cu / 2) & ~7;
             if (add && build) hipLaunchKernelGGL((scatter_out_lds_kernel<true, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W, pf_wgs);
             else if (add) hipLaunchKernelGGL((scatter_out_lds_kernel<true, false>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W, pf_wgs);
             else if (build) hipLaunchKernelGGL((scatter_out_lds_kernel<false, true>), grid, dim3(1024), lds, st, x, ws, out, M, N, (int)HW, npb, location, W, pf_wgs);

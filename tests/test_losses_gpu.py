@@ -693,6 +693,49 @@ def test_c51_samples_per_wave_kernel_ragged(B, sw):
     assert abs(l0 - l1) < 1e-6 * abs(l1)
 
 
+def test_c51_subnormal_probabilities_take_the_division():
+    """the samples-per-wave forward computes (-w proj) / p with v_rcp_f32 + one correction; v_rcp flushes subnormal
+    inputs, so p in [1e-45, 1e-38] with proj == 0 (every atom but one or two when done = 1) would give 0 * inf = NaN where
+    the division of the wave-per-sample kernel (tune key 24 = 1) and the reference give 0.  Lanes with p < FLT_MIN or an
+    overflowing quotient take the division: the two kernel families agree on such inputs, NaN-free where proj == 0."""
+    import hpc_rl_utils as U
+    from hpc_rll.rl_utils.td import DistNStepTD
+    T, B, N, n_atom = 2, 40000, 3, 51
+    rng = np.random.default_rng(77)
+    dist = (np.abs(f32(rng, B, N, n_atom)) + 1e-3).astype(np.float32)
+    tiny = rng.random((B, N, n_atom)) < 0.3
+    dist[tiny] = (10.0 ** rng.uniform(-45, -38, int(tiny.sum()))).astype(np.float32)    # subnormal (some flush to 0: kept > 0 below)
+    dist[tiny & (dist == 0)] = np.float32(1e-45)
+    nd = np.abs(f32(rng, B, N, n_atom))
+    a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+    r = (rng.integers(-8, 9, (T, B)) * 0.25).astype(np.float32)
+    done = np.ones(B, np.float32)                                   # the whole target mass lands on one or two atoms
+    w = rng.random(B).astype(np.float32)
+    res = {}
+    try:
+        for key in (1, 8, 0):
+            U.tune_set(24, key)
+            dd = G(dist, True)
+            loss, per = DistNStepTD(T, B, N, n_atom)(dd, G(nd), G(a), G(na), G(r), G(done), G(w), 1.0, -5., 5.)
+            loss.backward()
+            res[key] = (per.detach().cpu(), dd.grad.cpu())
+    finally:
+        U.tune_set(24, 0)
+    p1, g1 = res[1]
+    fin = torch.isfinite(g1)
+    assert fin.float().mean() > 0.97                                # (a subnormal p under a non-zero projection overflows: in both)
+    for key in (8, 0):
+        p0, g0 = res[key]
+        assert torch.equal(torch.isfinite(g0), fin), (int((~torch.isfinite(g0)).sum()), int((~fin).sum()))
+        assert not torch.isnan(g0[fin]).any()
+        assert float((g0[fin] - g1[fin]).abs().max()) <= 4e-7 * float(g1[fin].abs().max())
+        zero = fin & (g1 == 0)
+        assert float(g0[zero].abs().max()) == 0.0
+        okp = torch.isfinite(p1)
+        assert torch.equal(torch.isfinite(p0), okp)
+        assert float((p0[okp] - p1[okp]).abs().max()) <= 1e-6 * float(p1[okp].abs().max())
+
+
 # ------------------------------------------------------------------------------------------------ misc
 @pytest.mark.parametrize("op,B,N,K", [("c51", 20011, 6, 51), ("c51", 4096, 64, 51), ("qrdqn", 33000, 5, 32), ("qrdqn", 9001, 7, 20),
                                       ("qrdqn", 5000, 3, 64), ("qrdqn", 3000, 4, 76), ("c51", 7000, 3, 18)])
