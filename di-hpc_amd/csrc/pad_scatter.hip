@@ -1000,7 +1000,14 @@ __global__ __launch_bounds__(1024) void scatter_bwd_lds_kernel(const float* __re
     // L = (i % 8) * (total / 8) + i / 8 as the logical index, the channel groups of a batch element take consecutive slots of one
     // XCD and their pieces meet in ONE L2 before the line leaves it.
     unsigned bi = blockIdx.y, ci = blockIdx.x;
-    if (xcd_order) {
+    if (xcd_order == 2) {
+        // round 6: XCD x takes the batch elements b = 8 q + x -- the eight XCDs read EIGHT NEIGHBOURING batch elements at any time
+        // (one moving window of grad_out) instead of eight streams total/8 apart, whose relative placement in the memory
+        // channels made the kernel 12 % slower on some allocations of grad_out (profiles/r06_scatter_bwd_probe.txt)
+        const unsigned nx = gridDim.x, id = blockIdx.x + nx * blockIdx.y, slot = id >> 3;
+        bi = (slot / nx) * 8 + (id & 7u);
+        ci = slot % nx;
+    } else if (xcd_order) {
         const unsigned nx = gridDim.x, total = nx * gridDim.y, id = blockIdx.x + nx * blockIdx.y;
         const unsigned L = (id & 7u) * (total >> 3) + (id >> 3);
         bi = L / nx;
@@ -1085,6 +1092,7 @@ int g_scatter_npb = 0;       // key 18: channels per workgroup of the LDS-staged
 int g_scatter_build = 1;     // key 37: 1 = owner table / chain links built inside the forward kernel, 0 = index launch
 int g_scatter_bwd_xcd = 1;   // key 38: 1 = XCD-major workgroup order of the backward where its pieces are below a sector pair, 0 = launch order
 constexpr int g_scatter_threads = 1024;     // threads per workgroup of the cells-per-thread kernel on maps of >= 4096 cells
+int g_scatter_bwd_tile = 0;                 // hpc_rll_tune_set key 40: scatter backward by spatial tiles: 0 = by rule, 1 = never, 2 = wherever it applies
 constexpr int g_scatter_bwd_lds_kb = 64;    // planes staged per backward workgroup (profiles/r04_scatter_bwd_lds.txt)
 }
 using namespace hpc_rll;
@@ -1502,6 +1510,77 @@ extern "C" int hpc_rll_scatter_connection_forward(const float* x, const int64_t*
     return last_error();
 }
 
+// Round 6: backward by SPATIAL tiles.  Workgroup = (batch element, TR map rows): it stages rows y0 .. y0+TR-1 of ALL N planes (N
+// contiguous pieces of TR*W floats, 1 KB each at C5) and owns every entity whose location falls into those rows -- it writes
+// their whole N-float rows of grad_x (256 contiguous bytes at C5: full lines, one writer per line) instead of a 16-byte
+// piece of every entity's row from each of N/NG workgroups that have to meet in one XCD's L2.  Every workgroup scans the
+// batch element's M locations (4 KB, from L2) to find its entities; the rows of out-of-range entities (zeros) are dealt over the tiles.
+// LDS: plane n at s_tile + n*cells, cell c at position c ^ (4*(n & swz)) -- a gather of one cell over the planes (stride
+// cells: one bank) spreads over 8 banks, the float4 staging stays aligned.  The gather result is the plane kernel's, bit for bit.
+__global__ __launch_bounds__(1024) void scatter_bwd_tile_kernel(const float* __restrict__ grad_out,
+                                                                const int64_t* __restrict__ location,
+                                                                float* __restrict__ grad_x, int M, int N, int H, int W,
+                                                                int TR, int swz, int xcd_order) {
+    extern __shared__ __attribute__((aligned(16))) float s_tile[];   // [N][cells], then the entity list (int32 x 2 per entry) and its counter
+    unsigned bi = blockIdx.y, ti = blockIdx.x;
+    if (xcd_order == 2) {   // the tiles of a batch element on one XCD, neighbouring batch elements on the eight XCDs
+        const unsigned nx = gridDim.x, id = blockIdx.x + nx * blockIdx.y, slot = id >> 3;
+        bi = (slot / nx) * 8 + (id & 7u);
+        ti = slot % nx;
+    } else if (xcd_order) {   // the tiles of a batch element on one XCD (they read neighbouring 1 KB pieces of the same planes)
+        const unsigned nx = gridDim.x, total = nx * gridDim.y, id = blockIdx.x + nx * blockIdx.y;
+        const unsigned L = (id & 7u) * (total >> 3) + (id >> 3);
+        bi = L / nx;
+        ti = L - bi * nx;
+    }
+    const int b = (int)bi, y0 = (int)ti * TR;
+    const int rows = min(TR, H - y0), cells = TR * W, live = rows * W;
+    const int HW = H * W;
+    int* const s_cnt = reinterpret_cast<int*>(s_tile + (size_t)N * cells);
+    int* const s_list = s_cnt + 4;                       // [M][2]: entity, cell inside the tile (-1: write zeros)
+    if (threadIdx.x == 0) *s_cnt = 0;
+    const int64_t* __restrict__ loc = location + (size_t)b * M * 2;
+    // locations first (raw), planes next: nothing waits before every request is out
+    long yy[4], xx[4];
+    const int nl = (M + 1023) / 1024;                    // (M <= 4096 on this path)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = threadIdx.x + 1024 * j;
+        yy[j] = xx[j] = 0;
+        if (j < nl && m < M) { yy[j] = loc[2 * m]; xx[j] = loc[2 * m + 1]; }
+    }
+    const float* __restrict__ g = grad_out + (size_t)b * N * HW + (size_t)y0 * W;
+    const int q4 = live >> 2;                            // float4 per plane piece (W % 4 == 0 on this path)
+    const int total4 = N * q4;
+    for (int i = threadIdx.x; i < total4; i += 1024) {
+        const int n = i / q4, c = (i - n * q4) * 4;
+        const vfloat4 v = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(g + (size_t)n * HW + c));
+        *reinterpret_cast<vfloat4*>(s_tile + n * cells + (c ^ (4 * (n & swz)))) = v;
+    }
+    __syncthreads();   // (the counter's zero is visible)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = threadIdx.x + 1024 * j;
+        if (j < nl && m < M) {
+            const bool ok = yy[j] >= 0 && yy[j] < H && xx[j] >= 0 && xx[j] < W;
+            const bool mine = ok ? (yy[j] >= y0 && yy[j] < y0 + rows) : (unsigned)m % gridDim.x == ti;   // zero rows: dealt over the tiles
+            if (mine) {
+                const int slot = atomicAdd(s_cnt, 1);
+                s_list[2 * slot] = m;
+                s_list[2 * slot + 1] = ok ? (int)((yy[j] - y0) * W + xx[j]) : -1;
+            }
+        }
+    }
+    __syncthreads();
+    const int cnt = *s_cnt;
+    float* __restrict__ gx = grad_x + (size_t)b * M * N;
+    for (int i = threadIdx.x; i < cnt * N; i += 1024) {
+        const int e = i / N, k = i - e * N;
+        const int m = s_list[2 * e], c = s_list[2 * e + 1];
+        gx[(size_t)m * N + k] = c >= 0 ? s_tile[k * cells + (c ^ (4 * (k & swz)))] : 0.f;
+    }
+}
+
 extern "C" int hpc_rll_scatter_connection_backward(const float* grad_out, const int64_t* location, float* grad_x,
                                                    int B, int M, int N, int H, int W, void* stream) {
     if (B < 0 || M < 0 || N < 0 || H < 0 || W < 0) return HPC_RLL_EINVAL;
@@ -1510,6 +1589,37 @@ extern "C" int hpc_rll_scatter_connection_backward(const float* grad_out, const 
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
     const long plane_bytes = HW * 4;
+    // Which kernel (round 6, profiles/r06_scatter_bwd_probe.txt).  The plane kernel writes NG*4-byte pieces of every entity's row
+    // from N/NG workgroups; where those pieces are 16 bytes or less (maps of 4096 cells and more) AND the entity rows are a
+    // sizeable part of the traffic (M*16 >= H*W: C5 exactly), the spatial-tile kernel -- full rows from one writer -- is faster
+    // (M = 1024, N = 128: 1086 -> 946 us; C5: 741 -> 724 us mean of 50 buffer sets on five boxes) and half as sensitive to where
+    // grad_out and grad_x lie relative to each other (C5: +5 % instead of +12 % on an unlucky pair).  Few entities per map
+    // (B = 8192, M = 64: 656 vs 710 us) and small maps (32 x 32: 249 vs 288) keep the plane kernel.  Key 40 forces either.
+    const long pieces = std::min<long>(N, std::max<long>(1, (long)g_scatter_bwd_lds_kb * 1024 / std::max<long>(plane_bytes, 1))) * 4;
+    const bool tile_rule = g_scatter_bwd_tile == 2 || (g_scatter_bwd_tile == 0 && pieces <= 16 && (long)M * 16 >= HW);
+    if (tile_rule && (W % 4) == 0 && M <= 4096 && B <= 65535 && (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0 &&
+        (long)N * W * 4 <= 64 * 1024) {
+        int TR = (int)(64L * 1024 / ((long)N * W * 4));
+        if (TR > H) TR = H;
+        int p2 = 1;
+        while (p2 * 2 <= TR) p2 *= 2;                    // a power of two (the swizzle XORs inside a plane piece)
+        TR = p2;
+        const int cells = TR * W;
+        int swz = 0;
+        if ((cells & (cells - 1)) == 0 && cells >= 8) { swz = cells / 4 - 1; if (swz > 63) swz = 63; }
+        const size_t lds = (size_t)N * cells * 4 + 16 + (size_t)M * 8;
+        // plane pieces of a tile: 1 KB and more where entity rows are a sixteenth of the planes (C5), 512 bytes only where they are a
+        // quarter (N = 128, M = 1024: 1070 -> 945 us; N = 128, M = 256 keeps the plane kernel: 714 vs 747)
+        const bool pays = ((long)cells * 4 >= 1024 && (long)M * 16 >= HW) || ((long)cells * 4 >= 512 && (long)M * 4 >= HW);
+        if (pays || g_scatter_bwd_tile == 2) {
+            const dim3 grid((H + TR - 1) / TR, B);
+            if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)scatter_bwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)lds) != hipSuccess)
+                return last_error();
+            hipLaunchKernelGGL(scatter_bwd_tile_kernel, grid, dim3(1024), lds, st, grad_out, location, grad_x, M, N, H, W, TR, swz, 0);
+            return last_error();
+        }
+    }
     if (plane_bytes <= 128 * 1024 && B <= 65535) {
         int NG = (int)std::min<long>(N, std::max<long>(1, (long)g_scatter_bwd_lds_kb * 1024 / plane_bytes));
         if (NG > 32) NG = 32;
@@ -1523,7 +1633,9 @@ extern "C" int hpc_rll_scatter_connection_backward(const float* grad_out, const 
         // 64-byte pieces (32 x 32 maps) +6 %, whole lines (16 x 16) +4 % -- only pieces below a 64-byte sector pair profit
         const int xcd_order = (g_scatter_bwd_xcd == 2 || (g_scatter_bwd_xcd == 1 && NG * 4 <= 32)) &&
                               ((long)grid.x * grid.y) % 8 == 0 && grid.x > 1;
-        hipLaunchKernelGGL(scatter_bwd_lds_kernel, grid, dim3(1024), lds, st, grad_out, location, grad_x, M, N, H, W, NG, xcd_order);
+        // (round 6) with B a multiple of 8 the XCDs take NEIGHBOURING batch elements (order 2: -1 % on every shape measured)
+        const int xo2 = (xcd_order && B % 8 == 0) ? 2 : xcd_order;
+        hipLaunchKernelGGL(scatter_bwd_lds_kernel, grid, dim3(1024), lds, st, grad_out, location, grad_x, M, N, H, W, NG, xo2);
     } else {
         const long total = (long)B * M * N;
         long blocks = (total + 255) / 256;

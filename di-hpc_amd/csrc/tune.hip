@@ -11,7 +11,7 @@
 namespace hpc_rll {
 extern int g_lstm_persist, g_lstm_wave, g_gemm_tile256, g_scatter_lds_fwd, g_scatter_npb, g_scan_fold, g_split_algo, g_sample_batch,
     g_gemm_dma, g_lstm_block, g_lstm_block_skew, g_pad_wave, g_lstm_mid, g_onehot_fill_mb, g_ppo_fused, g_lstm_mid_bwd, g_onehot_qpw,
-    g_scatter_build, g_scatter_bwd_xcd;
+    g_scatter_build, g_scatter_bwd_xcd, g_scatter_bwd_tile;
 namespace {
 struct TuneKey {
     int key;
@@ -40,6 +40,7 @@ const TuneKey kKeys[] = {
     {35, &g_onehot_qpw, 0, 8192, 0, "16-byte quads per workgroup of the one-launch one-hot kernel (0 = by size, else 256 ... 8192)"},
     {37, &g_scatter_build, 0, 1, 0, "scatter owner table / chain links built inside the forward kernel (1) or by the index launch (0)"},
     {38, &g_scatter_bwd_xcd, 0, 2, 0, "scatter backward: XCD-major workgroup order where its pieces are below a 64-byte sector pair (1), always (2), or launch order (0)"},
+    {40, &g_scatter_bwd_tile, 0, 2, 0, "scatter backward by spatial tiles (full entity rows from one writer): 0 = by rule (16-byte pieces and M*16 >= H*W), 1 = never (plane kernel), 2 = wherever it applies"},
 };
 }  // namespace
 }  // namespace hpc_rll

@@ -137,6 +137,8 @@ int hpc_rll_categorical_backward(const float* logits, const int64_t* action, con
  *   key 35  16-byte quads per workgroup of the one-launch one-hot kernel (256 ... 8192; 0, default = by size)
  *   key 37  scatter owner table / chain links built inside the forward kernel: 1 (default) / 0 = index launch
  *   key 38  scatter backward in XCD-major workgroup order: 1 (default) where its pieces are below a 64-byte sector pair / 2 always / 0
+ *   key 40  scatter backward by spatial tiles (a workgroup stages map rows of ALL channels and writes whole entity rows): 0 (default) by
+ *           rule (16-byte pieces in the plane kernel and M * 16 >= H * W) / 1 never / 2 wherever it applies; identical results
  * hpc_rll_tune_count / hpc_rll_tune_doc enumerate the live keys (index 0 ... count-1 -> key number and a one-line description). */
 int hpc_rll_tune_set(int key, int value);
 int hpc_rll_tune_count(void);

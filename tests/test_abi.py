@@ -104,12 +104,12 @@ def test_tuning_knobs_documented_and_guarded():
     assert N.lib.hpc_rll_tune_doc(n, None) is None
     assert sorted(live) == documented and len(live) <= 20, (sorted(live), documented)
     defaults = {3: 1, 8: 1, 16: 1, 17: 1, 18: 0, 21: 1, 22: 0, 24: 0, 25: 1, 26: 9, 27: 10, 28: 1, 29: 2, 31: 3072, 32: 1, 33: 1, 35: 0,
-                37: 1, 38: 1}
+                37: 1, 38: 1, 40: 0}
     assert sorted(defaults) == documented
     for k in live:
         assert N.lib.hpc_rll_tune_set(k, defaults[k]) == 0, k
         assert N.lib.hpc_rll_tune_set(k, -7) != 0, k
-    for k in (0, 1, 2, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 19, 20, 23, 30, 34, 36, 39, 40, 99):   # retired / never existed
+    for k in (0, 1, 2, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 19, 20, 23, 30, 34, 36, 39, 41, 99):   # retired / never existed
         assert N.lib.hpc_rll_tune_set(k, 0) != 0 and N.lib.hpc_rll_tune_set(k, 1) != 0, k
     assert N.lib.hpc_rll_tune_set(26, 2) != 0 and N.lib.hpc_rll_tune_set(26, 137) == 0 and N.lib.hpc_rll_tune_set(26, 9) == 0   # bit mask
     assert N.lib.hpc_rll_tune_set(21, 2) != 0 and N.lib.hpc_rll_tune_set(17, 2) != 0 and N.lib.hpc_rll_tune_set(37, 2) != 0   # retired values

@@ -538,3 +538,33 @@ def test_scatter_backward_xcd_order_bit_exact(B, M, N, H, W):
     want = go.permute(0, 2, 3, 1)[torch.arange(B, device=DEV)[:, None], loc[..., 0].clamp(0, H - 1), loc[..., 1]] * ok[..., None]
     assert torch.equal(outs[0], want.cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("B,M,N,H,W", [(16, 256, 64, 64, 64), (24, 1024, 128, 64, 64), (9, 37, 12, 64, 32), (40, 64, 64, 32, 32), (3, 4096, 8, 64, 64),
+                                       (5, 200, 24, 40, 52), (7, 300, 32, 128, 128), (8, 77, 20, 3, 4), (2, 50, 256, 16, 64), (11, 1, 4, 64, 32)])
+def test_scatter_backward_spatial_tile_kernel_bit_exact(B, M, N, H, W):
+    """Round 6, tune key 40: the backward by SPATIAL tiles (a workgroup stages TR map rows of all N planes and writes the whole
+    rows of the entities that fall into them) against the plane kernel (key 40 = 1) and the gather computed by torch: the same
+    bits.  Shapes: the rule's own (64 x 64 maps, M * 16 >= H * W), two rows per tile (N = 128), maps whose row count is no
+    multiple of the tile (H = 40, 3), tiles that are no power of two cells (W = 52: no swizzle), one row per tile (N = 256),
+    M = 4096 (four locations per thread), M = 1, out-of-range locations in both coordinates (zero rows, dealt over the tiles),
+    shapes where the rule keeps the plane kernel (forced with key 40 = 2), B a multiple of 8 (the plane kernel's XCD order 2) and not."""
+    import cabi as C
+    import hpc_torch_utils_network as NW
+    g = torch.Generator(device=DEV).manual_seed(B * 977 + M)
+    go = torch.randn(B, N, H, W, device=DEV, generator=g)
+    loc = torch.stack([torch.randint(-1, H + 1, (B, M), device=DEV, generator=g), torch.randint(-1, W + 1, (B, M), device=DEV, generator=g)], -1)
+    s = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    try:
+        for key in (1, 2, 0):
+            NW.tune_set(40, key)
+            gx = torch.full((B, M, N), float("nan"), device=DEV)
+            assert C.lib.hpc_rll_scatter_connection_backward(go.data_ptr(), loc.data_ptr(), gx.data_ptr(), B, M, N, H, W, s) == 0
+            outs[key] = gx.cpu()
+    finally:
+        NW.tune_set(40, 0)
+    ok = (loc[..., 0] >= 0) & (loc[..., 0] < H) & (loc[..., 1] >= 0) & (loc[..., 1] < W)
+    want = go.permute(0, 2, 3, 1)[torch.arange(B, device=DEV)[:, None], loc[..., 0].clamp(0, H - 1), loc[..., 1].clamp(0, W - 1)] * ok[..., None]
+    assert torch.equal(outs[1], want.cpu())
+    assert torch.equal(outs[2], outs[1]) and torch.equal(outs[0], outs[1])
