@@ -453,11 +453,6 @@ typedef unsigned int blk_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t blk_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
-// the same descriptor as four dwords (for inline assembly): base, stride 0, 2^31 - 1 records, raw dword format
-__device__ __forceinline__ blk_u32x4 blk_desc(const void* p) {
-    const unsigned long long ad = (unsigned long long)p;
-    return blk_u32x4{(unsigned)ad, (unsigned)(ad >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
-}
 template <int AUX> __device__ __forceinline__ vfloat4 blk_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(vfloat4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
 }
@@ -506,7 +501,6 @@ struct BlockBwd {
     int skew_ticks;
     u64* prof;
     int xcd_map;                        // the 8-row-block groups of the launch are laid out XCD-major (see the kernel)
-    const float* dy_last;               // lstm_block_bwd2_kernel: (B,H) dy_{S-1} + dhn, prepared by blk_dy_last_kernel in `dc` (null: none)
 };
 
 // Round 5 on this kernel (profiles/r05_lstm_block_bwd_ab.json, _phases.txt, _abl.txt; C4, one process, interleaved):
@@ -525,6 +519,11 @@ struct BlockBwd {
 //   * 128 x 64 tiles with TWO 4-wave workgroups per CU (one's epilogue under the other's product; commit 7e6db35): 136.2 against
 //     134.5 ms -- a lone wave per SIMD does not drive the matrix pipe at twice its shared rate, the operand bytes per flop grow
 //     1.5 x, the epilogue passes slow down beside the partner's product (profiles/r05_lstm_bwd_bn_probe.txt).
+// Round 6 (profiles/r06_lstm_block_bwd.txt; the code is commit "experiment: row-block LSTM backward variants"): the product
+// starting on the workgroup's own k-range of dHW before the row block's flag (+10 ms: the eight workgroups of a row block stop
+// sharing A tiles in L2), pass A with every other chunk's xw / hw by LDS-DMA into per-wave LDS buffers or with register slots
+// reloaded the moment their pair is consumed (170-260 spills: 256 registers per wave leave no room for a second chunk in flight),
+// pass A's first chunk under the peeled last k-tile (pass A -3.8 us, product +12 us), the row-sum combine by all threads (neutral).
 struct BlkBwdCfg {
     static constexpr int NBUF = 2, BK = 32, BM = 128, BN = 128, NTH = 512;
     static constexpr int tile_floats = NBUF * BK * (BM + BN);   // operand tiles; their first 32 * NTH floats are also the
@@ -846,367 +845,6 @@ __global__ __launch_bounds__(512, 2) void lstm_block_bwd_kernel(const BlockBwd a
     }
 }
 
-// Round 6: the same kernel with pass A's first requests under the product (VAR = 1; VAR = 0 is the round-5 schedule in this
-// code, for A/B).  What was tried on the way (profiles/r06_lstm_block_bwd.txt): the product starting on the workgroup's own k-range
-// of dHW before the row block's flag (144 vs 134 ms: the eight workgroups of a row block stop sharing the A operand in L2);
-// pass A with the xw / hw of every other chunk arriving by LDS-DMA in a per-wave LDS buffer (correct, but the compiler makes
-// every later ds_read wait for a visible LDS-DMA, and from inline assembly the register file -- 256 per wave at two waves
-// per SIMD, 27 spills already -- has no room for the pipeline: 151-219 ms); a register slot reloaded the moment its pair is
-// consumed (two chunks of lead in the same 96 registers on paper; 260 spills, the loaded values themselves go to scratch).
-// What is left and kept:
-//   * the LAST k-tile of the product is peeled off the k-loop: nothing is left to stage there, pass A's first chunk is requested
-//     before its matrix instructions and nothing after them waits for vector memory; the row statistics are requested at the
-//     start of the step;
-//   * the incoming dh_n of the last step is folded into its dy by a small launch beforehand (no conditional load in the pair
-//     arithmetic), absent inputs are masked at the use, not next to the load.
-template <int VAR>
-__global__ __launch_bounds__(512, 2) void lstm_block_bwd2_kernel(const BlockBwd a) {
-    typedef BlkBwdCfg C;
-    constexpr int NBUF = C::NBUF, RC = 4, BK = C::BK, BM = C::BM, BN = C::BN, NTH = C::NTH, NQ = BK / 8, NS = 8 / RC, NCH = 32 / RC;
-    constexpr bool FAST = true, NF = true;
-    constexpr int SC = 16;   // sc1 (write-through / L1-bypassing) on the exchanged stores and loads
-    extern __shared__ __attribute__((aligned(16))) float blk_lds[];
-    float* const As = blk_lds;                    // [NBUF][BM rows][BK]
-    float* const Bs = As + NBUF * BK * BM;        // [NBUF][BN rows (units)][BK]
-    float* const sl = blk_lds + C::tile_floats;   // [BM][4] mean_x, rstd_x, mean_h, rstd_h of this step's rows
-    float* const sa = sl + BM * 4;                // [BM][4] the four LayerNorm-adjoint row sums / 4H
-    float* const cl = sa + BM * 4;                // [3][4 BN] column sums of the workgroup (final reduction only)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1, h = lane >> 5, i32 = lane & 31;
-    // the lane's row records in sl / sa: ONE address each + compile-time offsets (written as sl + (row) * 4 the compiler
-    // materialised all 32 addresses per array as loop invariants and spilled them)
-    const float* const slp = sl + (wm * 64 + 4 * h) * 4;
-    const float* const sap = sa + (wm * 64 + 4 * h) * 4;
-    // Workgroup id -> (row block, unit tile).  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own
-    // L2.  The A operand of a row block (128 rows x 4H of dHW, 2 MB) is read by all nnt of its workgroups and by nobody else:
-    // put them on ONE XCD (ids x, x + 8, x + 16, ...), so that it crosses the fabric once instead of nnt times; every XCD then
-    // streams all of Wh (16 MB per step, shared by its 32 workgroups) instead of one tile of it.  (Linear order otherwise.)
-    int rbl = (int)blockIdx.x / a.nnt, nt = (int)blockIdx.x % a.nnt;
-    if (a.xcd_map) {
-        const int id = (int)blockIdx.x, grp = 8 * a.nnt;
-        rbl = (id / grp) * 8 + (id & 7);
-        nt = (id % grp) >> 3;
-    }
-    const int H = a.H, G = 4 * H, nnt = a.nnt;
-    const long row0 = (long)(a.rb0 + rbl) * BM;
-    const int unit = nt * BN + wn * 32 + i32;
-    unsigned* const flag_s = a.flags + 2 * rbl;
-    unsigned* const flag_h = flag_s + 1;
-    float* const part = a.part + (size_t)rbl * 2 * 4 * nnt * BM * 4;
-    const vfloat4 gx = *reinterpret_cast<const vfloat4*>(a.pp + 4 * unit);
-    const vfloat4 gh = *reinterpret_cast<const vfloat4*>(a.pp + G + 4 * unit);
-    const vfloat4 bx = *reinterpret_cast<const vfloat4*>(a.pp + 2 * G + 4 * unit);
-    const vfloat4 bh = *reinterpret_cast<const vfloat4*>(a.pp + 3 * G + 4 * unit);
-    const vfloat4 bb = *reinterpret_cast<const vfloat4*>(a.pp + 4 * G + 4 * unit);
-    const unsigned xoff = (unsigned)(4 * h) * (unsigned)G + 4u * (unsigned)unit;
-    const unsigned uoff = (unsigned)(4 * h) * (unsigned)H + (unsigned)unit;
-    if (a.skew_ticks > 0 && rbl > 0) {
-        const long long t0 = wall_clock64(), want = (long long)rbl * a.skew_ticks;
-        while (wall_clock64() - t0 < want) __builtin_amdgcn_s_sleep(32);
-    }
-    const int ktiles = G / BK;
-    int a_off[NQ], b_off[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        a_off[q] = lds_pos<BK>(wm * 64 + i32, h * (BK / 2) + 4 * q);
-        b_off[q] = lds_pos<BK>(wn * 32 + i32, h * (BK / 2) + 4 * q);
-    }
-    const float inv_g = 1.f / (float)G;
-    vfloat4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0, cs2 = cs0;   // column sums of this lane's four gate columns, all steps
-    const bool prof_on = a.prof && blockIdx.x == gridDim.x / 2 && tid == 0;
-    u64 tprev_ = prof_on ? wall_clock64() : 0;
-
-    // the product: acc = A[row block rows, all 4H] @ whp[units of the tile, all 4H]^T.  The last k-tile is peeled off the loop:
-    // `tail` runs before its matrix instructions (the epilogue's first requests go out under them) and nothing waits for
-    // vector memory after it.
-    f32x16 acc[2];
-    auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
-        const float* __restrict__ as = As + buf * BK * BM;
-        const float* __restrict__ bs = Bs + buf * BK * BN;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            gf4 av[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const gf4*>(as + a_off[q] + i * 32 * BK);
-            const gf4 bv = *reinterpret_cast<const gf4*>(bs + b_off[q]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
-        }
-    };
-    auto product = [&](const float* arows, auto&& tail) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        DmaStage<BM, BK, NTH> da;
-        DmaStage<BN, BK, NTH> db;
-        da.init(arows, G, 0, 0);
-        db.init(a.whp + (size_t)(nt * BN) * G, G, 0, 0);
-        da.issue(As);
-        db.issue(Bs);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kt = 0; kt + 1 < ktiles; ++kt) {
-            const int buf = kt & 1;
-            da.issue(As + (buf ^ 1) * BK * BM);
-            db.issue(Bs + (buf ^ 1) * BK * BN);
-            mfma_tile(buf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        tail();
-        mfma_tile((ktiles - 1) & 1);
-        __syncthreads();
-    };
-
-    // pair k (0 .. 31) of a lane = accumulator register (k >> 4, k & 15): its row inside the wave's 64 (without the lane's 4 h)
-    auto pair_row = [&](int k) __attribute__((always_inline)) { return (k >> 4) * 32 + 8 * ((k & 15) >> 2) + (k & 3); };
-
-    auto no_tail = [&]() __attribute__((always_inline)) {};
-
-    for (int s = a.S - 1; s >= 0; --s) {
-        const size_t srow = (size_t)s * a.B + row0;
-        const bool last = s == a.S - 1;
-        // (the incoming dh_n of the last step is folded into its dy beforehand: blk_dy_last_kernel, a.dy_last)
-        const bool dyl = last && a.dy_last != nullptr;
-        const bool has_dy = a.dy != nullptr || dyl, has_dci = !last || a.dcn != nullptr;
-        // the buffer descriptors of the step (four scalar registers each) are built where they are used -- under the product's
-        // tail and again after it: held across the k-loop they pushed the scalar file into spills
-        struct Desc { __amdgpu_buffer_rsrc_t xw, hw, dg, cn, cp, dy, dci, dco; };
-        auto make_desc = [&]() __attribute__((always_inline)) {
-            Desc d;
-            d.xw = blk_rsrc(a.xw + srow * G);
-            d.hw = blk_rsrc(a.hw + srow * G);
-            d.dg = blk_rsrc(a.dgate + srow * G);
-            d.cn = blk_rsrc(a.c + srow * H);
-            d.cp = blk_rsrc(s == 0 ? a.c0 + (size_t)row0 * H : a.c + (srow - a.B) * H);
-            d.dy = blk_rsrc(dyl ? a.dy_last + (size_t)row0 * H : has_dy ? a.dy + srow * H : a.c);
-            d.dci = blk_rsrc(last ? (a.dcn ? a.dcn + (size_t)row0 * H : a.c) : a.dc + (size_t)row0 * H);
-            d.dco = blk_rsrc((s == 0 ? a.dc0 : a.dc) + (size_t)row0 * H);
-            return d;
-        };
-        const unsigned xob = 4u * xoff, uob = 4u * uoff;             // the lane's byte offsets
-        const unsigned gb = 4u * (unsigned)G, hb = 4u * (unsigned)H;   // bytes per row
-        const unsigned wrow = (unsigned)(wm * 64);
-
-        // ---- pass A's inputs: xw, hw and four scalars per pair, RC pairs per set.  Raw values: what is absent (dy == null, no dc
-        // input at the last step) reads a.c and is masked in do_pair.
-        struct Full { vfloat4 x[RC], hh[RC]; float cn[RC], cp[RC], dci[RC], dy[RC]; };
-        auto load_pair = [&](const Desc& D, int c, int q, Full& v) __attribute__((always_inline)) {
-            const unsigned R = wrow + (unsigned)pair_row(RC * c + q);
-            v.x[q] = blk_ld4<0>(D.xw, xob, R * gb);   // (read again in pass B: no streaming hint)
-            v.hh[q] = blk_ld4<0>(D.hw, xob, R * gb);
-            v.cn[q] = blk_ld1<0>(D.cn, uob, R * hb);
-            v.cp[q] = blk_ld1<0>(D.cp, uob, R * hb);
-            v.dci[q] = blk_ld1<0>(D.dci, uob, R * hb);
-            v.dy[q] = blk_ld1<0>(D.dy, uob, R * hb);
-        };
-        auto load_full = [&](const Desc& D, int c, Full& v) __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < RC; ++q) load_pair(D, c, q, v);
-        };
-        Full v[NS];
-        vfloat4 stat_row = {0.f, 0.f, 0.f, 0.f};
-        if (tid < BM) stat_row = *reinterpret_cast<const vfloat4*>(a.stats + (srow + tid) * 4);   // requested before everything else of the step
-        auto tail_prefetch = [&]() __attribute__((always_inline)) {
-            if (VAR & 1) {
-                const Desc D0 = make_desc();
-                load_full(D0, 0, v[0]);
-            }
-        };
-        if (!last) {
-            block_wait(flag_h, (unsigned)(nnt * (a.S - 1 - s)), NF);   // dHW_{s+1} of this row block is complete
-            HPC_RLL_BLK_TICK(0)
-            product(a.dhw + (srow + a.B) * G, tail_prefetch);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            tail_prefetch();
-        }
-        HPC_RLL_BLK_TICK(1)
-        const Desc D = make_desc();
-        if (tid < BM) *reinterpret_cast<vfloat4*>(sl + tid * 4) = stat_row;
-
-        // ---- pass A: gate adjoints of the lane's 32 (row, unit) pairs, LayerNorm-adjoint row sums, column sums.
-        // The product's accumulators go through LDS (the operand tiles are dead now): pair k = 16 i + r of every lane at
-        // accl[k][tid] -- the epilogue is ROLLED loops over chunks of consecutive pairs.
-        float* const accl = blk_lds;   // [32][NTH] floats = the first 64 KB of the operand tiles
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accl[(16 * i + r) * NTH + tid] = acc[i][r];
-        __syncthreads();   // sl
-        const __amdgpu_buffer_rsrc_t r_xw = D.xw, r_hw = D.hw, r_dg = D.dg, r_dco = D.dco;
-        vfloat4 my = {0.f, 0.f, 0.f, 0.f};
-        auto do_pair = [&](int k, const vfloat4 x4, const vfloat4 h4, float cn, float cp, float dci_raw, float dy_raw) __attribute__((always_inline)) {
-            const float dy = has_dy ? dy_raw : 0.f, dci = has_dci ? dci_raw : 0.f;
-            const unsigned R = wrow + (unsigned)pair_row(k);
-            const vfloat4 st = *reinterpret_cast<const vfloat4*>(slp + pair_row(k) * 4);
-            float pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] = gate_pre(x4[g], st.x, st.y, gx[g], bx[g], h4[g], st.z, st.w, gh[g], bh[g], bb[g]);
-            const float ig = blk_sigmoid<FAST>(pre[0]), fg = blk_sigmoid<FAST>(pre[1]), og = blk_sigmoid<FAST>(pre[2]);
-            const float ug = blk_tanh<FAST>(pre[3]);
-            const float dh = accl[k * NTH + tid] + dy;
-            const float tc = blk_tanh<FAST>(cn);
-            const float dc = dci + dh * og * (1.f - tc * tc);
-            const vfloat4 d4 = {dc * ug * ig * (1.f - ig), dc * cp * fg * (1.f - fg), dh * tc * og * (1.f - og),
-                                dc * ig * (1.f - ug * ug)};
-            blk_st4<0>(d4, r_dg, xob, R * gb);
-            blk_st1<0>(dc * fg, r_dco, uob, R * hb);
-            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-            vfloat4 xh, hh;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                xh[g] = (x4[g] - st.x) * st.y;
-                hh[g] = (h4[g] - st.z) * st.w;
-                const float dyx = d4[g] * gx[g], dyh = d4[g] * gh[g];
-                p0 += dyx; p1 += dyx * xh[g];
-                p2 += dyh; p3 += dyh * hh[g];
-            }
-            cs0 += d4;
-            cs1 += d4 * xh;
-            cs2 += d4 * hh;
-            p0 = half_sum_all(p0); p1 = half_sum_all(p1); p2 = half_sum_all(p2); p3 = half_sum_all(p3);
-            if (i32 == k) my = vfloat4{p0, p1, p2, p3};   // lane i32 = 16 i + r = k keeps row k of its half
-        };
-        {
-            static_assert(NS == 2, "two register sets");
-            if (!(VAR & 1)) load_full(D, 0, v[0]);   // (VAR & 1: requested under the product's last k-tile)
-#pragma unroll 1
-            for (int c = 0; c < NCH; c += NS) {   // NS chunks per trip: the input sets rotate statically
-#pragma unroll
-                for (int j = 0; j < NS; ++j) {
-                    if (c + j + NS - 1 < NCH) load_full(D, c + j + NS - 1, v[(j + NS - 1) % NS]);
-#pragma unroll
-                    for (int q = 0; q < RC; ++q)
-                        do_pair(RC * (c + j) + q, v[j].x[q], v[j].hh[q], v[j].cn[q], v[j].cp[q], v[j].dci[q], v[j].dy[q]);
-                }
-            }
-        }
-        float* const pslot = part + (size_t)(s & 1) * 4 * nnt * BM * 4;
-        const __amdgpu_buffer_rsrc_t r_ps = blk_rsrc(pslot);
-        {
-            const int rr = i32 & 15;
-            const int row = wm * 64 + (i32 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-            blk_st4<SC>(my, r_ps, (unsigned)(((4 * nt + wn) * BM + row) * 16), 0u);
-        }
-        block_arrive(flag_s, NF);
-        HPC_RLL_BLK_TICK(2)
-        block_wait(flag_s, (unsigned)(nnt * (a.S - s)), NF);
-        HPC_RLL_BLK_TICK(3)
-        if (tid < BM) {
-            vfloat4 t = {0.f, 0.f, 0.f, 0.f};
-            for (int c0 = 0; c0 < 4 * nnt; c0 += 8) {
-                vfloat4 p[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    p[k] = blk_ld4<SC>(r_ps, (unsigned)(tid * 16), (unsigned)((c0 + k < 4 * nnt ? c0 + k : 0) * BM * 16));
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (c0 + k < 4 * nnt) t += p[k];
-            }
-            *reinterpret_cast<vfloat4*>(sa + tid * 4) = t * inv_g;
-        }
-        __syncthreads();
-        HPC_RLL_BLK_TICK(4)
-
-        // ---- pass B: dXW_s, dHW_s of the lane's pairs (gate adjoints, xw, hw read back: this lane's own lines, from L2)
-        {
-            const __amdgpu_buffer_rsrc_t r_dxw = blk_rsrc(a.dxw + srow * G), r_dhw = blk_rsrc(a.dhw + srow * G);
-            struct InB { vfloat4 x[RC], hh[RC], d[RC]; };
-            auto loadb = [&](int c, InB& v) __attribute__((always_inline)) {
-#pragma unroll
-                for (int q = 0; q < RC; ++q) {
-                    const unsigned R = wrow + (unsigned)pair_row(RC * c + q);
-                    v.x[q] = blk_ld4<2>(r_xw, xob, R * gb);
-                    v.hh[q] = blk_ld4<2>(r_hw, xob, R * gb);
-                    v.d[q] = blk_ld4<2>(r_dg, xob, R * gb);
-                }
-            };
-            auto do_chunk = [&](int c, const InB& v) __attribute__((always_inline)) {
-#pragma unroll
-                for (int q = 0; q < RC; ++q) {
-                    const int pr = pair_row(RC * c + q);
-                    const unsigned R = wrow + (unsigned)pr;
-                    const vfloat4 st = *reinterpret_cast<const vfloat4*>(slp + pr * 4);
-                    const vfloat4 av = *reinterpret_cast<const vfloat4*>(sap + pr * 4);
-                    vfloat4 ox, oh;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float dyx = v.d[q][g] * gx[g], dyh = v.d[q][g] * gh[g];
-                        ox[g] = st.y * (dyx - av.x - (v.x[q][g] - st.x) * st.y * av.y);
-                        oh[g] = st.w * (dyh - av.z - (v.hh[q][g] - st.z) * st.w * av.w);
-                    }
-                    blk_st4<2>(ox, r_dxw, xob, R * gb);
-                    blk_st4<SC>(oh, r_dhw, xob, R * gb);   // the next product's operand
-                }
-            };
-            InB vb[NS];
-#pragma unroll
-            for (int j = 0; j < NS - 1; ++j) loadb(j, vb[j]);
-#pragma unroll 1
-            for (int c = 0; c < NCH; c += NS) {
-#pragma unroll
-                for (int j = 0; j < NS; ++j) {
-                    if (c + j + NS - 1 < NCH) loadb(c + j + NS - 1, vb[(j + NS - 1) % NS]);
-                    do_chunk(c + j, vb[j]);
-                }
-            }
-        }
-        HPC_RLL_BLK_TICK(5)
-        block_arrive(flag_h, NF);
-        HPC_RLL_BLK_TICK(6)
-    }
-    // ---- dh0 = dHW_0 @ Wh^T, dc0 is already in place
-    block_wait(flag_h, (unsigned)(nnt * a.S), NF);
-    product(a.dhw + (size_t)row0 * G, no_tail);
-    {
-        float* const dh0 = a.dh0 + (size_t)row0 * H;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int R = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);
-                (dh0 + (size_t)R * H)[uoff] = acc[i][r];
-            }
-    }
-    // ---- column sums: the 4 lanes-sets that share a unit (two halves x two row waves) meet in LDS; fixed order
-    __syncthreads();
-    for (int e = tid; e < 3 * 4 * BN; e += NTH) cl[e] = 0.f;
-    __syncthreads();
-    for (int turn = 0; turn < 4; ++turn) {   // (wm, h) = turn: each column gets exactly one writer per turn
-        if (wm * 2 + h == turn) {
-            float* c = cl + 4 * (wn * 32 + i32);
-            *reinterpret_cast<vfloat4*>(c) += cs0;
-            *reinterpret_cast<vfloat4*>(c + 4 * BN) += cs1;
-            *reinterpret_cast<vfloat4*>(c + 2 * 4 * BN) += cs2;
-        }
-        __syncthreads();
-    }
-    float* const mine = a.colacc + (size_t)rbl * 3 * G;
-    for (int e = tid; e < 3 * 4 * BN; e += NTH) {
-        const int k3 = e / (4 * BN), c = e - k3 * 4 * BN;
-        mine[(size_t)k3 * G + 4 * nt * BN + c] = cl[e];
-    }
-}
-
-
-// dy of the last step with the incoming dh_n folded in (lstm_block_bwd2_kernel reads it as that step's dy): out = dy + dhn
-__global__ __launch_bounds__(256) void blk_dy_last_kernel(const float* __restrict__ dy, const float* __restrict__ dhn,
-                                                          float* __restrict__ out, long n4) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    vfloat4 v = reinterpret_cast<const vfloat4*>(dhn)[i];
-    if (dy) v += reinterpret_cast<const vfloat4*>(dy)[i];
-    reinterpret_cast<vfloat4*>(out)[i] = v;
-}
-
 // One column-sum row of 3 * 4H floats per 128-row block goes to the workspace's `colpart` (launch_block_bwd_t), which carve()
 // sizes for kBlockBwdMaxRowBlocks (= kCellRowsMaxWgs) rows: larger batches (B > 131072) keep the step kernels.
 constexpr int kBlockBwdMaxRowBlocks = kCellRowsMaxWgs;   // (lstm.hip, above this include: the rows carve() gives colpart)
@@ -1236,16 +874,6 @@ inline int launch_block_bwd(BlockBwd a, float* part, unsigned* flags, float* col
     a.nnt = a.H / 128;
     a.skew_ticks = g_lstm_block_skew * 100;
     a.prof = persist_prof();
-    const int var = (g_lstm_block >> 8) & 7;   // experiment (round 6): 1 = lstm_block_bwd2_kernel<1>, 2 = <0>, 0 = the round-5 kernel
-    void (*k2)(const BlockBwd) = var == 1 ? lstm_block_bwd2_kernel<1> : var == 2 ? lstm_block_bwd2_kernel<0> : nullptr;
-    if (k2 && hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes) != hipSuccess) return last_error();
-    a.dy_last = nullptr;
-    if (k2 && a.dhn) {   // fold dh_n into the last step's dy once per layer (the dc scratch is free until that step writes it)
-        const long n4 = (long)a.B * a.H / 4;
-        hipLaunchKernelGGL(blk_dy_last_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                           a.dy ? a.dy + (size_t)(a.S - 1) * a.B * a.H : (const float*)nullptr, a.dhn, a.dc, n4);
-        a.dy_last = a.dc;
-    }
     for (int rb = 0; rb < nrb; rb += per) {
         const int n = nrb - rb < per ? nrb - rb : per;
         a.rb0 = rb;
@@ -1254,8 +882,7 @@ inline int launch_block_bwd(BlockBwd a, float* part, unsigned* flags, float* col
         a.colacc = colacc + (size_t)rb * 3 * 4 * a.H;
         a.xcd_map = n % 8 == 0 ? 1 : 0;   // (linear order: neutral end to end, round 4)
         persist_chain_before(st);
-        if (k2) hipLaunchKernelGGL(k2, dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
-        else hipLaunchKernelGGL(lstm_block_bwd_kernel, dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
+        hipLaunchKernelGGL(lstm_block_bwd_kernel, dim3(n * a.nnt), dim3(512), C::lds_bytes, st, a);
         persist_chain_after(st);
     }
     persist_prof_report("row-block bwd: wait_h product passA+publish wait_s combine passB arrive_h", 0, a.S, st);

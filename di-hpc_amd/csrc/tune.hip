@@ -30,7 +30,7 @@ const TuneKey kKeys[] = {
     {22, &g_split_algo, 0, 1, 0, "group split of the padding ops: 0 = runs of equal keys, 1 = the element-level DP (host; small n)"},
     {24, &g_sample_batch, 0, 64, 0, "samples per wave of the large-batch C51 / QR-DQN forwards: 0 by batch size, 1 off, 8 / 16 / 32 / 64"},
     {25, &g_gemm_dma, 0, 2, 0, "LDS-DMA staged GEMM tiles: 1 all forms, 2 the 256x256 NT tile only, 0 register staging everywhere"},
-    {26, &g_lstm_block, 0, 2047, 1 | 8 | 128 | 0x700, "large-batch LSTM row-block kernels: bit 0 forward, bit 3 backward, bit 7 fence-free forward exchanges (default 9)"},
+    {26, &g_lstm_block, 0, 255, 1 | 8 | 128, "large-batch LSTM row-block kernels: bit 0 forward, bit 3 backward, bit 7 fence-free forward exchanges (default 9)"},
     {27, &g_lstm_block_skew, 0, 200, 0, "microseconds between the starts of consecutive row blocks of those kernels (default 10)"},
     {28, &g_pad_wave, 0, 1, 0, "packed Pad1D: 1 = wave tiles in output space, 0 = the workgroup kernel (identical results)"},
     {29, &g_lstm_mid, 0, 2, 0, "mid-batch persistent LSTM forward (5 <= B <= 256): 0 off, 1 one stream, 2 two streams where they fit"},
