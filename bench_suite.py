@@ -61,6 +61,60 @@ def valu_min(name, tau=32, tau_p=32):
     return None
 
 
+# Measured HBM traffic of the suite's kernels: profiles/suite_traffic.json, written by
+# tests/tools/collect_suite_pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x 2, calibration copy) at the
+# SAME shapes as the rows below.  A static record of a profiler run, like profiles/gae_traffic.json -- the counters cannot be
+# collected inside this process.  OP_KERNELS: the kernels of an op's forward / backward (name prefixes as the summary prints them).
+OP_KERNELS = {
+    "td_lambda": (["colscan_rev_kernel<TdLambdaOp"], ["scale_rows4_kernel"]),
+    "vtrace": (["categorical_fwd_kernel<", "categorical_fwd_noent_kernel<", "colscan_rev_kernel<VtraceOp"], ["categorical_bwd_kernel<", "scale_rows4_kernel"]),
+    "upgo": (["categorical_fwd_noent_kernel<", "colscan_rev_kernel<UpgoOp"], ["categorical_bwd_kernel<"]),
+    "ppo": (["ppo_fwd_fused_kernel<"], None),
+    "scatter_cover": (["scatter_out_lds_kernel<false"], ["scatter_bwd_tile_kernel", "scatter_bwd_lds_kernel"]),
+    "scatter_add": (["scatter_out_lds_kernel<true"], ["scatter_bwd_tile_kernel", "scatter_bwd_lds_kernel"]),
+    "pad1d_packed_api": (["pad1d_packed_wave_kernel", "packed_table_kernel<", "packed_chunk_sums_kernel"], None),
+    "dist_nstep_td": (["dist_nstep_fwd_batch_kernel<"], None),
+    "iqn_nstep_td": (["iqn_fwd_group_kernel<"], None),
+    "qrdqn_nstep_td": (["qrdqn_fwd_quad_kernel<"], None),
+}
+
+
+def traffic_record():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "suite_traffic.json")))
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def attach_traffic(row, bytes_f, bytes_b):
+    """measured HBM bytes (fetched + written) of the op's forward / backward kernels beside the algorithmic bytes the fraction is
+    priced with: `*_traffic_over_algorithmic` well above 1 would mean wasted re-reads"""
+    rec = traffic_record()
+    if not rec or row["op"] not in OP_KERNELS:
+        return
+    ks = rec["kernels"]
+
+    def total(prefixes):
+        tot, found = 0.0, []
+        for pre in prefixes:
+            for name, v in ks.items():
+                if name.startswith(pre):
+                    tot += (v["fetch_mb"] + v["write_mb"]) * 1e6
+                    found.append(name)
+                    break
+        return tot, found
+
+    for tag, prefixes, alg in (("fwd", OP_KERNELS[row["op"]][0], bytes_f), ("bwd", OP_KERNELS[row["op"]][1], bytes_b)):
+        if not prefixes or not alg:
+            continue
+        tot, found = total(prefixes)
+        if tot > 0:
+            row[tag + "_traffic_bytes"] = tot
+            row[tag + "_traffic_over_algorithmic"] = tot / alg
+            row[tag + "_traffic_kernels"] = found
+    row["traffic_source"] = "profiles/suite_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, tests/tools/collect_suite_pmc.sh)"
+
+
 def timed(fn, n=5, rounds=3):
     fn()
     ts = []
@@ -109,6 +163,8 @@ def report(name, shape, t_f, bytes_f, t_b=None, bytes_b=None, flops_f=None, flop
             r.update(bwd_tflops=flops_b / t_b / 1e12, bwd_frac=flops_b / t_b / 1e12 / MFMA_F32)
         else:
             r.update(bwd_gbs=bytes_b / t_b / 1e9, bwd_frac=bytes_b / t_b / 1e9 / HBM)
+    if not flops_f:
+        attach_traffic(r, bytes_f, bytes_b)
     rows.append(r)
     if not QUIET:
         print(json.dumps(r), flush=True)

@@ -12,5 +12,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C -d /tmp/pmc_$C -o pmc -- python "$REPO/tests/tools/pmc_suite.py" > "$REPO/gpurun_out/${TAG}_pmc_$C.log" 2>&1
 done
 python "$REPO/tests/tools/summarize_suite_pmc.py" "$(find /tmp/pmc_FETCH_SIZE -name '*.db' | head -1)" \
-    "$(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1)" > "$REPO/gpurun_out/${TAG}_suite_pmc_traffic.txt"
+    "$(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1)" "$REPO/gpurun_out/${TAG}_suite_traffic.json" > "$REPO/gpurun_out/${TAG}_suite_pmc_traffic.txt"
 tail -40 "$REPO/gpurun_out/${TAG}_suite_pmc_traffic.txt"

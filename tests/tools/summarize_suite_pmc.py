@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""HBM traffic per kernel from two rocprofv3 --pmc passes (rocpd SQLite): FETCH_SIZE and WRITE_SIZE are KiB per dispatch,
+"""(round 6: with a third argument, also writes {kernel: {fetch_mb, write_mb, launches}} as JSON -- what bench_suite.py quotes as measured traffic)
+HBM traffic per kernel from two rocprofv3 --pmc passes (rocpd SQLite): FETCH_SIZE and WRITE_SIZE are KiB per dispatch,
 summed over the counter's instances.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of a
 wide coalesced streaming read -> x2, calibrated in the same run on the device copy of a known size.  The LARGEST launch
 of every kernel is listed.   Usage: summarize_suite_pmc.py <fetch.db> <write.db>"""
@@ -39,3 +40,14 @@ for k in sorted(set(fetch) | set(write)):
     if k.startswith("at::") or "elementwise" in k or "distribution" in k:
         continue
     print(f"{k:68s} {2 * fetch.get(k, 0.0) * 1024 / 1e6:10.1f} {write.get(k, 0.0) * 1024 / 1e6:10.1f} {nf.get(k, 0)}")
+
+if len(sys.argv) > 3:
+    import json
+    rec = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tests/tools/pmc_suite.py; FETCH_SIZE x 2 (gfx950 correction, "
+                     "MI355X_MICROARCH.md), calibrated in the same run on a device copy of 2147.5 MB",
+           "calibration_copy_fetch_mb": (2 * max(cal) * 1024 / 1e6) if cal else None, "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        if k.startswith("at::") or "elementwise" in k or "distribution" in k or not k:
+            continue
+        rec["kernels"][k] = {"fetch_mb": 2 * fetch.get(k, 0.0) * 1024 / 1e6, "write_mb": write.get(k, 0.0) * 1024 / 1e6, "launches": nf.get(k, 0)}
+    json.dump(rec, open(sys.argv[3], "w"), indent=1)
