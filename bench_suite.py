@@ -186,6 +186,44 @@ def fwd_bwd(make_loss, grads_of):
     return t_f, t_b
 
 
+def host_path(make_out, grads_of, n=300):
+    """Host cost of an eager call at a shape whose kernels take less than the host path: the enqueue-only wall time per call
+    (no synchronisation inside the loop; the GPU keeps up) of the forward alone and of forward + backward, and the wall time per
+    fwd+bwd call with the final synchronisation included.  host_us = what the CPU spends per call (python + pybind + allocator
+    + autograd engine), the quantity a launch-latency-bound training step is made of."""
+    import time as _t
+    out = make_out()
+    g = torch.ones_like(out)
+
+    def fb():
+        for p in grads_of:
+            p.grad = None
+        make_out().backward(g)
+
+    for _ in range(20):
+        fb()
+    torch.cuda.synchronize()
+    res = {}
+    for name, fn in (("fwd", make_out), ("fwd_bwd", fb)):
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            for _ in range(n):
+                fn()
+            host = (_t.perf_counter() - t0) / n
+            torch.cuda.synchronize()
+            best = min(best, host)
+        res[f"host_us_per_{name}_call"] = best * 1e6
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    for _ in range(n):
+        fb()
+    torch.cuda.synchronize()
+    res["wall_us_per_fwd_bwd_call"] = (_t.perf_counter() - t0) / n * 1e6
+    return res
+
+
 def timed_graph(fn, n=10, rounds=3):
     """GPU time per call of `fn` with the host taken out: n calls captured into ONE hipGraph, replayed.  For ops whose
     kernels take a few microseconds the eager figures above are the host's (torch's autograd engine: ~27 us per
@@ -504,6 +542,27 @@ def suite_small():
     m = GAE(T, B)
     t_f, t_b = fwd_bwd(lambda: m(v, r), [v])
     report("gae_small", f"T={T} B={B}", t_f, 12 * T * B, t_b, 12 * T * B)
+    rows[-1].update(host_path(lambda: m(v, r), [v]))
+    # the same host-side reading for TD-lambda and PPO at shapes whose kernels take a few microseconds
+    from hpc_rll.rl_utils.ppo import PPO
+    from hpc_rll.rl_utils.td import TDLambda
+    Ts, Bs, Ns = 64, 64, 32
+    vs = torch.randn(Ts + 1, Bs, device=dev, requires_grad=True)
+    rs = torch.randn(Ts, Bs, device=dev)
+    td = TDLambda(Ts, Bs)
+    rows.append(dict(op="td_lambda_small", shape=f"T={Ts} B={Bs}", **host_path(lambda: td(vs, rs), [vs])))
+    ln = torch.randn(Bs, Ns, device=dev, requires_grad=True)
+    lo, act = torch.randn(Bs, Ns, device=dev), torch.randint(0, Ns, (Bs,), device=dev)
+    vn = torch.randn(Bs, device=dev, requires_grad=True)
+    vo, adv, ret = (torch.randn(Bs, device=dev) for _ in range(3))
+    ppo = PPO(Bs, Ns, sync_info=False)
+    rows.append(dict(op="ppo_small", shape=f"B={Bs} N={Ns}", **host_path(lambda: sum(ppo(ln, lo, act, vn, vo, adv, ret)[0]), [ln, vn])))
+    xs = torch.randn(Ts + 1, Bs, device=dev, requires_grad=True)
+    rows.append(dict(op="torch_floor_small", shape=f"y = 2 x on ({Ts + 1},{Bs}); y.backward(g)", **host_path(lambda: xs * 2.0, [xs]),
+                     note="torch's own smallest op pair through the same autograd engine: the floor of any eager forward + backward here"))
+    if not QUIET:
+        for r_ in rows[-4:]:
+            print(json.dumps(r_), flush=True)
     S, B, I, H, L = 64, 3, 1792, 384, 3
     m = LSTM(S, B, I, H, L).to(dev)
     x = torch.randn(S, B, I, device=dev, requires_grad=True)
