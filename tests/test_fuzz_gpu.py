@@ -277,6 +277,32 @@ def test_fuzz_scatter_and_padding():
             assert all(torch.equal(a, b) for a, b in zip(xs, unpad(new_x, shp)))
 
 
+def test_fuzz_scatter_backward_kernels():
+    """Round 6: the three backward paths of ScatterConnection -- plane kernel (tune key 40 = 1), spatial-tile kernel wherever it
+    applies (2), the rule (0) -- on random shapes (W a multiple of 4 or not: the tile kernel needs 16-byte rows and falls back;
+    maps from 1 x 4 to 96 x 96, up to 300 entities, out-of-range locations) against torch's gather: the same bits."""
+    import cabi as C
+    import hpc_torch_utils_network as NW
+    rng = np.random.default_rng(66)
+    s = torch.cuda.current_stream().cuda_stream
+    try:
+        for B, M, N, H, W in shapes(rng, (1, 24), (1, 300), (1, 96), (1, 96), (1, 96)):
+            if rng.random() < 0.7:
+                W = max(4, W // 4 * 4)
+            go = G(f32(rng, B, N, H, W))
+            loc = torch.from_numpy(np.stack([rng.integers(-1, H + 1, (B, M)), rng.integers(-1, W + 1, (B, M))], -1).astype(np.int64)).to(DEV)
+            ok = (loc[..., 0] >= 0) & (loc[..., 0] < H) & (loc[..., 1] >= 0) & (loc[..., 1] < W)
+            want = (go.permute(0, 2, 3, 1)[torch.arange(B, device=DEV)[:, None], loc[..., 0].clamp(0, H - 1), loc[..., 1].clamp(0, W - 1)]
+                    * ok[..., None]).cpu()
+            for key in (1, 2, 0):
+                NW.tune_set(40, key)
+                gx = torch.full((B, M, N), float("nan"), device=DEV)
+                assert C.lib.hpc_rll_scatter_connection_backward(go.data_ptr(), loc.data_ptr(), gx.data_ptr(), B, M, N, H, W, s) == 0
+                assert torch.equal(gx.cpu(), want), (B, M, N, H, W, key)
+    finally:
+        NW.tune_set(40, 0)
+
+
 def test_fuzz_lstm():
     from hpc_rll.torch_utils.network.rnn import LSTM
     rng = np.random.default_rng(7)
