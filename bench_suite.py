@@ -450,7 +450,17 @@ def suite_td(B=1 << 18, N=64, nstep=5, n_atom=51, tau=32):
     ri, di, wi = reward[:, :Bi].contiguous(), done[:Bi].contiguous(), weight[:Bi].contiguous()
     add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: m(qi, nqi, ai, nai, ri, di, rq, 0.99, 1.0, wi)[0], [qi]),
                                          (Bi * (2 * tau * 128 + 8 * tau + per_sample), Bi * (4 * tau * N + 4 * tau))) for x in pair])
+    # round 6: the same loss on the quantile-innermost layout (layout='bnt': q (B,N,tau)) -- a sample's quantiles are ONE row
+    qb = qi.detach().permute(1, 2, 0).contiguous().requires_grad_(True)
+    nqb = nqi.permute(1, 2, 0).contiguous()
     del qi, nqi
+    mb = IQNNStepTDError(tau, tau, nstep, Bi, N, layout='bnt')
+    t_f, t_b = fwd_bwd(lambda: mb(qb, nqb, ai, nai, ri, di, rq, 0.99, 1.0, wi)[0], [qb])
+    by_f, by_b = Bi * (2 * line(4 * tau) + 8 * tau + per_sample), Bi * (4 * tau * N + 4 * tau)
+    report("iqn_nstep_td_bnt", f"tau=tau'={tau} B={Bi} N={N}, q (B,N,tau)", t_f, by_f, t_b, by_b)
+    rows[-1].update(note="IQNNStepTDError(layout='bnt'), not in the reference: the reference layout's forward is the iqn_nstep_td row")
+    add_kernel_times(*[x for pair in zip(fwd_bwd_graph(lambda: mb(qb, nqb, ai, nai, ri, di, rq, 0.99, 1.0, wi)[0], [qb]), (by_f, by_b)) for x in pair])
+    del qb, nqb
 
     qq = torch.randn(B, N, tau, device=dev, generator=g, requires_grad=True)
     nqq = torch.randn(B, N, tau, device=dev, generator=g)

@@ -3,7 +3,7 @@
 
 #include "hpc_rll_hip.h"
 
-extern "C" int hpc_rll_abi_version(void) { return 5; }
+extern "C" int hpc_rll_abi_version(void) { return 6; }
 
 extern "C" const char* hpc_rll_status_string(int status) {
     switch (status) {

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void iqn_fwd_kernel(
     const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
     const float* __restrict__ rq, const float* __restrict__ weight, const float* __restrict__ value_gamma,
     float* __restrict__ td_err, float* __restrict__ buf, float* __restrict__ partials, int tau, int tau_p,
-    int nstep, int B, int N, float gamma, float gamma_n, float kappa, float scale, const ScanFold fold) {
+    int nstep, int B, int N, float gamma, float gamma_n, float kappa, float scale, const ScanFold fold, int bnt) {
     wave_per_sample(B, partials, fold, [&](int b, int lane) -> float {
         const float R = nstep_return1(reward, B, nstep, gamma, b);
         const float vg = (value_gamma ? value_gamma[b] : gamma_n) * (1.f - done[b]);
@@ -103,11 +103,11 @@ __global__ __launch_bounds__(256) void iqn_fwd_kernel(
         const float inv_tp = 1.f / (float)tau_p;
         float loss = 0.f;
         for (int i = lane; i < tau; i += 64) {
-            const float qi = q[((size_t)i * B + b) * N + a];
+            const float qi = bnt ? q[((size_t)b * N + a) * tau + i] : q[((size_t)i * B + b) * N + a];
             const float rho = rq[(size_t)i * B + b];
             float li = 0.f, gi = 0.f;
             for (int j = 0; j < tau_p; ++j) {
-                const float tgt = fmaf(vg, next_q[((size_t)j * B + b) * N + na], R);
+                const float tgt = fmaf(vg, bnt ? next_q[((size_t)b * N + na) * tau_p + j] : next_q[((size_t)j * B + b) * N + na], R);
                 const float e = tgt - qi;
                 const float ae = fabsf(e);
                 const float hub = (ae <= kappa) ? 0.5f * e * e : kappa * (ae - 0.5f * kappa);
@@ -489,7 +489,9 @@ __global__ __launch_bounds__(256) void dist_nstep_fwd_batch_kernel(
     publish_sums<1, 256>(tot, partials, fold);
 }
 
-template <int G>
+// BNT (round 6): q (B,N,tau), next_q (B,N,tau') -- the sample's quantiles are ONE contiguous row (128 bytes at tau = 32) instead of
+// tau values a whole (B,N) plane apart: 2 lines per sample instead of 2 tau.  Same arithmetic, same buf (B,tau).
+template <int G, bool BNT>
 __global__ __launch_bounds__(256) void iqn_fwd_group_kernel(
     const float* __restrict__ q, const float* __restrict__ next_q, const int64_t* __restrict__ action,
     const int64_t* __restrict__ next_action, const float* __restrict__ reward, const float* __restrict__ done,
@@ -506,8 +508,8 @@ __global__ __launch_bounds__(256) void iqn_fwd_group_kernel(
             if (gl < tau) rho = rq[(size_t)gl * B + b];
             R = nstep_return1(reward, B, nstep, gamma, b);
             vg = vgm * (1.f - dn);
-            if (gl < tau) qi = q[((size_t)gl * B + b) * N + a];
-            if (gl < tau_p) tgt = fmaf(vg, next_q[((size_t)gl * B + b) * N + na], R);
+            if (gl < tau) qi = BNT ? q[((size_t)b * N + a) * tau + gl] : q[((size_t)gl * B + b) * N + a];
+            if (gl < tau_p) tgt = fmaf(vg, BNT ? next_q[((size_t)b * N + na) * tau_p + gl] : next_q[((size_t)gl * B + b) * N + na], R);
         }
         const float inv_tp = 1.f / (float)tau_p;
         // The pair loop is VALU-bound (tau * tau' pairs per sample, a wave64 instruction costs 4 cycles): two targets per
@@ -925,12 +927,11 @@ extern "C" int hpc_rll_dist_nstep_td_backward(const float* grad_loss, const floa
     return onehot_scatter(grad_loss, buf, action, grad_dist, B, N, n_atom, (hipStream_t)stream);
 }
 
-extern "C" int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_q, const int64_t* action,
-                                            const int64_t* next_n_action, const float* reward, const float* done,
-                                            const float* replay_quantiles, const float* weight,
-                                            const float* value_gamma, float* loss, float* td_err, float* buf,
-                                            float* partials, int tau, int tau_prime, int nstep, int B, int N,
-                                            float gamma, float kappa, float scale, void* stream) {
+namespace hpc_rll { namespace {
+int iqn_forward_impl(const float* q, const float* next_n_q, const int64_t* action, const int64_t* next_n_action,
+                     const float* reward, const float* done, const float* replay_quantiles, const float* weight,
+                     const float* value_gamma, float* loss, float* td_err, float* buf, float* partials, int tau,
+                     int tau_prime, int nstep, int B, int N, float gamma, float kappa, float scale, bool bnt, void* stream) {
     if (tau <= 0 || tau_prime <= 0 || nstep < 0 || B < 0 || N <= 0 || !loss || !(kappa > 0.f)) return HPC_RLL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) return (int)hipMemsetAsync(loss, 0, sizeof(float), st);
@@ -945,20 +946,55 @@ extern "C" int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_
     if (gmax <= 64) {
         const int G = group_lanes(gmax);
 #define HPC_RLL_IQN_G(G_)                                                                                               \
-        if (G == G_)                                                                                                    \
-            hipLaunchKernelGGL(iqn_fwd_group_kernel<G_>, dim3(blocks), dim3(256), 0, st, q, next_n_q, action,            \
-                               next_n_action, reward, done, replay_quantiles, weight, value_gamma, td_err, buf, partials, \
-                               tau, tau_prime, nstep, B, N, gamma, gamma_n, kappa, scale, fold);
+        if (G == G_) {                                                                                                  \
+            if (bnt)                                                                                                    \
+                hipLaunchKernelGGL((iqn_fwd_group_kernel<G_, true>), dim3(blocks), dim3(256), 0, st, q, next_n_q, action, \
+                                   next_n_action, reward, done, replay_quantiles, weight, value_gamma, td_err, buf,     \
+                                   partials, tau, tau_prime, nstep, B, N, gamma, gamma_n, kappa, scale, fold);          \
+            else                                                                                                        \
+                hipLaunchKernelGGL((iqn_fwd_group_kernel<G_, false>), dim3(blocks), dim3(256), 0, st, q, next_n_q, action, \
+                                   next_n_action, reward, done, replay_quantiles, weight, value_gamma, td_err, buf,     \
+                                   partials, tau, tau_prime, nstep, B, N, gamma, gamma_n, kappa, scale, fold);          \
+        }
         HPC_RLL_IQN_G(8) HPC_RLL_IQN_G(16) HPC_RLL_IQN_G(32) HPC_RLL_IQN_G(64)
 #undef HPC_RLL_IQN_G
     } else {
         hipLaunchKernelGGL(iqn_fwd_kernel, dim3(blocks), dim3(256), 0, st, q, next_n_q, action, next_n_action, reward,
                            done, replay_quantiles, weight, value_gamma, td_err, buf, partials, tau, tau_prime, nstep, B,
-                           N, gamma, gamma_n, kappa, scale, fold);
+                           N, gamma, gamma_n, kappa, scale, fold, bnt ? 1 : 0);
     }
     const int rc = last_error();
     if (rc || fold.out) return rc;
     return finalize_sums(partials, blocks, 1, &scale, loss, st);
+}
+} }  // namespace hpc_rll::(anonymous)
+
+extern "C" int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_q, const int64_t* action,
+                                            const int64_t* next_n_action, const float* reward, const float* done,
+                                            const float* replay_quantiles, const float* weight,
+                                            const float* value_gamma, float* loss, float* td_err, float* buf,
+                                            float* partials, int tau, int tau_prime, int nstep, int B, int N,
+                                            float gamma, float kappa, float scale, void* stream) {
+    return iqn_forward_impl(q, next_n_q, action, next_n_action, reward, done, replay_quantiles, weight, value_gamma, loss,
+                            td_err, buf, partials, tau, tau_prime, nstep, B, N, gamma, kappa, scale, false, stream);
+}
+// ABI 6: the same loss on q (B,N,tau), next_n_q (B,N,tau') -- the layout of the QR-DQN op; replay_quantiles stays (tau,B)
+extern "C" int hpc_rll_iqn_nstep_td_forward_bnt(const float* q, const float* next_n_q, const int64_t* action,
+                                                const int64_t* next_n_action, const float* reward, const float* done,
+                                                const float* replay_quantiles, const float* weight,
+                                                const float* value_gamma, float* loss, float* td_err, float* buf,
+                                                float* partials, int tau, int tau_prime, int nstep, int B, int N,
+                                                float gamma, float kappa, float scale, void* stream) {
+    return iqn_forward_impl(q, next_n_q, action, next_n_action, reward, done, replay_quantiles, weight, value_gamma, loss,
+                            td_err, buf, partials, tau, tau_prime, nstep, B, N, gamma, kappa, scale, true, stream);
+}
+// grad_q (B,N,tau): one-hot rows of tau values at [a_b * tau, a_b * tau + tau) -- the QR-DQN backward's shape
+extern "C" int hpc_rll_iqn_nstep_td_backward_bnt(const float* grad_loss, const float* buf, const int64_t* action,
+                                                 float* grad_q, int tau, int B, int N, void* stream) {
+    if (tau <= 0 || B < 0 || N <= 0) return HPC_RLL_EINVAL;
+    if (B == 0) return HPC_RLL_OK;
+    if (!grad_loss || !buf || !action || !grad_q) return HPC_RLL_EINVAL;
+    return onehot_scatter(grad_loss, buf, action, grad_q, B, N, tau, (hipStream_t)stream);
 }
 
 extern "C" int hpc_rll_iqn_nstep_td_backward(const float* grad_loss, const float* buf, const int64_t* action,

@@ -1585,9 +1585,12 @@ extern "C" int hpc_rll_scatter_connection_backward(const float* grad_out, const 
                                                    int B, int M, int N, int H, int W, void* stream) {
     if (B < 0 || M < 0 || N < 0 || H < 0 || W < 0) return HPC_RLL_EINVAL;
     if ((size_t)B * M * N == 0) return HPC_RLL_OK;
-    if (!grad_out || !location || !grad_x) return HPC_RLL_EINVAL;
+    if (!location || !grad_x) return HPC_RLL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
+    // an empty map: every location is out of range, every gradient row is zero (grad_out has no elements and may be null)
+    if (HW == 0) return (int)hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)B * M * N, st);
+    if (!grad_out) return HPC_RLL_EINVAL;
     const long plane_bytes = HW * 4;
     // Which kernel (round 6, profiles/r06_scatter_bwd_probe.txt).  The plane kernel writes NG*4-byte pieces of every entity's row
     // from N/NG workgroups; where those pieces are 16 bytes or less (maps of 4096 cells and more) AND the entity rows are a

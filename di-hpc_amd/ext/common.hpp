@@ -36,7 +36,7 @@ using OptTensor = std::optional<Tensor>;
 using OptList = std::vector<OptTensor>;   // python lists that may hold None
 namespace ag = torch::autograd;
 
-constexpr int kAbiVersion = 5;   // 3: + kernel timing, packed / grouped pad, last GAE configuration (round 3); 4: + lstm_*_y (round 4); 5: tune table, retired keys (round 5)
+constexpr int kAbiVersion = 6;   // 3: + kernel timing, packed / grouped pad, last GAE configuration (round 3); 4: + lstm_*_y (round 4); 5: tune table, retired keys (round 5); 6: + iqn_*_bnt (round 6)
 
 // torch's current stream of `dev` as the void* the C ABI takes.  (Tensors of a ROCm build carry DeviceType::CUDA
 // while c10::hip::HIPStream carries DeviceType::HIP; the underlying thread-local current stream is the same.)

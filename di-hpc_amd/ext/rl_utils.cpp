@@ -595,15 +595,21 @@ struct DistFn : public ag::Function<DistFn> {
 
 // =========================================================================================================== IQN
 struct IqnDims { int64_t tau, tau_p, B, N, nstep; at::Device dev; };
+// bnt (round 6, not in the reference): q (B,N,tau), next_n_q (B,N,tau') -- the quantile axis innermost, QR-DQN's layout
 IqnDims iqn_check(const Tensor& q, const Tensor& nq, const Tensor& action, const Tensor& naction, const Tensor& reward,
-                  const Tensor& done, const Tensor& rq, const OptTensor& weight, const OptTensor& vg) {
+                  const Tensor& done, const Tensor& rq, const OptTensor& weight, const OptTensor& vg, bool bnt = false) {
     req(q, "q");
-    TORCH_CHECK(q.dim() == 3, "q: expected (tau,B,N), got ", q.sizes());
-    const int64_t tau = q.size(0), B = q.size(1), N = q.size(2);
+    TORCH_CHECK(q.dim() == 3, "q: expected ", bnt ? "(B,N,tau)" : "(tau,B,N)", ", got ", q.sizes());
+    const int64_t tau = bnt ? q.size(2) : q.size(0), B = bnt ? q.size(0) : q.size(1), N = bnt ? q.size(1) : q.size(2);
     const at::Device dev = q.device();
     req(nq, "next_n_q", dev);
-    TORCH_CHECK(nq.dim() == 3 && nq.size(1) == B && nq.size(2) == N, "next_n_q: shape ", nq.sizes(), ", expected (tau',",
-                B, ",", N, ")");
+    if (bnt) {
+        TORCH_CHECK(nq.dim() == 3 && nq.size(0) == B && nq.size(1) == N, "next_n_q: shape ", nq.sizes(), ", expected (", B, ",",
+                    N, ",tau')");
+    } else {
+        TORCH_CHECK(nq.dim() == 3 && nq.size(1) == B && nq.size(2) == N, "next_n_q: shape ", nq.sizes(), ", expected (tau',",
+                    B, ",", N, ")");
+    }
     req(action, "action", dev, {B}, at::kLong);
     req(naction, "next_n_action", dev, {B}, at::kLong);
     const int64_t nstep = check_nstep_reward(reward, B, dev);
@@ -612,14 +618,14 @@ IqnDims iqn_check(const Tensor& q, const Tensor& nq, const Tensor& action, const
     TORCH_CHECK(rq.numel() == tau * B, "replay_quantiles: ", rq.sizes(), " does not hold tau*B = ", tau * B, " values");
     req_opt(weight, "weight", dev, {B});
     req_opt(vg, "value_gamma", dev, {B});
-    return {tau, nq.size(0), B, N, nstep, dev};
+    return {tau, bnt ? nq.size(2) : nq.size(0), B, N, nstep, dev};
 }
 void iqn_forward_launch(const IqnDims& d, const Tensor& q, const Tensor& nq, const Tensor& action, const Tensor& naction,
                         const Tensor& reward, const Tensor& done, const Tensor& rq, const OptTensor& weight,
                         const OptTensor& vg, const Tensor& loss, const Tensor& td_err, const Tensor& grad_buf,
-                        double gamma, double kappa, std::optional<double> scale) {
+                        double gamma, double kappa, std::optional<double> scale, bool bnt = false) {
     Tensor partials = new_f32({hpc_rll_partials_floats(d.B)}, d.dev);
-    check(hpc_rll_iqn_nstep_td_forward(fptr(q), fptr(nq), iptr(action), iptr(naction), fptr(reward), fptr(done), fptr(rq),
+    check((bnt ? hpc_rll_iqn_nstep_td_forward_bnt : hpc_rll_iqn_nstep_td_forward)(fptr(q), fptr(nq), iptr(action), iptr(naction), fptr(reward), fptr(done), fptr(rq),
                                        fptr(weight), fptr(vg), fmut(loss), fmut(td_err), fmut(grad_buf), fmut(partials),
                                        to_int(d.tau, "tau"), to_int(d.tau_p, "tau'"), to_int(d.nstep, "nstep"),
                                        to_int(d.B, "B"), to_int(d.N, "N"), (float)gamma, (float)kappa,
@@ -673,24 +679,34 @@ struct IqnFn : public ag::Function<IqnFn> {
     static ag::tensor_list forward(ag::AutogradContext* ctx, const Tensor& q, const Tensor& nq, const Tensor& action,
                                    const Tensor& naction, const Tensor& reward, const Tensor& done, const Tensor& rq,
                                    const OptTensor& weight, const OptTensor& vg, double gamma, double kappa,
-                                   std::optional<double> scale) {
-        const IqnDims d = iqn_check(q, nq, action, naction, reward, done, rq, weight, vg);
+                                   std::optional<double> scale, bool bnt) {
+        const IqnDims d = iqn_check(q, nq, action, naction, reward, done, rq, weight, vg, bnt);
         c10::DeviceGuard g(d.dev);
         Tensor loss = new_f32({1}, d.dev), td_err = new_f32({d.B}, d.dev), grad_buf = new_f32({d.B, d.tau}, d.dev);
         iqn_forward_launch(d, q, nq, action, naction, reward, done, rq, weight, vg, loss, td_err, grad_buf, gamma, kappa,
-                           scale);
+                           scale, bnt);
         ctx->save_for_backward({grad_buf, action});
         ctx->saved_data["N"] = d.N;
+        ctx->saved_data["bnt"] = bnt;
         ctx->mark_non_differentiable({td_err});
         return {loss, td_err};
     }
     static ag::tensor_list backward(ag::AutogradContext* ctx, ag::tensor_list grads) {
-        ag::tensor_list out(12);
+        ag::tensor_list out(13);
         if (!ctx->needs_input_grad(0)) return out;
         const auto saved = ctx->get_saved_variables();
         const Tensor &grad_buf = saved[0], &action = saved[1];
         const at::Device dev = grad_buf.device();
         c10::DeviceGuard g(dev);
+        if (ctx->saved_data["bnt"].toBool()) {   // grad_q (B,N,tau): one-hot rows of tau values
+            const int64_t B = grad_buf.size(0), tau = grad_buf.size(1), N = ctx->saved_data["N"].toInt();
+            Tensor gq = new_f32({B, N, tau}, dev);
+            check(hpc_rll_iqn_nstep_td_backward_bnt(fptr(grad1(grads[0], dev, "grad_loss")), fptr(grad_buf), iptr(action), fmut(gq),
+                                                    (int)tau, (int)B, (int)N, stream_of(dev)),
+                  "hpc_rll_iqn_nstep_td_backward_bnt");
+            out[0] = gq;
+            return out;
+        }
         Tensor gq = new_f32({grad_buf.size(1), grad_buf.size(0), ctx->saved_data["N"].toInt()}, dev);
         iqn_backward_launch(grad1(grads[0], dev, "grad_loss"), grad_buf, action, gq);
         out[0] = gq;
@@ -898,11 +914,11 @@ PYBIND11_MODULE(hpc_rl_utils, m) {
           py::arg("scale") = py::none());
     m.def("iqn_nstep_td", [](const Tensor& q, const Tensor& nq, const Tensor& action, const Tensor& naction,
                              const Tensor& reward, const Tensor& done, const Tensor& rq, const OptTensor& weight,
-                             const OptTensor& vg, double gamma, double kappa, std::optional<double> scale) {
-        return IqnFn::apply(q, nq, action, naction, reward, done, rq, weight, vg, gamma, kappa, scale);
+                             const OptTensor& vg, double gamma, double kappa, std::optional<double> scale, bool bnt) {
+        return IqnFn::apply(q, nq, action, naction, reward, done, rq, weight, vg, gamma, kappa, scale, bnt);
     }, py::arg("q"), py::arg("next_n_q"), py::arg("action"), py::arg("next_n_action"), py::arg("reward"), py::arg("done"),
           py::arg("replay_quantiles"), py::arg("weight") = py::none(), py::arg("value_gamma") = py::none(),
-          py::arg("gamma") = 0.99, py::arg("kappa") = 1.0, py::arg("scale") = py::none());
+          py::arg("gamma") = 0.99, py::arg("kappa") = 1.0, py::arg("scale") = py::none(), py::arg("bnt") = false);
     m.def("qrdqn_nstep_td", [](const Tensor& q, const Tensor& nq, const Tensor& action, const Tensor& naction,
                                const Tensor& reward, const Tensor& done, const OptTensor& weight, const OptTensor& vg,
                                double gamma, std::optional<double> tau_value, std::optional<double> scale) {

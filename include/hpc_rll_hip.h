@@ -219,6 +219,17 @@ int hpc_rll_iqn_nstep_td_forward(const float* q, const float* next_n_q, const in
                                  int nstep, int B, int N, float gamma, float kappa, float scale, void* stream);
 int hpc_rll_iqn_nstep_td_backward(const float* grad_loss, const float* buf, const int64_t* action, float* grad_q,
                                   int tau, int B, int N, void* stream);
+/* ABI 6 (not in the reference): the same loss with the quantile axis INNERMOST -- q (B,N,tau), next_n_q (B,N,tau'), grad_q
+ * (B,N,tau), the layout of the QR-DQN op (rl_utils/entry.h:121-129); replay_quantiles stays (tau,B), buf (B,tau).  A sample's
+ * quantiles are one contiguous row instead of tau values a (B,N) plane apart: 2 cache lines per sample instead of 2 tau
+ * (iqn_nstep_td_error_kernel.h:11-70 reads the (tau,B,N) layout). */
+int hpc_rll_iqn_nstep_td_forward_bnt(const float* q, const float* next_n_q, const int64_t* action,
+                                     const int64_t* next_n_action, const float* reward, const float* done,
+                                     const float* replay_quantiles, const float* weight, const float* value_gamma,
+                                     float* loss, float* td_err, float* buf, float* partials, int tau, int tau_prime,
+                                     int nstep, int B, int N, float gamma, float kappa, float scale, void* stream);
+int hpc_rll_iqn_nstep_td_backward_bnt(const float* grad_loss, const float* buf, const int64_t* action, float* grad_q,
+                                      int tau, int B, int N, void* stream);
 
 /* QR-DQN n-step TD -- replaces QRDQNNStepTDErrorForward/Backward (rl_utils/entry.h:121-129).
  * q,next_n_q (B,N,tau); tau_value = the `tau` the caller passes to the oracle (the reference kernel hard

@@ -6,7 +6,7 @@
 #include "hpc_rll_hip.h"
 
 int main(void) {
-    if (hpc_rll_abi_version() != 5) return 1;
+    if (hpc_rll_abi_version() != 6) return 1;
     if (strcmp(hpc_rll_status_string(HPC_RLL_OK), hpc_rll_status_string(HPC_RLL_EINVAL)) == 0) return 2;
     /* argument validation happens before any device work: invalid sizes come back as status codes */
     if (hpc_rll_gae_forward(NULL, NULL, NULL, NULL, -1, 4, 0.99f, NULL) != HPC_RLL_EINVAL) return 3;

@@ -62,7 +62,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     _fn.restype = _res
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 if lib.hpc_rll_abi_version() != ABI_VERSION and not os.environ.get("HPC_RLL_LIB"):   # A/B tools load older builds on purpose
     raise ImportError(f"libhpc_rll_hip.so ABI {lib.hpc_rll_abi_version()} != expected {ABI_VERSION}; rebuild")
 

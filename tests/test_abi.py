@@ -134,7 +134,7 @@ def test_c_program_links_and_runs(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and "abi 5 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    assert r.returncode == 0 and "abi 6 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
 def test_xcd_relabelling_is_a_permutation():

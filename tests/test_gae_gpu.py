@@ -65,7 +65,7 @@ def test_native_library_is_loaded():
     import hpc_rl_utils
     maps = open("/proc/self/maps").read()
     assert "libhpc_rll_hip.so" in maps
-    assert hpc_rl_utils.abi_version() == 5
+    assert hpc_rl_utils.abi_version() == 6
     assert "hpc_rl_utils.so" in maps            # the compiled torch extension, not a python shim
 
 

@@ -536,6 +536,44 @@ def test_iqn_oracle_reference_shape(quirks):
     assert grad_err(q64.grad.numpy(), dq.grad.cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("tau,taup,B,N", [(32, 32, 4099, 64), (33, 34, 64, 8), (5, 7, 1000, 6), (64, 48, 513, 17), (80, 70, 130, 9), (8, 8, 9, 3),
+                                         (1, 1, 70, 2), (16, 64, 257, 64)])
+def test_iqn_quantile_innermost_layout(tau, taup, B, N):
+    """Round 6, ``layout='bnt'`` (not in the reference): q (B,N,tau), next_n_q (B,N,tau') -- a sample's quantiles are one
+    contiguous row.  Against the default (tau,B,N) layout on the permuted tensors: the same kernel arithmetic on the same
+    values, so loss, per-sample errors and the gradient (compared as grad_bnt.permute(2,0,1)) are the SAME BITS; and against
+    the fp64 oracle.  Every group width (tau 1 ... 64), tau != tau', the wave-per-sample kernel (tau > 64), golden cases
+    of the reference through the new layout, weights / value_gamma present and absent."""
+    from hpc_rll.rl_utils.td import IQNNStepTDError
+    T, kappa, gamma = 4, 0.8, 0.93
+    rng = np.random.default_rng(tau * 131 + taup)
+    q, nq = f32(rng, tau, B, N), f32(rng, taup, B, N)
+    a, na = rng.integers(0, N, B).astype(np.int64), rng.integers(0, N, B).astype(np.int64)
+    r, done, rq = f32(rng, T, B), (rng.random(B) < 0.3).astype(np.float32), rng.random((tau, B)).astype(np.float32)
+    w = rng.random(B).astype(np.float32) if tau % 2 == 0 else None
+    vg = (0.9 + 0.1 * rng.random(B)).astype(np.float32) if taup % 2 == 0 else None
+    Gw, Gvg = (None if w is None else G(w)), (None if vg is None else G(vg))
+    d0 = G(q, True)
+    l0, p0 = IQNNStepTDError(tau, taup, T, B, N)(d0, G(nq), G(a), G(na), G(r), G(done), G(rq), gamma, kappa, Gw, Gvg)
+    l0.backward()
+    d1 = G(np.ascontiguousarray(q.transpose(1, 2, 0)), True)
+    l1, p1 = IQNNStepTDError(tau, taup, T, B, N, layout='bnt')(d1, G(np.ascontiguousarray(nq.transpose(1, 2, 0))), G(a), G(na), G(r),
+                                                             G(done), G(rq), gamma, kappa, Gw, Gvg)
+    l1.backward()
+    assert d1.grad.shape == (B, N, tau)
+    assert l1.item() == l0.item() and torch.equal(p1, p0)
+    assert torch.equal(d1.grad.permute(2, 0, 1), d0.grad)
+    q64 = D(q, True)
+    l64, p64 = R.iqn_nstep_td_error(q64, D(nq), torch.from_numpy(a), torch.from_numpy(na), D(r), D(done), D(rq),
+                                    None if w is None else D(w), gamma, kappa, None if vg is None else D(vg))
+    l64.backward()
+    assert rel_err(l64.item(), l1.item()) < 2e-5
+    assert rel_err(p64.detach().numpy(), p1.cpu().numpy()) < 2e-5
+    assert grad_err(q64.grad.numpy().transpose(1, 2, 0), d1.grad.cpu().numpy()) < 2e-5
+    with pytest.raises(RuntimeError):      # the default layout's shape is rejected in the new one (B read as tau)
+        IQNNStepTDError(tau, taup, T, B, N, layout='bnt')(G(q), G(nq), G(a), G(na), G(r), G(done), G(rq), gamma, kappa)
+
+
 def test_qrdqn_golden(golden):
     from hpc_rll.rl_utils.td import QRDQNNStepTDError
     g = golden("qrdqn")

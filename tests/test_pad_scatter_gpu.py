@@ -568,3 +568,16 @@ def test_scatter_backward_spatial_tile_kernel_bit_exact(B, M, N, H, W):
     want = go.permute(0, 2, 3, 1)[torch.arange(B, device=DEV)[:, None], loc[..., 0].clamp(0, H - 1), loc[..., 1].clamp(0, W - 1)] * ok[..., None]
     assert torch.equal(outs[1], want.cpu())
     assert torch.equal(outs[2], outs[1]) and torch.equal(outs[0], outs[1])
+
+
+def test_scatter_backward_of_an_empty_map_is_zero():
+    """C ABI edge (round 6): H * W == 0 -- every location is out of range, the gradient rows are zeros (until round 5 the launcher
+    divided by the plane size)."""
+    import cabi as C
+    B, M, N = 3, 5, 8
+    loc = torch.zeros(B, M, 2, dtype=torch.int64, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    for H, W in ((0, 4), (4, 0), (0, 0)):
+        gx = torch.full((B, M, N), float("nan"), device=DEV)
+        assert C.lib.hpc_rll_scatter_connection_backward(0, loc.data_ptr(), gx.data_ptr(), B, M, N, H, W, s) == 0
+        assert float(gx.abs().max()) == 0.0
