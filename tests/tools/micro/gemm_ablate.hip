@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "gemm_f32.hpp"
@@ -21,6 +22,7 @@ int g_gemm_xcd = 1, g_gemm_bk = 0, g_gemm_tile256 = 0, g_gemm_lat_target = 256, 
     g_gemm_big_target = 768;
 }
 using namespace hpc_rll;
+static int g_dyn_lds = 0;   // extra dynamic LDS per workgroup: > 80 KB forces ONE workgroup per CU (round 6: what a lone 4-wave workgroup reaches)
 
 // Shader clock during a launch: one wave per CU-sized slice of the grid spins on s_memtime (shader cycles) against
 // wall_clock64 (constant 100 MHz) while the GEMM runs on another stream -- effective GHz = d(cycles) / d(wall) * 0.1.
@@ -43,14 +45,15 @@ static double run(const char* tag, const float* A, const float* B, float* C, int
     static_assert(!DMA || LAYOUT == 2, "the LDS-DMA kernel is the NT form");
     auto k = gemm_f32_kernel<BM, BN, BK, WM, WN, (DMA ? kDmaK : LAYOUT == 1 ? kContigMN : kContigK),
                              (DMA ? kDmaK : LAYOUT == 2 ? kContigK : kContigMN), true, ABL, NW>;
+    if (g_dyn_lds) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, g_dyn_lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), 0, 0, g);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), g_dyn_lds, 0, g);
     double best = 1e30;
     for (int r = 0; r < 5; ++r) {
         hipEventRecord(e0, 0);
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), 0, 0, g);
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), g_dyn_lds, 0, g);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -63,9 +66,9 @@ static double run(const char* tag, const float* A, const float* B, float* C, int
     static long long* d_clk = nullptr;
     if (!s2) { hipStreamCreate(&s2); hipMalloc(&d_clk, 16); }
     const int reps = (int)(25.0 / best) + 1;
-    for (int i = 0; i < reps / 4 + 1; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), 0, 0, g);   // get going first
+    for (int i = 0; i < reps / 4 + 1; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), g_dyn_lds, 0, g);   // get going first
     hipLaunchKernelGGL(clock_probe, dim3(1), dim3(64), 0, s2, d_clk, 15);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), 0, 0, g);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(NW * 64), g_dyn_lds, 0, g);
     hipDeviceSynchronize();
     long long h[2];
     hipMemcpy(h, d_clk, 16, hipMemcpyDeviceToHost);
@@ -130,6 +133,7 @@ int main() {
         long long h[2]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
         printf("idle device: shader clock %.2f GHz\n", (double)h[0] / (double)h[1] * 0.1);
     }
+    const bool lone = getenv("LONE") != nullptr;
     const int shapes[2][3] = {{4096, 4096, 4096}, {65536, 4096, 1024}};
     for (auto& s : shapes) {
         const int M = s[0], N = s[1], K = s[2];
@@ -147,6 +151,20 @@ int main() {
         }
         hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
         hipMemcpy(B, h.data(), (size_t)K * N * 4, hipMemcpyHostToDevice);
+        if (lone) {
+            // ONE workgroup per CU (96 KB of dynamic LDS on top): 8 waves of 64x32 (the row-block backward's product shape) against 4 waves of 64x64
+            for (int pad : {0, 96 * 1024}) {
+                g_dyn_lds = pad;
+                printf("--- dynamic LDS pad %d KB (%s)\n", pad / 1024, pad ? "one workgroup per CU" : "as many workgroups per CU as fit");
+                run<128, 128, 32, 2, 2, 0, 2, 4, true>("128x128x32 NT LDS-DMA 4 waves (64x64)", A, B, C, M, N, K, 1);
+                run<128, 128, 16, 2, 2, 0, 2, 4, true>("128x128x16 NT LDS-DMA 4 waves (64x64)", A, B, C, M, N, K, 1);
+                run<128, 128, 32, 2, 1, 0, 2, 8, true>("128x128x32 NT LDS-DMA 8 waves (64x32)", A, B, C, M, N, K, 1);
+                if (!pad) run<256, 128, 32, 2, 2, 0, 2, 8, true>("256x128x32 NT LDS-DMA 8 waves", A, B, C, M, N, K, 1);   // (96 KB of tiles: no room for the pad)
+            }
+            g_dyn_lds = 0;
+            hipFree(A); hipFree(B); hipFree(C);
+            continue;
+        }
         run<128, 128, 16, 2, 2, 0>("128x128x16 full", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 1>("128x128x16 ABL1 mfma+ds_read", A, B, C, M, N, K, 1);
         run<128, 128, 16, 2, 2, 2>("128x128x16 ABL2 +global prefetch", A, B, C, M, N, K, 1);
